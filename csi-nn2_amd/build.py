@@ -1,0 +1,102 @@
+"""Build every native artefact of the MI355X backend, in-tree.
+
+    python csi-nn2_amd/build.py [--force] [--no-oracle]
+
+Artefacts (all git-ignored, all travel to the GPU box with the snapshot):
+  csi-nn2_amd/lib/libshl_mi355x.so      HIP kernels + C-ABI (hipcc --offload-arch=gfx950)
+  csi-nn2_amd/lib/libcsinn_nn2.so       stand-alone csinn_* front-end + graph executor (gcc)
+  csi-nn2_amd/lib/libshl_mi355x_opt.so  source/mi355x_opt backend (gcc), links the HIP library
+  oracle/libshl_ref_oracle.so           CPU restatement of the reference (tests only)
+  oracle/_ref/libshl_ref_x86.so         genuine reference, only when /root/reference exists
+hipcc cross-compiles for gfx950 without a GPU.
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "lib")
+INC = os.path.join(ROOT, "include")
+REFERENCE = "/root/reference"
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, **kw):
+    print("+ " + " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, **kw)
+
+
+def _glob(d, exts):
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
+
+
+def build_hip(force=False):
+    src = _glob(os.path.join(HERE, "csrc"), (".hip",))
+    deps = src + _glob(os.path.join(HERE, "csrc"), (".h",)) + [os.path.join(INC, "shl_mi355x.h")]
+    out = os.path.join(LIB, "libshl_mi355x.so")
+    if not force and not _newer(out, deps):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+          "-fno-gpu-rdc", "-ffp-contract=off", "-I" + INC, "-I" + os.path.join(HERE, "csrc")]
+         + src + ["-o", out])
+    return out
+
+
+def build_host(force=False):
+    cflags = ["-O2", "-fPIC", "-std=gnu99", "-ffp-contract=off", "-Wall", "-Wno-unused-parameter",
+              "-Wno-strict-prototypes", "-I" + INC, "-I" + os.path.join(INC, "csinn")]
+    hdrs = []
+    for base, _, files in os.walk(INC):
+        hdrs += [os.path.join(base, f) for f in files]
+    nn2 = _glob(os.path.join(HERE, "source", "nn2"), (".c",)) + \
+        _glob(os.path.join(HERE, "source", "graph_ref"), (".c",))
+    out_nn2 = os.path.join(LIB, "libcsinn_nn2.so")
+    if force or _newer(out_nn2, nn2 + hdrs):
+        _run(["gcc"] + cflags + ["-shared"] + nn2 + ["-o", out_nn2, "-lm"])
+    opt_dir = os.path.join(HERE, "source", "mi355x_opt")
+    opt = _glob(opt_dir, (".c",))
+    out_opt = os.path.join(LIB, "libshl_mi355x_opt.so")
+    if force or _newer(out_opt, opt + hdrs + _glob(opt_dir, (".h",))):
+        # front-end symbols (shl_mem_alloc, shl_register_*, shl_gref_*) stay undefined: they
+        # come from libcsinn_nn2.so or from the genuine libshl at load time
+        _run(["gcc"] + cflags + ["-shared", "-I" + opt_dir] + opt +
+             ["-o", out_opt, "-L" + LIB, "-lshl_mi355x", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lm"])
+    return out_nn2, out_opt
+
+
+def build_oracle(force=False):
+    odir = os.path.join(ROOT, "oracle")
+    _run(["make", "-s", "-C", odir] + (["-B"] if force else []))
+    ref_so = os.path.join(odir, "_ref", "libshl_ref_x86.so")
+    if os.path.isdir(os.path.join(REFERENCE, "source", "reference")):
+        if force or not os.path.exists(ref_so):
+            _run(["make", "-s", "-C", odir, "ref", "-j8"])
+    return ref_so if os.path.exists(ref_so) else None
+
+
+def build_all(force=False, oracle=True):
+    os.makedirs(LIB, exist_ok=True)
+    build_hip(force)
+    build_host(force)
+    if oracle:
+        build_oracle(force)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--no-oracle", action="store_true")
+    a = ap.parse_args()
+    build_all(a.force, not a.no_oracle)
+    print("build ok")
+    sys.exit(0)

@@ -1,0 +1,135 @@
+// common.h -- shared definitions of the gfx950 compute library (libshl_mi355x.so).
+//
+// Numerical contract (DESIGN.md "numerical contract"):
+//   int8 : S = sum over in-bounds taps of (q - zp_in) * w  in exact int32
+//          f = fl(fl((float)S * mult[oc]) + bias_f[oc])            two roundings, no FMA
+//          q = sat8(rint(f / s_out) + zp_out)                       IEEE divide, ties-to-even
+//          then relu / relu6 exactly as shl_ref_relu_quant / shl_ref_relu6_quant do on the
+//          quantised value (source/reference/relu.c:21-43, relu6.c:21-43)
+//   f16  : fp32 accumulation of exact products, fp32 bias add, reference f32->f16 rounding
+//          (source/nn2/utils.c:576-620: truncate 12 bits, scale, +0x1000, >>13; saturating)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "shl_mi355x.h"
+
+namespace shl {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+// Everything a convolution kernel needs; passed by value as the kernel argument.
+struct ConvArgs {
+    const void *in;
+    const void *w;       // packed weights (layout depends on the algorithm)
+    void *out;
+    const int32_t *acc_init;  // int8: -zp_in * sum(w[oc]) when padding is materialised as zp
+    const float *mult;        // int8: s_in * s_k[oc]
+    const float *bias;        // fp32 bias per output channel (zeros when absent)
+    int32_t N, H, W, C;
+    int32_t Ho, Wo, Co;
+    int32_t Kh, Kw;
+    int32_t sh, sw, pt, pl, dh, dw;
+    int32_t group;
+    int32_t M;        // N * Ho * Wo
+    int32_t kchunks;  // igemm: number of 16-byte K chunks = Kh*Kw*C*esize/16
+    int32_t kstride;  // igemm: bytes per packed weight row (multiple of 64)
+    int32_t cchunks;  // igemm: 16-byte chunks per pixel = C*esize/16
+    int32_t in_zp;
+    int32_t act;
+    float out_scale;
+    float out_zp_f;
+    float inv_out_scale;  // f16 only: 1/out_scale, applied when out_scale != 1
+    int32_t scale_out;    // f16 only: out_scale differs from 1
+};
+
+// ---- int8 epilogue ---------------------------------------------------------------------
+__device__ __forceinline__ int sat8_from_float(float r)
+{
+    // float_to_int8_base (source/nn2/utils.c:550-560): saturate, then truncate
+    r = r > 127.0f ? 127.0f : r;
+    r = r < -128.0f ? -128.0f : r;
+    return (int)r;
+}
+
+__device__ __forceinline__ int requant_i8(int32_t S, float mult, float bias_f, float out_scale,
+                                          float out_zp_f, int act)
+{
+    float f = __fadd_rn(__fmul_rn((float)S, mult), bias_f);
+    float r = __fadd_rn(rintf(__fdiv_rn(f, out_scale)), out_zp_f);
+    int q = sat8_from_float(r);
+    if (act != SHL_MI355X_ACT_NONE) {
+        float x = __fmul_rn(__fsub_rn((float)q, out_zp_f), out_scale);
+        x = x > 0.0f ? x : 0.0f;
+        if (act == SHL_MI355X_ACT_RELU6) x = fminf(x, 6.0f);
+        r = __fadd_rn(rintf(__fdiv_rn(x, out_scale)), out_zp_f);
+        q = sat8_from_float(r);
+    }
+    return q;
+}
+
+// ---- binary16 <-> fp32 with the reference's rounding ----------------------------------------
+__device__ __forceinline__ float f16_bits_to_float(uint16_t h)
+{
+    // float16_to_float32_base (source/nn2/utils.c:624-643) is an exact widening; so is the
+    // hardware conversion.
+    _Float16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return (float)v;
+}
+
+__device__ __forceinline__ uint16_t float_to_f16_bits_ref(float x)
+{
+    if (x > 65519.0f) return 0x7BFFu;
+    if (x < -65519.0f) return 0xFBFFu;
+    uint32_t u = __float_as_uint(x);
+    const uint32_t sign = u & 0x80000000u;
+    u ^= sign;
+    uint32_t h;
+    if (u >= 0x7F800000u) {
+        h = (u > 0x7F800000u) ? 0x7FFFu : 0x7C00u;
+    } else {
+        u &= 0xFFFFF000u;
+        // * 2^-112: fp32 subnormal results must survive (default denormal mode keeps them)
+        float s = __fmul_rn(__uint_as_float(u), __uint_as_float(15u << 23));
+        u = __float_as_uint(s) + 0x1000u;
+        if (u > (31u << 23)) u = 31u << 23;
+        h = u >> 13;
+    }
+    return (uint16_t)(h | (sign >> 16));
+}
+
+__device__ __forceinline__ uint16_t finish_f16(float acc, float bias_f, const ConvArgs &a)
+{
+    float f = __fadd_rn(acc, bias_f);
+    if (a.scale_out) f = __fmul_rn(f, a.inv_out_scale);
+    if (a.act != SHL_MI355X_ACT_NONE) {
+        // relu after rounding == rounding after relu (monotone, sign-preserving, 6.0 exact)
+        f = f > 0.0f ? f : 0.0f;
+        if (a.act == SHL_MI355X_ACT_RELU6) f = fminf(f, 6.0f);
+    }
+    return float_to_f16_bits_ref(f);
+}
+
+// ---- host-side error plumbing (shim_runtime.hip) --------------------------------------------
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+#define SHL_HIP(expr)                                          \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return shl::hip_fail(e_, #expr); \
+    } while (0)
+
+// ---- launchers implemented by the kernel translation units ----------------------------------
+int launch_conv_direct(const ConvArgs &a, int dtype, int layout, int dw_nhwc_weights,
+                       hipStream_t s);
+int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s);
+int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
+bool igemm_supports(const shl_mi355x_conv_desc &d);
+bool dwconv_supports(const shl_mi355x_conv_desc &d);
+
+}  // namespace shl

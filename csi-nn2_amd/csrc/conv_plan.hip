@@ -1,0 +1,276 @@
+// conv_plan.hip -- per-layer plans: algorithm choice, weight packing, epilogue tables, launch.
+//
+// A plan owns ONE device allocation (the "constant block"):
+//     [ packed weights | acc_init (int32[Co]) | mult (float[Co]) | bias (float[Co]) ]
+// with 256-byte aligned sections.  The block is position independent, so a multi-GPU caller
+// builds it on rank 0 and broadcasts the bytes; other ranks create the plan with
+// kernel_host == NULL and receive the block.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+struct shl_mi355x_conv_plan {
+    shl_mi355x_conv_desc desc;
+    int algo;
+    char *block;       // device
+    size_t block_bytes;
+    size_t off_w, off_acc, off_mult, off_bias;
+    int32_t kstride;   // igemm: packed row bytes
+    int32_t kchunks;
+    int32_t cchunks;
+    const char *kernel_name;
+};
+
+namespace shl {
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int esize_of(const shl_mi355x_conv_desc &d) { return d.dtype == SHL_MI355X_I8 ? 1 : 2; }
+
+static bool is_depthwise(const shl_mi355x_conv_desc &d) { return d.group > 1 && d.group == d.in_c; }
+
+static int validate(const shl_mi355x_conv_desc &d)
+{
+    if (d.layout != SHL_MI355X_NHWC && d.layout != SHL_MI355X_NCHW) return SHL_MI355X_EINVAL;
+    if (d.dtype != SHL_MI355X_I8 && d.dtype != SHL_MI355X_F16) return SHL_MI355X_EINVAL;
+    if (d.act < SHL_MI355X_ACT_NONE || d.act > SHL_MI355X_ACT_RELU6) return SHL_MI355X_EINVAL;
+    if (d.batch < 0 || d.in_h <= 0 || d.in_w <= 0 || d.in_c <= 0) return SHL_MI355X_EINVAL;
+    if (d.out_h <= 0 || d.out_w <= 0 || d.out_c <= 0) return SHL_MI355X_EINVAL;
+    if (d.kernel_h <= 0 || d.kernel_w <= 0) return SHL_MI355X_EINVAL;
+    if (d.stride_h <= 0 || d.stride_w <= 0 || d.dilation_h <= 0 || d.dilation_w <= 0)
+        return SHL_MI355X_EINVAL;
+    if (d.group <= 0 || d.in_c % d.group || d.out_c % d.group) return SHL_MI355X_EINVAL;
+    if (d.pad_top < 0 || d.pad_left < 0) return SHL_MI355X_EINVAL;
+    // every output position must start inside the padded image
+    if ((int64_t)(d.out_h - 1) * d.stride_h - d.pad_top >= d.in_h) return SHL_MI355X_EINVAL;
+    if ((int64_t)(d.out_w - 1) * d.stride_w - d.pad_left >= d.in_w) return SHL_MI355X_EINVAL;
+    if (d.dtype == SHL_MI355X_I8 && !(d.out_scale > 0.0f)) return SHL_MI355X_EINVAL;
+    return SHL_MI355X_OK;
+}
+
+static int choose_algo(const shl_mi355x_conv_desc &d)
+{
+    if (is_depthwise(d)) return dwconv_supports(d) ? SHL_MI355X_ALGO_DW : SHL_MI355X_ALGO_DIRECT;
+    if (d.group != 1) return -1;  // grouped convolution: SURVEY 8f3
+    return igemm_supports(d) ? SHL_MI355X_ALGO_IGEMM : SHL_MI355X_ALGO_DIRECT;
+}
+
+// weights -> [Co][kstride] rows in (ky, kx, ic) order, zero padded (igemm)
+static void pack_igemm(const shl_mi355x_conv_desc &d, const char *src, char *dst, int kstride)
+{
+    const int es = esize_of(d);
+    const int K = d.kernel_h * d.kernel_w * d.in_c;
+    memset(dst, 0, (size_t)d.out_c * kstride);
+    for (int oc = 0; oc < d.out_c; ++oc) {
+        char *row = dst + (size_t)oc * kstride;
+        if (d.layout == SHL_MI355X_NHWC) {  // OHWI is already K-major
+            memcpy(row, src + (size_t)oc * K * es, (size_t)K * es);
+        } else {  // OIHW
+            for (int ic = 0; ic < d.in_c; ++ic)
+                for (int ky = 0; ky < d.kernel_h; ++ky)
+                    for (int kx = 0; kx < d.kernel_w; ++kx) {
+                        const size_t s = (((size_t)oc * d.in_c + ic) * d.kernel_h + ky) * d.kernel_w + kx;
+                        const size_t k = ((size_t)ky * d.kernel_w + kx) * d.in_c + ic;
+                        memcpy(row + k * es, src + s * es, es);
+                    }
+        }
+    }
+}
+
+}  // namespace shl
+
+using namespace shl;
+
+extern "C" {
+
+int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const void *kernel_host,
+                                const float *mult_host, const float *bias_host, void *stream,
+                                shl_mi355x_conv_plan **plan_out)
+{
+    if (!desc || !plan_out) {
+        set_error("conv_plan_create: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    *plan_out = nullptr;
+    int rc = validate(*desc);
+    if (rc != SHL_MI355X_OK) {
+        set_error("conv_plan_create: invalid descriptor");
+        return rc;
+    }
+    const shl_mi355x_conv_desc &d = *desc;
+    if (d.dtype == SHL_MI355X_I8 && kernel_host && !mult_host) {
+        set_error("conv_plan_create: int8 needs the per-channel multiplier table");
+        return SHL_MI355X_EINVAL;
+    }
+    int algo = d.algo;
+    if (algo == SHL_MI355X_ALGO_AUTO) algo = choose_algo(d);
+    if (algo < 0) {
+        set_error("conv_plan_create: grouped convolution (group=%d) is not supported", d.group);
+        return SHL_MI355X_ENOTSUP;
+    }
+    if (algo == SHL_MI355X_ALGO_IGEMM && !igemm_supports(d)) {
+        set_error("conv_plan_create: IGEMM needs group==1, NHWC and C*esize %% 16 == 0");
+        return SHL_MI355X_ENOTSUP;
+    }
+    if (algo == SHL_MI355X_ALGO_DW && !dwconv_supports(d)) {
+        set_error("conv_plan_create: DW kernel needs NHWC, multiplier 1 and C %% 4 == 0");
+        return SHL_MI355X_ENOTSUP;
+    }
+    if (algo != SHL_MI355X_ALGO_IGEMM && algo != SHL_MI355X_ALGO_DW && algo != SHL_MI355X_ALGO_DIRECT) {
+        set_error("conv_plan_create: unknown algorithm %d", algo);
+        return SHL_MI355X_EINVAL;
+    }
+
+    shl_mi355x_conv_plan *p = (shl_mi355x_conv_plan *)calloc(1, sizeof(*p));
+    if (!p) return SHL_MI355X_ENOMEM;
+    p->desc = d;
+    p->algo = algo;
+    const int es = esize_of(d);
+    const int cpg = d.in_c / d.group;
+    const size_t raw_w = (size_t)d.out_c * cpg * d.kernel_h * d.kernel_w * es;
+    size_t w_bytes = raw_w;
+    if (algo == SHL_MI355X_ALGO_IGEMM) {
+        const int Kb = d.kernel_h * d.kernel_w * d.in_c * es;
+        p->kstride = (int32_t)align_up((size_t)Kb, 64);
+        p->kchunks = Kb / 16;
+        p->cchunks = d.in_c * es / 16;
+        w_bytes = (size_t)d.out_c * p->kstride;
+        p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_igemm_i8_mfma32x32x32" : "conv_igemm_f16_mfma32x32x16";
+    } else if (algo == SHL_MI355X_ALGO_DW) {
+        p->kernel_name = d.dtype == SHL_MI355X_I8 ? "dwconv_nhwc_i8" : "dwconv_nhwc_f16";
+    } else {
+        p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_direct_i8" : "conv_direct_f16";
+    }
+    p->off_w = 0;
+    p->off_acc = align_up(w_bytes, 256);
+    p->off_mult = p->off_acc + align_up((size_t)d.out_c * 4, 256);
+    p->off_bias = p->off_mult + align_up((size_t)d.out_c * 4, 256);
+    p->block_bytes = p->off_bias + align_up((size_t)d.out_c * 4, 256);
+
+    hipError_t e = hipMalloc((void **)&p->block, p->block_bytes);
+    if (e != hipSuccess) {
+        free(p);
+        return hip_fail(e, "hipMalloc(plan block)");
+    }
+
+    std::vector<char> host(p->block_bytes, 0);
+    if (kernel_host) {
+        const char *src = static_cast<const char *>(kernel_host);
+        if (algo == SHL_MI355X_ALGO_IGEMM)
+            pack_igemm(d, src, host.data() + p->off_w, p->kstride);
+        else
+            memcpy(host.data() + p->off_w, src, raw_w);
+        int32_t *acc = reinterpret_cast<int32_t *>(host.data() + p->off_acc);
+        float *mult = reinterpret_cast<float *>(host.data() + p->off_mult);
+        float *bias = reinterpret_cast<float *>(host.data() + p->off_bias);
+        for (int oc = 0; oc < d.out_c; ++oc) {
+            mult[oc] = mult_host ? mult_host[oc] : 1.0f;
+            bias[oc] = bias_host ? bias_host[oc] : 0.0f;
+            acc[oc] = 0;
+        }
+        if (algo == SHL_MI355X_ALGO_IGEMM && d.dtype == SHL_MI355X_I8) {
+            // padding is materialised as zp_in, so sum(q*w) carries zp_in*sum(w) for EVERY tap
+            const int K = d.kernel_h * d.kernel_w * d.in_c;
+            for (int oc = 0; oc < d.out_c; ++oc) {
+                const int8_t *row = reinterpret_cast<const int8_t *>(host.data() + p->off_w) +
+                                    (size_t)oc * p->kstride;
+                int64_t s = 0;
+                for (int k = 0; k < K; ++k) s += row[k];
+                acc[oc] = (int32_t)(-(int64_t)d.in_zp * s);
+            }
+        }
+    }
+    e = hipMemcpyAsync(p->block, host.data(), p->block_bytes, hipMemcpyHostToDevice,
+                       (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);  // host staging dies here
+    if (e != hipSuccess) {
+        (void)hipFree(p->block);
+        free(p);
+        return hip_fail(e, "upload(plan block)");
+    }
+    *plan_out = p;
+    return SHL_MI355X_OK;
+}
+
+int shl_mi355x_conv_plan_destroy(shl_mi355x_conv_plan *plan)
+{
+    if (!plan) return SHL_MI355X_OK;
+    hipError_t e = hipFree(plan->block);
+    free(plan);
+    if (e != hipSuccess) return hip_fail(e, "hipFree(plan block)");
+    return SHL_MI355X_OK;
+}
+
+int shl_mi355x_conv_plan_algo(const shl_mi355x_conv_plan *plan) { return plan ? plan->algo : SHL_MI355X_EINVAL; }
+
+const char *shl_mi355x_conv_plan_kernel_name(const shl_mi355x_conv_plan *plan)
+{
+    return plan ? plan->kernel_name : "";
+}
+
+size_t shl_mi355x_conv_plan_bytes(const shl_mi355x_conv_plan *plan) { return plan ? plan->block_bytes : 0; }
+
+void *shl_mi355x_conv_plan_const_block(shl_mi355x_conv_plan *plan, size_t *bytes)
+{
+    if (!plan) return nullptr;
+    if (bytes) *bytes = plan->block_bytes;
+    return plan->block;
+}
+
+int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev,
+                            void *output_dev, int32_t batch, void *stream)
+{
+    if (!plan || !input_dev || !output_dev) {
+        set_error("conv_forward: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    const shl_mi355x_conv_desc &d = plan->desc;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = input_dev;
+    a.out = output_dev;
+    a.w = plan->block + plan->off_w;
+    a.acc_init = reinterpret_cast<const int32_t *>(plan->block + plan->off_acc);
+    a.mult = reinterpret_cast<const float *>(plan->block + plan->off_mult);
+    a.bias = reinterpret_cast<const float *>(plan->block + plan->off_bias);
+    a.N = batch > 0 ? batch : d.batch;
+    a.H = d.in_h; a.W = d.in_w; a.C = d.in_c;
+    a.Ho = d.out_h; a.Wo = d.out_w; a.Co = d.out_c;
+    a.Kh = d.kernel_h; a.Kw = d.kernel_w;
+    a.sh = d.stride_h; a.sw = d.stride_w;
+    a.pt = d.pad_top; a.pl = d.pad_left;
+    a.dh = d.dilation_h; a.dw = d.dilation_w;
+    a.group = d.group;
+    const int64_t M = (int64_t)a.N * a.Ho * a.Wo;
+    if (M > 0x7FFFFFFF) {
+        set_error("conv_forward: N*Ho*Wo exceeds 2^31-1");
+        return SHL_MI355X_EINVAL;
+    }
+    a.M = (int32_t)M;
+    a.kchunks = plan->kchunks;
+    a.kstride = plan->kstride;
+    a.cchunks = plan->cchunks;
+    a.in_zp = d.in_zp;
+    a.act = d.act;
+    a.out_scale = d.out_scale;
+    a.out_zp_f = (float)d.out_zp;
+    const float os = d.out_scale;
+    a.scale_out = (d.dtype == SHL_MI355X_F16) && (os - 1.0f > 1.1920929e-07f || 1.0f - os > 1.1920929e-07f);
+    a.inv_out_scale = a.scale_out ? 1.0f / os : 1.0f;
+    if (a.M == 0) return SHL_MI355X_OK;
+    hipStream_t s = (hipStream_t)stream;
+    switch (plan->algo) {
+        case SHL_MI355X_ALGO_IGEMM:
+            return launch_conv_igemm(a, d.dtype, d.layout, s);
+        case SHL_MI355X_ALGO_DW:
+            return launch_dwconv(a, d.dtype, d.layout, s);
+        default:
+            return launch_conv_direct(a, d.dtype, d.layout,
+                                      is_depthwise(d) && d.layout == SHL_MI355X_NHWC, s);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// elementwise.hip -- relu / relu6 on quantised int8 tensors.
+// Replaces shl_ref_relu_quant / shl_ref_relu6_quant (source/reference/relu.c:21-43,
+// relu6.c:21-43): dequantise with the input record, clamp in fp32, requantise with the output
+// record.  HBM-bound: 16 bytes per lane per access.
+#include "common.h"
+
+namespace shl {
+
+__device__ __forceinline__ uint32_t relu4(uint32_t v, float si, float zi, float so, float zo, int relu6)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = __fmul_rn(__fsub_rn((float)(int8_t)(v >> (8 * e)), zi), si);
+        x = x > 0.0f ? x : 0.0f;
+        if (relu6) x = fminf(x, 6.0f);
+        const int q = sat8_from_float(__fadd_rn(rintf(__fdiv_rn(x, so)), zo));
+        r |= (uint32_t)(q & 0xFF) << (8 * e);
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void relu_i8_kernel(const int8_t *in, int8_t *out, size_t count,
+                                                      float si, float zi, float so, float zo,
+                                                      int relu6)
+{
+    const size_t nvec = count / 16;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        uint4 v = reinterpret_cast<const uint4 *>(in)[i];
+        v.x = relu4(v.x, si, zi, so, zo, relu6);
+        v.y = relu4(v.y, si, zi, so, zo, relu6);
+        v.z = relu4(v.z, si, zi, so, zo, relu6);
+        v.w = relu4(v.w, si, zi, so, zo, relu6);
+        reinterpret_cast<uint4 *>(out)[i] = v;
+    }
+    // ragged tail
+    for (size_t i = nvec * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        float x = __fmul_rn(__fsub_rn((float)in[i], zi), si);
+        x = x > 0.0f ? x : 0.0f;
+        if (relu6) x = fminf(x, 6.0f);
+        out[i] = (int8_t)sat8_from_float(__fadd_rn(rintf(__fdiv_rn(x, so)), zo));
+    }
+}
+
+}  // namespace shl
+
+extern "C" int shl_mi355x_relu_i8(const int8_t *input_dev, int8_t *output_dev, size_t count,
+                                  float in_scale, int32_t in_zp, float out_scale, int32_t out_zp,
+                                  int32_t relu6, void *stream)
+{
+    if (!input_dev || !output_dev) {
+        shl::set_error("relu_i8: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    if (count == 0) return SHL_MI355X_OK;
+    if ((((uintptr_t)input_dev | (uintptr_t)output_dev) & 15) != 0) {
+        shl::set_error("relu_i8: buffers must be 16-byte aligned");
+        return SHL_MI355X_EINVAL;
+    }
+    size_t blocks = (count / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(shl::relu_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       input_dev, output_dev, count, in_scale, (float)in_zp, out_scale, (float)out_zp,
+                       (int)relu6);
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}

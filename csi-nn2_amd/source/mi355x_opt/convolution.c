@@ -1,0 +1,318 @@
+/*
+ * convolution.c -- init / exec callbacks of the MI355X backend for conv2d, depthwise_conv2d
+ * and fullyconnected (int8 and fp16, NHWC and NCHW), fused relu / relu6 variants included.
+ *
+ * init  (once per layer): translate the csinn tensors + params into the C-ABI descriptor of
+ *        include/shl_mi355x.h, convert the quantisation records into the per-output-channel
+ *        fp32 tables of the numerical contract, and create the device-resident plan.
+ *        Reference analogue: the init functions of the optimised backends
+ *        (source/thead_rvv/int8/convolution.c:21-206) -- weight reorder, zero-point fold,
+ *        per-channel scale derivation.
+ * exec  (every inference): stage host tensors through HBM if needed and enqueue the kernel.
+ *        Reference analogue: shl_ref_conv2d_quant / shl_ref_depthwise_conv2d_quant /
+ *        shl_ref_fullyconnected_quant (source/reference/convolution.c:370-460,
+ *        fullyconnected.c:54-87).
+ *
+ * There is no CPU compute path in this file: if the HIP library reports an error the
+ * callback logs it through shl_debug_error and returns CSINN_FALSE.
+ */
+#include <math.h>
+#include <string.h>
+
+#include "mi355x_internal.h"
+
+/* ------------------------------------------------------------------------ descriptor */
+
+static int layout_of(struct csinn_conv2d_params *params)
+{
+    if (params->base.layout == CSINN_LAYOUT_NHWC) return SHL_MI355X_NHWC;
+    if (params->base.layout == CSINN_LAYOUT_NCHW) return SHL_MI355X_NCHW;
+    return -1;
+}
+
+static int dtype_of(struct csinn_tensor *t)
+{
+    if (t->dtype == CSINN_DTYPE_INT8) return SHL_MI355X_I8;
+    if (t->dtype == CSINN_DTYPE_FLOAT16) return SHL_MI355X_F16;
+    return -1;
+}
+
+static int scale_is_one(float s) { return fabsf(s - 1.0f) <= 1.1920929e-07f; }
+
+/* fp32 image of the bias as the reference computes it, and the per-channel multipliers.
+ * Returns CSINN_TRUE or a negative status. */
+static int build_tables(const struct shl_mi355x_conv_desc *d, struct csinn_tensor *input,
+                        struct csinn_tensor *kernel, struct csinn_tensor *bias, int fuse_zp2bias,
+                        int dw_weights_last, float *mult, float *bias_f)
+{
+    const int co = d->out_c;
+    const int has_bias = bias != NULL && bias->dim_count != 0 && bias->data != NULL;
+    const int64_t kelems = (int64_t)co * (d->in_c / d->group) * d->kernel_h * d->kernel_w;
+
+    if (d->dtype == SHL_MI355X_I8) {
+        if (kernel->quant_channel != 1 && kernel->quant_channel != co) {
+            shl_debug_error("mi355x: kernel has %d quant records, expected 1 or %d\n",
+                            kernel->quant_channel, co);
+            return CSINN_FALSE;
+        }
+        for (int q = 0; q < kernel->quant_channel; q++) {
+            if (kernel->qinfo[q].zero_point != 0) {
+                shl_debug_error("mi355x: asymmetric weights (zero point %d) are not supported\n",
+                                kernel->qinfo[q].zero_point);
+                return CSINN_UNSUPPORT_DTYPE;
+            }
+        }
+        const float s_in = input->qinfo->scale;
+        for (int oc = 0; oc < co; oc++)
+            mult[oc] = s_in * kernel->qinfo[kernel->quant_channel > 1 ? oc : 0].scale;
+        for (int oc = 0; oc < co; oc++) bias_f[oc] = 0.0f;
+        if (has_bias) {
+            if (bias->dtype != CSINN_DTYPE_INT32) {
+                shl_debug_error("mi355x: int8 convolution expects an int32 bias (dtype %d)\n",
+                                bias->dtype);
+                return CSINN_UNSUPPORT_DTYPE;
+            }
+            const int32_t *b = bias->data;
+            const int per_ch = bias->quant_channel > 1;
+            /* int32_to_float_base, source/nn2/utils.c:509-512 */
+            for (int oc = 0; oc < co; oc++) bias_f[oc] = (float)b[oc] * bias->qinfo[per_ch ? oc : 0].scale;
+            if (fuse_zp2bias) {
+                /* reference/convolution.c:375-395 and :426-450 -- undo the caller's fold in
+                 * fp32, in the reference's summation order */
+                const int8_t *w = kernel->data;
+                const float sp = s_in * (float)input->qinfo->zero_point;
+                const int64_t inner = kelems / co;
+                const int dw = d->group > 1;
+                for (int oc = 0; oc < co; oc++) {
+                    const float sk = kernel->qinfo[kernel->quant_channel > 1 ? oc : 0].scale;
+                    float t = dw ? bias_f[oc] : 0.0f;
+                    for (int64_t j = 0; j < inner; j++) {
+                        const int8_t wq = dw_weights_last ? w[j * co + oc] : w[oc * inner + j];
+                        t = t + ((float)wq * sk) * sp;
+                    }
+                    bias_f[oc] = dw ? t : bias_f[oc] + t;
+                }
+            }
+        }
+    } else {
+        /* fp16: the reference multiplies by qinfo->scale only when it differs from 1
+         * (source/nn2/utils.c:1175-1205); the device path implements the scale == 1 case for
+         * inputs, weights and bias, and an arbitrary output scale. */
+        if (!scale_is_one(input->qinfo->scale) || !scale_is_one(kernel->qinfo->scale) ||
+            (has_bias && !scale_is_one(bias->qinfo->scale))) {
+            shl_debug_error("mi355x: fp16 tensors with qinfo scale != 1 are not supported\n");
+            return CSINN_UNSUPPORT_DTYPE;
+        }
+        for (int oc = 0; oc < co; oc++) {
+            mult[oc] = 1.0f;
+            bias_f[oc] = 0.0f;
+        }
+        if (has_bias) {
+            if (bias->dtype != CSINN_DTYPE_FLOAT16) {
+                shl_debug_error("mi355x: fp16 convolution expects an fp16 bias\n");
+                return CSINN_UNSUPPORT_DTYPE;
+            }
+            const uint16_t *b = bias->data;
+            for (int oc = 0; oc < co; oc++) bias_f[oc] = shl_mi355x_half_to_float(b[oc]);
+        }
+    }
+    return CSINN_TRUE;
+}
+
+static int create_plan(void *params_key, struct shl_mi355x_conv_desc *d, struct csinn_tensor *input,
+                       struct csinn_tensor *output, struct csinn_tensor *kernel,
+                       struct csinn_tensor *bias, int fuse_zp2bias)
+{
+    if (kernel->data == NULL || kernel->mtype == CSINN_MEM_TYPE_DMABUF) {
+        shl_debug_error("mi355x: the kernel tensor must be host resident at init time\n");
+        return CSINN_FALSE;
+    }
+    if (d->dtype == SHL_MI355X_I8) {
+        d->in_zp = input->qinfo->zero_point;
+        d->out_zp = output->qinfo->zero_point;
+    }
+    d->out_scale = output->qinfo->scale;
+
+    float *mult = shl_mem_alloc((int64_t)d->out_c * sizeof(float));
+    float *bias_f = shl_mem_alloc((int64_t)d->out_c * sizeof(float));
+    const int dw_last = d->group > 1 && d->layout == SHL_MI355X_NHWC;
+    int rc = build_tables(d, input, kernel, bias, fuse_zp2bias, dw_last, mult, bias_f);
+    if (rc == CSINN_TRUE) {
+        shl_mi355x_conv_plan *plan = NULL;
+        int st = shl_mi355x_conv_plan_create(d, kernel->data, mult, bias_f, shl_mi355x_get_stream(),
+                                             &plan);
+        if (st != SHL_MI355X_OK) {
+            shl_debug_error("mi355x: plan creation failed (%d): %s\n", st, shl_mi355x_last_error());
+            rc = st == SHL_MI355X_ENOTSUP ? CSINN_UNSUPPORT_LAYOUT : CSINN_FALSE;
+        } else {
+            shl_mi355x_registry_put(params_key, plan);
+        }
+    }
+    shl_mem_free(mult);
+    shl_mem_free(bias_f);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ conv2d family */
+
+static int conv_init_common(struct csinn_tensor *input, struct csinn_tensor *output,
+                            struct csinn_tensor *kernel, struct csinn_tensor *bias,
+                            struct csinn_conv2d_params *params, int act)
+{
+    struct shl_mi355x_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.layout = layout_of(params);
+    d.dtype = dtype_of(input);
+    if (d.layout < 0) {
+        shl_debug_error("mi355x: conv2d layout %d unsupported\n", params->base.layout);
+        return CSINN_UNSUPPORT_LAYOUT;
+    }
+    if (d.dtype < 0 || dtype_of(kernel) != d.dtype || dtype_of(output) != d.dtype) {
+        shl_debug_error("mi355x: conv2d dtypes in=%d kernel=%d out=%d unsupported\n", input->dtype,
+                        kernel->dtype, output->dtype);
+        return CSINN_UNSUPPORT_DTYPE;
+    }
+    const int nhwc = d.layout == SHL_MI355X_NHWC;
+    d.act = act;
+    d.batch = input->dim[0];
+    d.in_h = input->dim[nhwc ? 1 : 2];
+    d.in_w = input->dim[nhwc ? 2 : 3];
+    d.in_c = input->dim[nhwc ? 3 : 1];
+    d.out_h = output->dim[nhwc ? 1 : 2];
+    d.out_w = output->dim[nhwc ? 2 : 3];
+    d.out_c = output->dim[nhwc ? 3 : 1];
+    d.kernel_h = kernel->dim[nhwc ? 1 : 2];
+    d.kernel_w = kernel->dim[nhwc ? 2 : 3];
+    d.stride_h = params->stride_height;
+    d.stride_w = params->stride_width;
+    d.pad_top = params->pad_top;
+    d.pad_left = params->pad_left;
+    d.dilation_h = params->dilation_height > 0 ? params->dilation_height : 1;
+    d.dilation_w = params->dilation_width > 0 ? params->dilation_width : 1;
+    d.group = params->group > 0 ? params->group : 1;
+
+    int rc = create_plan(params, &d, input, output, kernel, bias, params->conv_extra.fuse_zp2bias);
+    if (rc != CSINN_TRUE) return rc;
+    /* the way every optimised backend of the reference selects its kernel */
+    params->base.cb->exec = shl_mi355x_conv2d_exec;
+    return CSINN_TRUE;
+}
+
+int shl_mi355x_conv2d_init(CSINN_CONV_ARGS)
+{
+    return conv_init_common(input, output, kernel, bias, params, SHL_MI355X_ACT_NONE);
+}
+int shl_mi355x_conv2d_relu_init(CSINN_CONV_ARGS)
+{
+    return conv_init_common(input, output, kernel, bias, params, SHL_MI355X_ACT_RELU);
+}
+int shl_mi355x_conv2d_relu6_init(CSINN_CONV_ARGS)
+{
+    return conv_init_common(input, output, kernel, bias, params, SHL_MI355X_ACT_RELU6);
+}
+
+static int run_plan(void *params_key, struct csinn_tensor *input, struct csinn_tensor *output,
+                    int batch, const char *what)
+{
+    shl_mi355x_conv_plan *plan = shl_mi355x_registry_get(params_key);
+    if (plan == NULL) {
+        shl_debug_error("mi355x: %s called without a successful init\n", what);
+        return CSINN_FALSE;
+    }
+    void *stream = shl_mi355x_get_stream();
+    const void *in_dev = shl_mi355x_stage_in(input, 0);
+    void *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
+    int st = shl_mi355x_conv_forward(plan, in_dev, out_dev, batch, stream);
+    if (st != SHL_MI355X_OK) {
+        shl_debug_error("mi355x: %s launch failed (%d): %s\n", what, st, shl_mi355x_last_error());
+        return CSINN_FALSE;
+    }
+    return shl_mi355x_stage_out_end(output, out_dev);
+}
+
+int shl_mi355x_conv2d_exec(CSINN_CONV_ARGS)
+{
+    (void)kernel;
+    (void)bias;
+    return run_plan(params, input, output, input->dim[0], "conv2d");
+}
+
+/* ------------------------------------------------------------------------ fullyconnected
+ * out[b, o] = sum_d in[b, d] * w[o, d] + bias[o]  ==  1x1 convolution over a
+ * [batches, 1, 1, in_nodes] NHWC tensor (source/reference/fullyconnected.c:21-52). */
+
+int shl_mi355x_fullyconnected_init(struct csinn_tensor *input, struct csinn_tensor *output,
+                                   struct csinn_tensor *weights, struct csinn_tensor *bias,
+                                   struct csinn_fc_params *params)
+{
+    struct shl_mi355x_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.layout = SHL_MI355X_NHWC;
+    d.dtype = dtype_of(input);
+    if (d.dtype < 0 || dtype_of(weights) != d.dtype || dtype_of(output) != d.dtype) {
+        shl_debug_error("mi355x: fullyconnected dtypes in=%d w=%d out=%d unsupported\n",
+                        input->dtype, weights->dtype, output->dtype);
+        return CSINN_UNSUPPORT_DTYPE;
+    }
+    if (weights->dim_count < 2) return CSINN_FALSE;
+    int batches = 1;
+    for (int i = 0; i < output->dim_count - 1; i++) batches *= output->dim[i];
+    d.batch = batches;
+    d.in_h = d.in_w = d.out_h = d.out_w = 1;
+    d.kernel_h = d.kernel_w = 1;
+    d.stride_h = d.stride_w = d.dilation_h = d.dilation_w = 1;
+    d.group = 1;
+    d.out_c = weights->dim[weights->dim_count - 2];
+    d.in_c = weights->dim[weights->dim_count - 1];
+    int rc = create_plan(params, &d, input, output, weights, bias, params->fc_extra.fuse_zp2bias);
+    if (rc != CSINN_TRUE) return rc;
+    params->base.cb->exec = shl_mi355x_fullyconnected_exec;
+    return CSINN_TRUE;
+}
+
+int shl_mi355x_fullyconnected_exec(struct csinn_tensor *input, struct csinn_tensor *output,
+                                   struct csinn_tensor *weights, struct csinn_tensor *bias,
+                                   struct csinn_fc_params *params)
+{
+    (void)weights;
+    (void)bias;
+    int batches = 1;
+    for (int i = 0; i < output->dim_count - 1; i++) batches *= output->dim[i];
+    return run_plan(params, input, output, batches, "fullyconnected");
+}
+
+/* ------------------------------------------------------------------------ relu / relu6 */
+
+static int relu_common(struct csinn_tensor *input, struct csinn_tensor *output, int relu6)
+{
+    if (input->dtype != CSINN_DTYPE_INT8 || output->dtype != CSINN_DTYPE_INT8) {
+        shl_debug_error("mi355x: relu supports int8 tensors only\n");
+        return CSINN_UNSUPPORT_DTYPE;
+    }
+    const void *in_dev = shl_mi355x_stage_in(input, 0);
+    void *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
+    int st = shl_mi355x_relu_i8(in_dev, out_dev, (size_t)csinn_tensor_size(input),
+                                input->qinfo->scale, input->qinfo->zero_point, output->qinfo->scale,
+                                output->qinfo->zero_point, relu6, shl_mi355x_get_stream());
+    if (st != SHL_MI355X_OK) {
+        shl_debug_error("mi355x: relu launch failed (%d): %s\n", st, shl_mi355x_last_error());
+        return CSINN_FALSE;
+    }
+    return shl_mi355x_stage_out_end(output, out_dev);
+}
+
+int shl_mi355x_relu_exec(struct csinn_tensor *input, struct csinn_tensor *output,
+                         struct csinn_relu_params *params)
+{
+    (void)params;
+    return relu_common(input, output, 0);
+}
+
+int shl_mi355x_relu6_exec(struct csinn_tensor *input, struct csinn_tensor *output,
+                          struct csinn_relu_params *params)
+{
+    (void)params;
+    return relu_common(input, output, 1);
+}

@@ -1,0 +1,27 @@
+/* mi355x_internal.h -- private glue of the source/mi355x_opt backend. */
+#ifndef MI355X_INTERNAL_H_
+#define MI355X_INTERNAL_H_
+
+#include "shl_mi355x.h"
+#include "shl_mi355x_backend.h"
+
+/* params-block -> device plan association (struct csinn_fc_params has no spare pointer, so a
+ * side table serves every op uniformly) */
+void shl_mi355x_registry_put(void *params, shl_mi355x_conv_plan *plan);
+shl_mi355x_conv_plan *shl_mi355x_registry_get(void *params);
+
+/* Host <-> HBM staging for tensors that do not already live on the device.
+ * slot: 0 = first input, 1 = output.
+ *   stage_in        device address holding the tensor's bytes (uploads host tensors)
+ *   stage_out_begin device address the kernel should write
+ *   stage_out_end   downloads + synchronises for host tensors; CSINN_TRUE on success */
+const void *shl_mi355x_stage_in(struct csinn_tensor *t, int slot);
+void *shl_mi355x_stage_out_begin(struct csinn_tensor *t, int slot);
+int shl_mi355x_stage_out_end(struct csinn_tensor *t, void *dev);
+
+float shl_mi355x_half_to_float(uint16_t h);
+
+int shl_mi355x_conv2d_relu_init(CSINN_CONV_ARGS);
+int shl_mi355x_conv2d_relu6_init(CSINN_CONV_ARGS);
+
+#endif /* MI355X_INTERNAL_H_ */

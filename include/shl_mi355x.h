@@ -1,0 +1,196 @@
+/*
+ * shl_mi355x.h -- C-ABI of libshl_mi355x.so, the HIP/gfx950 compute library
+ * behind the source/mi355x_opt backend.
+ *
+ * Plain C: pointers, sizes and PODs only -- no HIP, C++ or torch types cross
+ * this boundary.  The host backend (C, compiled by gcc) and any foreign-language
+ * binding (ctypes, cgo, JNI ...) talk to the GPU exclusively through these
+ * entry points.  Each compute entry point names the reference function it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - return value: 0 on success, a negative SHL_MI355X_E* code on failure;
+ *     shl_mi355x_last_error() returns a human-readable message for the calling
+ *     thread's last failure.  There is NO CPU fallback anywhere in this library:
+ *     without a usable gfx950 device every compute call fails with
+ *     SHL_MI355X_ENODEV.
+ *   - `stream` is an opaque hipStream_t (NULL = the default stream).  All compute
+ *     entry points only enqueue work; they never synchronise.
+ *   - pointers named *_dev must be device-accessible (hipMalloc / torch CUDA
+ *     tensor storage); pointers named *_host are ordinary host memory.
+ */
+#ifndef SHL_MI355X_H_
+#define SHL_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHL_MI355X_ABI_VERSION 1
+
+enum shl_mi355x_status {
+    SHL_MI355X_OK = 0,
+    SHL_MI355X_ENODEV = -1,   /* no gfx950 device / HIP runtime unusable */
+    SHL_MI355X_EINVAL = -2,   /* malformed descriptor or NULL pointer */
+    SHL_MI355X_ENOTSUP = -3,  /* descriptor valid but no kernel covers it */
+    SHL_MI355X_EHIP = -4,     /* a HIP runtime call failed (see last_error) */
+    SHL_MI355X_ENOMEM = -5
+};
+
+enum shl_mi355x_layout {
+    SHL_MI355X_NHWC = 0, /* activations [N,H,W,C]; conv kernel OHWI; dw kernel 1HWO */
+    SHL_MI355X_NCHW = 1  /* activations [N,C,H,W]; conv kernel OIHW; dw kernel O1HW */
+};
+
+enum shl_mi355x_dtype {
+    SHL_MI355X_I8 = 0,  /* int8 activations/weights, int32 bias, int32 accumulation */
+    SHL_MI355X_F16 = 1  /* IEEE binary16 activations/weights/bias, fp32 accumulation */
+};
+
+enum shl_mi355x_act {
+    SHL_MI355X_ACT_NONE = 0,
+    SHL_MI355X_ACT_RELU = 1, /* reference/convolution_relu.c:34-71 semantics */
+    SHL_MI355X_ACT_RELU6 = 2 /* reference/convolution_relu6.c:21-43 semantics */
+};
+
+enum shl_mi355x_algo {
+    SHL_MI355X_ALGO_AUTO = 0,
+    SHL_MI355X_ALGO_DIRECT = 1, /* one thread per output, any shape (VALU) */
+    SHL_MI355X_ALGO_IGEMM = 2,  /* LDS-staged implicit GEMM on MFMA */
+    SHL_MI355X_ALGO_DW = 3,     /* bandwidth-tuned depthwise kernel */
+    SHL_MI355X_ALGO_GEMV = 4    /* fullyconnected, small batch */
+};
+
+/* ------------------------------------------------------------------------------------
+ * Problem descriptor shared by conv2d, depthwise_conv2d and fullyconnected
+ * (fullyconnected == 1x1 convolution over a [batch,1,1,in_nodes] NHWC tensor).
+ * Mirrors the fields the reference reads from csinn_tensor.dim[] and
+ * struct csinn_conv2d_params (csinn_data_structure.h:591-610).
+ * ------------------------------------------------------------------------------------ */
+struct shl_mi355x_conv_desc {
+    int32_t layout; /* enum shl_mi355x_layout */
+    int32_t dtype;  /* enum shl_mi355x_dtype */
+    int32_t act;    /* enum shl_mi355x_act */
+    int32_t algo;   /* enum shl_mi355x_algo; AUTO lets the library choose */
+    int32_t batch, in_h, in_w, in_c;
+    int32_t out_h, out_w, out_c;
+    int32_t kernel_h, kernel_w;
+    int32_t stride_h, stride_w;
+    int32_t pad_top, pad_left;
+    int32_t dilation_h, dilation_w;
+    int32_t group;       /* 1: conv2d; == in_c: depthwise (out_c = in_c * multiplier) */
+    int32_t in_zp;       /* int8 only: input zero point */
+    int32_t out_zp;      /* int8 only: output zero point */
+    float out_scale;     /* int8: output scale; f16: output qinfo scale (1.0 = none) */
+    int32_t reserved[4]; /* must be zero */
+};
+
+/* ------------------------------------------------------------------------------------
+ * A prepared convolution: packed weights + per-output-channel epilogue tables in HBM.
+ * Built once per layer (the backend's `init` callback), reused by every `exec`.
+ * Opaque to the caller.
+ * ------------------------------------------------------------------------------------ */
+typedef struct shl_mi355x_conv_plan shl_mi355x_conv_plan;
+
+/* ---- library / device ------------------------------------------------------------- */
+int shl_mi355x_abi_version(void);
+const char *shl_mi355x_last_error(void);
+/* number of visible gfx950 devices (0 when the HIP runtime finds none) */
+int shl_mi355x_device_count(void);
+int shl_mi355x_set_device(int ordinal);
+/* "gfx950:sramecc+:xnack-", compute-unit count, HBM bytes of the current device */
+int shl_mi355x_device_info(char *arch, size_t arch_len, int32_t *cu_count, int64_t *hbm_bytes);
+
+/* ---- memory and streams (stand in for hipMalloc/hipMemcpyAsync/hipStream*) --------- */
+void *shl_mi355x_malloc(size_t bytes);
+int shl_mi355x_free(void *ptr_dev);
+/* 1 if `ptr` is device memory of the current process, 0 if host/unknown */
+int shl_mi355x_is_device_ptr(const void *ptr);
+int shl_mi355x_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int shl_mi355x_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int shl_mi355x_copy(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+int shl_mi355x_memset(void *dst_dev, int byte_value, size_t bytes, void *stream);
+void *shl_mi355x_stream_create(void);
+int shl_mi355x_stream_destroy(void *stream);
+int shl_mi355x_stream_sync(void *stream);
+
+/* ---- timing on a stream (HIP events) ------------------------------------------------ */
+void *shl_mi355x_event_create(void);
+int shl_mi355x_event_destroy(void *event);
+int shl_mi355x_event_record(void *event, void *stream);
+/* waits for `stop`, then returns milliseconds between the two records */
+int shl_mi355x_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* ---- hipGraph capture of a launch sequence (launch-bound layer chains) --------------- */
+int shl_mi355x_graph_begin(void *stream);
+/* ends capture on `stream` and instantiates; returns an opaque executable graph or NULL */
+void *shl_mi355x_graph_end(void *stream);
+int shl_mi355x_graph_launch(void *graph_exec, void *stream);
+int shl_mi355x_graph_destroy(void *graph_exec);
+
+/* ---- conv2d / depthwise_conv2d / fullyconnected -------------------------------------- */
+
+/*
+ * Build the device-resident plan for one layer.
+ *
+ *   kernel_host   weights exactly as the csinn kernel tensor holds them
+ *                 (OHWI / 1HWO for NHWC, OIHW / O1HW for NCHW; [units,in] for FC),
+ *                 int8 or binary16.
+ *   mult_host     int8: out_c floats, s_in * s_kernel[oc]   (reference: the product of
+ *                 int8_to_float_base scales, source/nn2/utils.c:499-502)
+ *                 f16 : NULL
+ *   bias_host     out_c floats: the bias already converted to fp32 exactly as the
+ *                 reference does ((float)b * s_bias[oc], source/nn2/utils.c:509-512, plus
+ *                 the fuse_zp2bias correction of reference/convolution.c:375-395), or NULL
+ *                 for "no bias"
+ *
+ * Replaces the per-call work of shl_ref_conv_callback_base
+ * (source/reference/utils.c:639-655: dequantise kernel + bias on every call) and plays the
+ * role of the optimised backends' init-time weight reorder + zero-point fold
+ * (source/thead_rvv/int8/convolution.c:161-190).
+ */
+int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc,
+                                const void *kernel_host, const float *mult_host,
+                                const float *bias_host, void *stream,
+                                shl_mi355x_conv_plan **plan_out);
+int shl_mi355x_conv_plan_destroy(shl_mi355x_conv_plan *plan);
+/* the algorithm the plan resolved to (enum shl_mi355x_algo) and its kernel name */
+int shl_mi355x_conv_plan_algo(const shl_mi355x_conv_plan *plan);
+const char *shl_mi355x_conv_plan_kernel_name(const shl_mi355x_conv_plan *plan);
+/* bytes of packed weights + tables resident in HBM for this plan */
+size_t shl_mi355x_conv_plan_bytes(const shl_mi355x_conv_plan *plan);
+/*
+ * Weight broadcast support: expose the plan's constant HBM block so that the
+ * caller can ncclBroadcast it from rank 0; contents are position-independent.
+ */
+void *shl_mi355x_conv_plan_const_block(shl_mi355x_conv_plan *plan, size_t *bytes);
+
+/*
+ * Enqueue one forward pass: out = act(requant(conv(in))).
+ *
+ * int8 : bit-exact restatement of shl_ref_conv2d_quant / shl_ref_depthwise_conv2d_quant /
+ *        shl_ref_fullyconnected_quant (source/reference/convolution.c:370-400, :416-460,
+ *        fullyconnected.c:54-87) in exact integer arithmetic with an fp32 epilogue
+ *        (see DESIGN.md "numerical contract").
+ * f16  : same functions, dtype FLOAT16; fp32 accumulation, reference rounding on store.
+ *
+ * `batch` overrides desc.batch for this call (<= the plan's batch is NOT required: the plan
+ * is batch independent); pass 0 to use the plan's batch.
+ */
+int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev,
+                            void *output_dev, int32_t batch, void *stream);
+
+/* ---- elementwise neighbours of the path ---------------------------------- */
+/* relu / relu6 on a quantised int8 tensor: shl_ref_relu_quant / shl_ref_relu6_quant
+ * (source/reference/relu.c:21-43, relu6.c:21-43) */
+int shl_mi355x_relu_i8(const int8_t *input_dev, int8_t *output_dev, size_t count,
+                       float in_scale, int32_t in_zp, float out_scale, int32_t out_zp,
+                       int32_t relu6, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHL_MI355X_H_ */

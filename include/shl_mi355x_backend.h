@@ -1,0 +1,62 @@
+/*
+ * shl_mi355x_backend.h -- public surface of the source/mi355x_opt backend (host C code).
+ *
+ * The backend plugs into the CSI-NN2 front-end through the two registration calls of
+ * include/shl_utils.h (reference: source/nn2/setup.c:98-99,127-129), exactly like the
+ * reference's own optimised backends do (pattern: source/c920v2_opt/setup.c:391-413):
+ *
+ *     shl_target_init_mi355x();            // once, after the first csinn_alloc_session()
+ *     params->base.api = CSINN_MI355X;     // or sess->base_api for graph mode
+ *     csinn_conv2d_init(...); csinn_conv2d(...);
+ *
+ * Tensors may live on the host (any mtype except DMABUF: the backend stages them through HBM
+ * and synchronises before returning) or in HBM (mtype == CSINN_MEM_TYPE_DMABUF: `data` is a
+ * device pointer, nothing is copied and nothing synchronises -- this is the mode bench.py
+ * measures).
+ */
+#ifndef SHL_MI355X_BACKEND_H_
+#define SHL_MI355X_BACKEND_H_
+
+#include "shl_gref.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* registers the op map and the runtime map in slot CSINN_MI355X */
+void shl_target_init_mi355x(void);
+struct csinn_callback *shl_cb_map_mi355x(int op, int dtype);
+void *shl_mi355x_runtime_callback(int runtime_op);
+
+/* stream (opaque hipStream_t) on which subsequent exec callbacks enqueue; NULL = default */
+void shl_mi355x_set_stream(void *stream);
+void *shl_mi355x_get_stream(void);
+
+/* release the device plan attached to a params block by an init callback (the reference's
+ * optimised backends leak theirs: "XXX: memory leak", thead_rvv/int8/convolution.c:177) */
+int shl_mi355x_release_params(void *params);
+/* number of live plans and their total HBM bytes (leak checks in tests) */
+int shl_mi355x_live_plans(int64_t *hbm_bytes);
+/* device block of the plan attached to `params` (for the RCCL weight broadcast) */
+void *shl_mi355x_params_const_block(void *params, size_t *bytes);
+/* name of the HIP kernel the plan attached to `params` launches ("" if none) */
+const char *shl_mi355x_params_kernel_name(void *params);
+
+/* init / exec callbacks (exported so that a reference-side setup.c can list them) */
+int shl_mi355x_conv2d_init(CSINN_CONV_ARGS);
+int shl_mi355x_conv2d_exec(CSINN_CONV_ARGS);
+int shl_mi355x_fullyconnected_init(struct csinn_tensor *input, struct csinn_tensor *output,
+                                   struct csinn_tensor *weights, struct csinn_tensor *bias,
+                                   struct csinn_fc_params *params);
+int shl_mi355x_fullyconnected_exec(struct csinn_tensor *input, struct csinn_tensor *output,
+                                   struct csinn_tensor *weights, struct csinn_tensor *bias,
+                                   struct csinn_fc_params *params);
+int shl_mi355x_relu_exec(struct csinn_tensor *input, struct csinn_tensor *output,
+                         struct csinn_relu_params *params);
+int shl_mi355x_relu6_exec(struct csinn_tensor *input, struct csinn_tensor *output,
+                          struct csinn_relu_params *params);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHL_MI355X_BACKEND_H_ */
