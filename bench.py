@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X CSI-NN2 backend.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): MobileNetV1 int8 NHWC, batch 1 per
+GPU -- the 28 convolution layers of example/c906_mobilenetv1_f16.c (conv1, 13 x (depthwise 3x3 +
+pointwise 1x1) with fused ReLU, 1x1 classifier), synthetic seeded tensors in the exact-arithmetic
+quantisation regime, activations resident in HBM.  A "step" is one pass of all 28 layers over one
+image, dispatched through the C operator API (csinn_conv2d_relu on CSINN_MI355X) and replayed as
+one hipGraph so that the timed region contains no host work.  Batch-1 inference does not shard:
+with N GPUs every rank runs its own replica on its own image ("replicas only", weak scaling); the
+only communication is the one-time RCCL broadcast of rank 0's packed weights.
+
+The JSON line also carries
+  roofline     -- the dominant kernel function of the step (largest share of GPU time), its
+                  algorithmic bytes per launch over its average launch duration measured with HIP
+                  events on the launch stream, against the 8 TB/s HBM peak (MobileNetV1 at batch 1
+                  is HBM/latency bound: 78.7 op/B vs a ridge of ~630 op/B);
+  cpu_baseline -- the reference C backend (kind "reference": the genuine library built by
+                  oracle/Makefile.ref, or kind "port": this repo's oracle) timed on the host cores
+                  on a bounded sample of the same network;
+  extra        -- the ResNet-50 3x3 set at batch 128 (BASELINE configs[2], MFMA-bound) when
+                  --extra is given.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA, 2x the bf16 2.5 PF (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TFLOPS = 2500.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="mobilenetv1", choices=["mobilenetv1", "resnet50_3x3"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 1 mobilenetv1, 128 resnet50_3x3)")
+    ap.add_argument("--dtype", default="int8", choices=["int8", "f16"])
+    ap.add_argument("--layout", default="", choices=["", "NHWC", "NCHW"])
+    ap.add_argument("--extra", action="store_true", help="also time the ResNet-50 3x3 set at batch 128")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--detail", action="store_true", help="print the per-layer table to stderr")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline_worker(args):
+    """Runs in its own process (the genuine library and this repo's front-end export the same
+    csinn_* symbols).  Times whole MobileNetV1 images layer by layer through csinn_conv2d on
+    CSINN_REF (layer mode, NHWC, int8) until ~cpu-seconds have elapsed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    pkg = cases.pkg
+    wl = importlib.import_module("csi-nn2_amd.workloads")
+    layers = wl.MOBILENETV1
+    kind = "reference" if cases.have_reference() else "port"
+    cores = 1
+    if kind == "reference":
+        fe = pkg.load_frontend("reference")
+    else:
+        cores = cases.oracle_lib().oracle_num_threads()
+    budget = args.cpu_seconds
+    t_used, ops_done, layers_done = 0.0, 0, 0
+    images = 0
+    done = False
+    while not done:
+        for i, L in enumerate(layers):
+            case = cases.make_case(50 + i, n=1, h=L["h"], w=L["w"], c=L["cin"], co=L["cout"], k=(L["k"], L["k"]),
+                                   stride=(L["stride"],) * 2, pad=(L["pad"],) * 4, depthwise=L["depthwise"],
+                                   act=1 if L["act"] else 0)
+            t0 = time.perf_counter()
+            if kind == "reference":
+                cases.csinn_run(fe, pkg.API_REF, case)
+            else:
+                cases.oracle_run(case, "ref")
+            t_used += time.perf_counter() - t0
+            ops_done += wl.layer_ops(L)
+            layers_done += 1
+            if t_used > budget and layers_done >= len(layers):
+                done = True
+                break
+        images += 1
+        if t_used > budget:
+            done = True
+    print(json.dumps({"value": ops_done / t_used / 1e9, "unit": "GOPS", "cores": cores, "kind": kind,
+                      "imgs_per_sec": (ops_done / sum(wl.layer_ops(l) for l in layers)) / t_used,
+                      "sample": "%d MobileNetV1 int8 NHWC layer calls (%.2f images) via csinn_conv2d on %s, %.1f s"
+                                % (layers_done, ops_done / sum(wl.layer_ops(l) for l in layers),
+                                   "CSINN_REF of the genuine library" if kind == "reference" else "the oracle port",
+                                   t_used)}))
+
+
+def run_cpu_baseline(args):
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
+                              "--cpu-seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=600)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # the baseline is reported, never required
+        return {"value": None, "unit": "GOPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+# ------------------------------------------------------------------------------------ GPU side
+class TorchHBM:
+    """Device memory from torch (plumbing only): raw pointers go into csinn_tensor.data."""
+
+    def __init__(self, torch, device):
+        self.torch, self.device, self.live = torch, device, []
+
+    def alloc(self, nbytes):
+        t = self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+        self.live.append(t)
+        return t.data_ptr()
+
+    def upload(self, ptr, host):
+        t = next(x for x in self.live if x.data_ptr() == ptr)
+        flat = self.torch.from_numpy(np.ascontiguousarray(host).view(np.uint8).reshape(-1))
+        t[:flat.numel()].copy_(flat)
+        self.torch.cuda.synchronize()
+
+
+def time_groups(chain, hip, opt, stream, reps=20):
+    """Average launch duration per layer, measured with HIP events recorded on the launch stream
+    around `reps` back-to-back launches of that layer (captured in a graph: no host gaps)."""
+    out = []
+    ev0, ev1 = hip.shl_mi355x_event_create(), hip.shl_mi355x_event_create()
+    ms = C.c_float()
+    for i in range(len(chain.entries)):
+        opt.shl_mi355x_set_stream(stream)
+        hip.shl_mi355x_graph_begin(stream)
+        for _ in range(reps):
+            chain.run_layer(i)
+        g = hip.shl_mi355x_graph_end(stream)
+        hip.shl_mi355x_graph_launch(g, stream)  # warm
+        hip.shl_mi355x_stream_sync(stream)
+        best = []
+        for _ in range(3):
+            hip.shl_mi355x_event_record(ev0, stream)
+            hip.shl_mi355x_graph_launch(g, stream)
+            hip.shl_mi355x_event_record(ev1, stream)
+            hip.shl_mi355x_event_elapsed_ms(ev0, ev1, C.byref(ms))
+            best.append(ms.value / reps)
+        hip.shl_mi355x_graph_destroy(g)
+        out.append(float(np.median(best)) * 1e-3)  # seconds per launch
+    hip.shl_mi355x_event_destroy(ev0)
+    hip.shl_mi355x_event_destroy(ev1)
+    return out
+
+
+def summarise_kernels(chain, wl, per_layer_s, bound_hint):
+    groups = {}
+    for e, t in zip(chain.entries, per_layer_s):
+        g = groups.setdefault(e["kernel_name"], dict(time=0.0, bytes=0, ops=0, launches=0))
+        g["time"] += t
+        g["bytes"] += wl.layer_bytes(e["layer"], chain.batch, chain.esize)
+        g["ops"] += wl.layer_ops(e["layer"], chain.batch)
+        g["launches"] += 1
+    name, g = max(groups.items(), key=lambda kv: kv[1]["time"])
+    if bound_hint == "hbm":
+        achieved, peak, unit = g["bytes"] / g["time"] / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved = g["ops"] / g["time"] / 1e12
+        peak = I8_MFMA_PEAK_TOPS if chain.dtype == "int8" else F16_MFMA_PEAK_TFLOPS
+        unit = "TOP/s" if chain.dtype == "int8" else "TFLOP/s"
+    roof = {"bound": bound_hint, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+            "traffic": None, "kernel": name, "launches_per_step": g["launches"],
+            "avg_launch_us": g["time"] / g["launches"] * 1e6,
+            "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
+            "ops_per_launch": g["ops"] / g["launches"],
+            "share_of_step_time": g["time"] / sum(per_layer_s)}
+    return roof, groups
+
+
+def main():
+    args = parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("csi-nn2_amd")
+    wl = importlib.import_module("csi-nn2_amd.workloads")
+    par = importlib.import_module("csi-nn2_amd.sharding")
+    fe = pkg.load_frontend("standalone")
+    hip, opt = pkg.load_backend(fe)
+    pkg.check(hip.shl_mi355x_set_device(local_rank), hip, "set_device")
+    arch = C.create_string_buffer(64)
+    cus = C.c_int32()
+    hip.shl_mi355x_device_info(arch, 64, C.byref(cus), None)
+
+    hbm = TorchHBM(torch, torch.device("cuda", local_rank))
+    if args.workload == "mobilenetv1":
+        layers, batch, chained, bound = wl.MOBILENETV1, args.batch or 1, True, "hbm"
+        layout = args.layout or "NHWC"
+    else:
+        layers, batch, chained, bound = wl.RESNET50_3X3, args.batch or 128, False, "mfma"
+        layout = args.layout or "NHWC"
+    # rank 0 owns the real weights; other ranks build their plans from a different seed and must
+    # receive rank 0's packed blocks over RCCL before they can agree with it
+    chain = wl.LayerChain(fe, hip, opt, layers, batch, hbm.alloc, hbm.upload, dtype=args.dtype, layout=layout,
+                          seed=1234 if rank == 0 else 999 + rank, chained=chained)
+    if world > 1:
+        par.broadcast_plan_blocks(chain, torch, dist, hip, src=0)
+        par.assert_replicas_agree(chain, torch, dist, hip)
+
+    stream = hip.shl_mi355x_stream_create()
+    chain.capture(stream)
+    for _ in range(args.warmup):
+        chain.replay()
+    hip.shl_mi355x_stream_sync(stream)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chain.replay()
+    hip.shl_mi355x_stream_sync(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    images = world * batch * args.steps
+    ops_per_step = chain.total_ops() * world
+    result = {
+        "metric": "mobilenetv1_int8_images_per_sec" if args.workload == "mobilenetv1" else "resnet50_3x3_int8_conv_gops",
+        "value": images / elapsed if args.workload == "mobilenetv1" else ops_per_step * args.steps / elapsed / 1e9,
+        "unit": "img/s" if args.workload == "mobilenetv1" else "GOPS",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8" if args.dtype == "int8" else "f16", "data": "synthetic",
+        "conv_gops": ops_per_step * args.steps / elapsed / 1e9,
+        "images_per_sec": images / elapsed,
+        "config": {"workload": "%s %s %s, %d conv layers, batch %d per GPU, hipGraph replay via csinn_* C API"
+                               % (args.workload, args.dtype, layout, len(layers), batch),
+                   "per_gpu_batch": batch, "parallelism": "replicas x%d (batch shard, RCCL weight bcast)" % world,
+                   "ops_per_image": chain.total_ops() // batch, "algorithmic_bytes_per_image": chain.total_bytes() // batch,
+                   "device": arch.value.decode(), "compute_units": cus.value},
+    }
+
+    if rank == 0:
+        per_layer = time_groups(chain, hip, opt, stream)
+        roof, groups = summarise_kernels(chain, wl, per_layer, bound)
+        roof["mfma_frac_info"] = (chain.total_ops() / sum(per_layer) / 1e12) / (
+            I8_MFMA_PEAK_TOPS if args.dtype == "int8" else F16_MFMA_PEAK_TFLOPS)
+        result["roofline"] = roof
+        result["kernels"] = {k: {"launches": v["launches"], "us_total": v["time"] * 1e6,
+                                 "GBps": v["bytes"] / v["time"] / 1e9, "TOPs": v["ops"] / v["time"] / 1e12}
+                             for k, v in groups.items()}
+        result["sum_layer_us"] = sum(per_layer) * 1e6
+        if args.detail:
+            for e, t in zip(chain.entries, per_layer):
+                L = e["layer"]
+                sys.stderr.write("%-28s %-28s %8.2f us %8.1f GB/s %8.2f TOP/s\n" % (
+                    wl.layer_name(L), e["kernel_name"], t * 1e6,
+                    wl.layer_bytes(L, batch, chain.esize) / t / 1e9, wl.layer_ops(L, batch) / t / 1e12))
+        if args.extra and args.workload == "mobilenetv1":
+            hbm2 = TorchHBM(torch, torch.device("cuda", local_rank))
+            rc = wl.LayerChain(fe, hip, opt, wl.RESNET50_3X3, 128, hbm2.alloc, hbm2.upload, dtype=args.dtype,
+                               layout="NHWC", seed=4321, chained=False)
+            rt = time_groups(rc, hip, opt, stream, reps=3)
+            rroof, _ = summarise_kernels(rc, wl, rt, "mfma")
+            result["extra"] = {"workload": "resnet50 3x3 set int8 NHWC batch 128 (BASELINE configs[2])",
+                               "gops": rc.total_ops() / sum(rt) / 1e9, "ms_per_pass": sum(rt) * 1e3,
+                               "roofline": rroof}
+            rc.release()
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = run_cpu_baseline(args)
+        else:
+            result["cpu_baseline"] = {"value": None, "unit": "GOPS", "cores": 0, "kind": "port", "sample": "skipped"}
+        print(json.dumps(result))
+    chain.release()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

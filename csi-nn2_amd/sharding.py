@@ -1,0 +1,126 @@
+"""Multi-GPU support for the conv path: batch sharding + one-time weight broadcast.
+
+The path shards over the batch dimension only: images are independent, so each rank (one process
+per GPU) runs its own contiguous slice of the batch -- or, for batch-1 workloads, its own replica --
+with no collective on the data path.  The single exchange is at setup: rank 0 packs the weights
+(the plan's constant block: packed kernel + zero-point fold + scale/bias tables) and every other
+rank receives the bytes with an RCCL broadcast over xGMI.  Blocks are coalesced into a few large
+buckets so that the broadcast is a handful of big messages rather than one small one per layer
+(xGMI links are point-to-point: message count, not bytes, is what costs at this size).
+
+Everything here is written against a tiny "memory" interface so that the same code runs under
+gloo on CPU in the tests (world_size 2) and under nccl(=RCCL) on MI355X.
+"""
+import zlib
+
+import numpy as np
+
+BUCKET_BYTES = 64 << 20
+
+
+def shard_batch(total, world, rank):
+    """Contiguous slice [start, stop) of a batch of `total` images owned by `rank`.
+    The first total % world ranks take one extra image (ragged batches are allowed)."""
+    base, extra = divmod(int(total), int(world))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def plan_buckets(sizes, bucket_bytes=BUCKET_BYTES):
+    """Greedy coalescing of block sizes into buckets: list of lists of block indices."""
+    buckets, cur, cur_bytes = [], [], 0
+    for i, n in enumerate(sizes):
+        if cur and cur_bytes + n > bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(i)
+        cur_bytes += n
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+def broadcast_blocks(sizes, read_block, write_block, new_buffer, dist, src=0, bucket_bytes=BUCKET_BYTES):
+    """Broadcast opaque byte blocks from rank `src` to every rank.
+
+    sizes[i]               byte size of block i (identical on every rank)
+    read_block(i, view)    copy block i into the torch uint8 tensor `view`       (used on src)
+    write_block(i, view)   copy the torch uint8 tensor `view` into block i       (used elsewhere)
+    new_buffer(nbytes)     uint8 tensor on the device the process group works on
+    Returns the number of collectives issued.
+    """
+    rank = dist.get_rank()
+    issued = 0
+    for bucket in plan_buckets(sizes, bucket_bytes):
+        total = sum(sizes[i] for i in bucket)
+        buf = new_buffer(total)
+        off = 0
+        if rank == src:
+            for i in bucket:
+                read_block(i, buf[off:off + sizes[i]])
+                off += sizes[i]
+        dist.broadcast(buf, src=src)
+        issued += 1
+        if rank != src:
+            off = 0
+            for i in bucket:
+                write_block(i, buf[off:off + sizes[i]])
+                off += sizes[i]
+    return issued
+
+
+def broadcast_plan_blocks(chain, torch, dist, hip, src=0):
+    """RCCL broadcast of every layer's constant block of `chain` (workloads.LayerChain)."""
+    blocks = chain.const_blocks()
+    sizes = [n for _, n in blocks]
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def read_block(i, view):
+        hip.shl_mi355x_copy(view.data_ptr(), blocks[i][0], sizes[i], None)
+
+    def write_block(i, view):
+        hip.shl_mi355x_copy(blocks[i][0], view.data_ptr(), sizes[i], None)
+
+    def new_buffer(n):
+        return torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def synced_read(i, view):
+        read_block(i, view)
+        hip.shl_mi355x_stream_sync(None)
+
+    n = broadcast_blocks(sizes, synced_read, write_block, new_buffer, dist, src)
+    hip.shl_mi355x_stream_sync(None)
+    torch.cuda.synchronize()
+    return n
+
+
+def checksum_bytes(arr):
+    return zlib.crc32(np.ascontiguousarray(arr).view(np.uint8).tobytes())
+
+
+def assert_replicas_agree(chain, torch, dist, hip):
+    """After the weight broadcast every rank must hold identical plans: run the chain on a
+    rank-independent probe image and compare output checksums across ranks."""
+    sums = []
+    for e in chain.entries:
+        n = int(np.prod(e["in_dims"])) * chain.esize
+        probe = (np.arange(n, dtype=np.int64) * 37 % 251 - 125).astype(np.int8)
+        if chain.dtype != "int8":
+            probe = probe[: n // 2].astype(np.float16) / 64
+        hip.shl_mi355x_upload(e["d_in"], probe.ctypes.data, probe.nbytes, None)
+        hip.shl_mi355x_stream_sync(None)
+        chain.opt.shl_mi355x_set_stream(None)
+        rc = e["run"](*e["args"])
+        assert rc == 1
+        out = np.empty(int(np.prod(e["out_dims"])) * chain.esize, dtype=np.uint8)
+        hip.shl_mi355x_stream_sync(None)
+        hip.shl_mi355x_download(out.ctypes.data, e["d_out"], out.nbytes, None)
+        hip.shl_mi355x_stream_sync(None)
+        sums.append(checksum_bytes(out))
+    mine = torch.tensor(sums, dtype=torch.int64, device="cuda")
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not bool((lo == hi).all()):
+        raise RuntimeError("replicas disagree after the weight broadcast: %s" % (lo != hi).nonzero().flatten().tolist())
+    return True

@@ -1,0 +1,214 @@
+"""Workload tables and a layer-chain runner for the benchmark / smoke / tests.
+
+Shapes restate SURVEY.md 8(d):
+  * MOBILENETV1: the 28 convolution layers of example/c906_mobilenetv1_f16.c (conv1, 13 x
+    (depthwise 3x3, pointwise 1x1), classifier 1x1 1024->1000 on the pooled 1x1 map).
+  * RESNET50_3X3: the 16 3x3 convolutions of ResNet-50 v1.5 (7 distinct shapes x repeats).
+Op counts use the reference's own formula (source/utils/debug.c:1084-1120):
+  conv 2*Cout*Ho*Wo*Cin*Kh*Kw, depthwise 2*Cout*Ho*Wo*Kh*Kw, per image.
+Algorithmic bytes = input + weights + 4 B/ch bias + output at storage width (no im2col, no fp32
+temporaries), as fixed in SURVEY.md 8(d).
+
+LayerChain builds the layers through the C API (csinn_*_init with HBM-resident DMABUF tensors on
+CSINN_MI355X), runs them with csinn_* calls, and can capture the whole chain in a hipGraph through
+the C-ABI so that a replay contains no host work.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import (ACT_NONE, ACT_RELU, API_MI355X, CSINN_TRUE, DTYPE_FLOAT16, DTYPE_INT8, DTYPE_INT32,
+               LAYOUT_1HWO, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_O, LAYOUT_O1HW, LAYOUT_OHWI,
+               LAYOUT_OIHW, Keep, MI355XError, check, conv_params, layer_session, make_tensor)
+
+
+def _conv(cin, cout, hw, k, s, dw=False, act=ACT_RELU):
+    return dict(cin=cin, cout=cout, h=hw, w=hw, k=k, stride=s, pad=k // 2, depthwise=dw, act=act)
+
+
+def _mobilenet():
+    layers = [_conv(3, 32, 224, 3, 2)]
+    cfg = [(32, 64, 112, 1), (64, 128, 112, 2), (128, 128, 56, 1), (128, 256, 56, 2), (256, 256, 28, 1),
+           (256, 512, 28, 2)] + [(512, 512, 14, 1)] * 5 + [(512, 1024, 14, 2), (1024, 1024, 7, 1)]
+    for cin, cout, hw, s in cfg:
+        layers.append(_conv(cin, cin, hw, 3, s, dw=True))
+        layers.append(_conv(cin, cout, hw // s, 1, 1))
+    layers.append(_conv(1024, 1000, 1, 1, 1, act=ACT_NONE))  # classifier on the pooled map
+    return layers
+
+
+MOBILENETV1 = _mobilenet()
+
+RESNET50_3X3 = ([_conv(64, 64, 56, 3, 1)] * 3 + [_conv(128, 128, 56, 3, 2)] + [_conv(128, 128, 28, 3, 1)] * 3 +
+                [_conv(256, 256, 28, 3, 2)] + [_conv(256, 256, 14, 3, 1)] * 5 + [_conv(512, 512, 14, 3, 2)] +
+                [_conv(512, 512, 7, 3, 1)] * 2)
+
+
+def out_hw(layer):
+    return (layer["h"] + 2 * layer["pad"] - layer["k"]) // layer["stride"] + 1
+
+
+def layer_ops(layer, batch=1):
+    ho = out_hw(layer)
+    cin_eff = 1 if layer["depthwise"] else layer["cin"]
+    return 2 * batch * layer["cout"] * ho * ho * cin_eff * layer["k"] * layer["k"]
+
+
+def layer_bytes(layer, batch=1, esize=1):
+    ho = out_hw(layer)
+    cin_eff = 1 if layer["depthwise"] else layer["cin"]
+    bias_b = 4 if esize == 1 else 2
+    return (batch * layer["cin"] * layer["h"] * layer["w"] * esize +
+            layer["cout"] * cin_eff * layer["k"] * layer["k"] * esize + layer["cout"] * bias_b +
+            batch * layer["cout"] * ho * ho * esize)
+
+
+def layer_name(layer):
+    kind = "dw" if layer["depthwise"] else "conv"
+    return "%s%dx%d_s%d_%d->%d@%d" % (kind, layer["k"], layer["k"], layer["stride"], layer["cin"], layer["cout"],
+                                      layer["h"])
+
+
+def synth_layer_operands(layer, seed, dtype="int8", layout="NHWC", in_scale=None):
+    """Seeded weights / bias / quantisation records in SURVEY 8(d)'s exact regime (power-of-two
+    scales, bias scale = s_in * s_k); `in_scale` is the producer's output scale in a chain."""
+    rng = np.random.default_rng(seed)
+    k, cin, cout = layer["k"], layer["cin"], layer["cout"]
+    cpg = 1 if layer["depthwise"] else cin
+    if layer["depthwise"]:
+        wshape = (1, k, k, cout) if layout == "NHWC" else (cout, 1, k, k)
+    else:
+        wshape = (cout, k, k, cpg) if layout == "NHWC" else (cout, cpg, k, k)
+    if dtype == "int8":
+        kernel = rng.integers(-32, 32, wshape, dtype=np.int8)
+        bias = rng.integers(-10000, 10001, (cout,), dtype=np.int32)
+        s_in, s_k = (in_scale if in_scale else 2.0 ** -4), 2.0 ** -7
+        sigma = np.sqrt(k * k * cpg) * 37.0 * 18.5 * s_in * s_k
+        s_out = float(2.0 ** np.ceil(np.log2(3.0 * max(sigma, 20.0 * s_in * s_k * 250) / 127.0)))
+        return dict(kernel=kernel, bias=bias, in_scale=s_in, in_zp=-5, k_scale=s_k, b_scale=s_in * s_k,
+                    out_scale=s_out, out_zp=7)
+    kernel = (0.1 * rng.standard_normal(wshape)).astype(np.float16)
+    bias = rng.standard_normal((cout,)).astype(np.float16)
+    return dict(kernel=kernel, bias=bias, in_scale=1.0, in_zp=0, k_scale=1.0, b_scale=1.0, out_scale=1.0, out_zp=0)
+
+
+class LayerChain:
+    """A list of independent or chained conv layers living in HBM, driven through the C API.
+
+    alloc(nbytes) -> device pointer is supplied by the caller (torch or the C-ABI allocator).
+    chained=True feeds layer i's output to layer i+1 when shapes allow (MobileNetV1 body);
+    otherwise every layer reads its own synthetic input (ResNet-50 3x3 set, classifier).
+    """
+
+    def __init__(self, fe, hip, opt, layers, batch, alloc, upload, dtype="int8", layout="NHWC", seed=1234,
+                 chained=True):
+        self.fe, self.hip, self.opt = fe, hip, opt
+        self.layers, self.batch, self.dtype, self.layout = layers, batch, dtype, layout
+        self.keep = Keep()
+        self.sess = layer_session(fe, API_MI355X, self.keep)
+        self.esize = 1 if dtype == "int8" else 2
+        self.entries = []
+        dt = DTYPE_INT8 if dtype == "int8" else DTYPE_FLOAT16
+        nhwc = layout == "NHWC"
+        act_l = LAYOUT_NHWC if nhwc else LAYOUT_NCHW
+        prev_out = None
+        prev_desc = None
+        for i, L in enumerate(layers):
+            ho = out_hw(L)
+            in_dims = (batch, L["h"], L["w"], L["cin"]) if nhwc else (batch, L["cin"], L["h"], L["w"])
+            out_dims = (batch, ho, ho, L["cout"]) if nhwc else (batch, L["cout"], ho, ho)
+            in_bytes = int(np.prod(in_dims)) * self.esize
+            out_bytes = int(np.prod(out_dims)) * self.esize
+            reuse = chained and prev_out is not None and prev_desc == in_dims
+            ops = synth_layer_operands(L, seed + i, dtype, layout, prev_out[1] if reuse else None)
+            if reuse:
+                d_in, in_scale, in_zp = prev_out
+            else:
+                d_in = alloc(in_bytes)
+                rng = np.random.default_rng(seed + 1000 + i)
+                if dtype == "int8":
+                    host = rng.integers(-64, 64, in_dims, dtype=np.int8)
+                else:
+                    host = rng.standard_normal(in_dims).astype(np.float16)
+                upload(d_in, host)
+                in_scale, in_zp = ops["in_scale"], ops["in_zp"]
+            d_out = alloc(out_bytes)
+            t_in = make_tensor(fe, self.keep, in_dims, dt, act_l, scales=(in_scale,), zps=(in_zp,),
+                               name=b"in", sess=self.sess, device_ptr=d_in)
+            t_out = make_tensor(fe, self.keep, out_dims, dt, act_l, scales=(ops["out_scale"],),
+                                zps=(ops["out_zp"],), name=b"out", sess=self.sess, device_ptr=d_out)
+            if L["depthwise"]:
+                w_l = LAYOUT_1HWO if nhwc else LAYOUT_O1HW
+            else:
+                w_l = LAYOUT_OHWI if nhwc else LAYOUT_OIHW
+            # bias scale follows the actual input scale of a chained layer
+            b_scale = in_scale * ops["k_scale"] if dtype == "int8" else 1.0
+            t_w = make_tensor(fe, self.keep, ops["kernel"].shape, dt, w_l, data=ops["kernel"],
+                              scales=(ops["k_scale"],), zps=(0,), is_const=1, name=b"w", sess=self.sess)
+            t_b = make_tensor(fe, self.keep, (L["cout"],), DTYPE_INT32 if dtype == "int8" else dt, LAYOUT_O,
+                              data=ops["bias"], scales=(b_scale,), zps=(0,), is_const=1, name=b"b", sess=self.sess)
+            params = conv_params(fe, self.keep, API_MI355X, act_l, (L["stride"],) * 2, (L["pad"],) * 4, (1, 1),
+                                 L["cin"] if L["depthwise"] else 1, 0, self.sess)
+            relu = L["act"] == ACT_RELU
+            init = fe.csinn_conv2d_relu_init if relu else fe.csinn_conv2d_init
+            run = fe.csinn_conv2d_relu if relu else fe.csinn_conv2d
+            rc = init(t_in, t_out, t_w, t_b, params)
+            if rc != CSINN_TRUE:
+                raise MI355XError("init of layer %d (%s) returned %d" % (i, layer_name(L), rc))
+            self.entries.append(dict(layer=L, run=run, args=(t_in, t_out, t_w, t_b, params), d_in=d_in, d_out=d_out,
+                                     in_dims=in_dims, out_dims=out_dims, params=params, ops=ops,
+                                     in_scale=in_scale, in_zp=in_zp,
+                                     kernel_name=opt.shl_mi355x_params_kernel_name(params).decode()))
+            prev_out = (d_out, ops["out_scale"], ops["out_zp"])
+            prev_desc = out_dims
+        self.graph = None
+
+    # ---- execution ----------------------------------------------------------------------------
+    def run_layer(self, i):
+        e = self.entries[i]
+        rc = e["run"](*e["args"])
+        if rc != CSINN_TRUE:
+            raise MI355XError("layer %d returned %d" % (i, rc))
+
+    def run_eager(self):
+        for i in range(len(self.entries)):
+            self.run_layer(i)
+
+    def capture(self, stream):
+        """Record one pass of the chain on `stream` into a hipGraph (C-ABI graph entry points)."""
+        self.opt.shl_mi355x_set_stream(stream)
+        check(self.hip.shl_mi355x_graph_begin(stream), self.hip, "graph_begin")
+        try:
+            self.run_eager()
+        finally:
+            g = self.hip.shl_mi355x_graph_end(stream)
+        if not g:
+            raise MI355XError("graph capture failed: " + self.hip.shl_mi355x_last_error().decode())
+        self.graph, self.stream = g, stream
+        return g
+
+    def replay(self):
+        check(self.hip.shl_mi355x_graph_launch(self.graph, self.stream), self.hip, "graph_launch")
+
+    # ---- accounting ---------------------------------------------------------------------------
+    def total_ops(self):
+        return sum(layer_ops(e["layer"], self.batch) for e in self.entries)
+
+    def total_bytes(self):
+        return sum(layer_bytes(e["layer"], self.batch, self.esize) for e in self.entries)
+
+    def const_blocks(self):
+        """[(device pointer, bytes)] of every layer's packed weights + tables (RCCL broadcast)."""
+        out = []
+        for e in self.entries:
+            n = C.c_size_t()
+            p = self.opt.shl_mi355x_params_const_block(e["params"], C.byref(n))
+            out.append((p, n.value))
+        return out
+
+    def release(self):
+        if self.graph:
+            self.hip.shl_mi355x_graph_destroy(self.graph)
+            self.graph = None
+        for e in self.entries:
+            self.opt.shl_mi355x_release_params(e["params"])

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure the native libraries exist (built in-tree by csi-nn2_amd/build.py)."""
+    import cases
+    lib = cases.pkg.lib_path("libshl_mi355x.so")
+    if not (os.path.exists(lib) and os.path.exists(cases.pkg.lib_path("libcsinn_nn2.so"))
+            and os.path.exists(cases.pkg.lib_path("libshl_mi355x_opt.so"))):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("build", os.path.join(cases.ROOT, "csi-nn2_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build_all(oracle=True)
+    return True
+
+
+@pytest.fixture(scope="session")
+def standalone(built):
+    """(front-end, hip library, backend library) of the product, backend registered."""
+    import cases
+    fe = cases.pkg.load_frontend("standalone")
+    hip, opt = cases.pkg.load_backend(fe)
+    return fe, hip, opt

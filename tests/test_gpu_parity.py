@@ -1,0 +1,293 @@
+"""Parity of the HIP path with the reference, on a real MI355X (pytest -m gpu).
+
+Every test drives the product through its C entry points -- csinn_conv2d & co. of the front-end
+with params->base.api = CSINN_MI355X, or the C-ABI of include/shl_mi355x.h -- and checks the
+result against (a) golden vectors produced by the genuine reference, (b) the CPU oracle on the
+same seeded inputs.  int8 must be bit-exact against oracle formulation X always, and against the
+reference in the exact-arithmetic regime; fp16 within 1e-3 relative (bit-exact where the kernel
+keeps the reference's summation order).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import golden_util
+from cases import NCHW, NHWC, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(standalone):
+    fe, hip, opt = standalone
+    assert hip.shl_mi355x_device_count() >= 1, "no MI355X visible: " + hip.shl_mi355x_last_error().decode()
+    arch = C.create_string_buffer(64)
+    cus = C.c_int32()
+    mem = C.c_int64()
+    pkg.check(hip.shl_mi355x_device_info(arch, 64, C.byref(cus), C.byref(mem)), hip, "device_info")
+    assert arch.value.decode().startswith("gfx950"), arch.value
+    return fe, hip, opt, cases.HipDevice(hip)
+
+
+def _check(case, got, expected, what, kernel_name=""):
+    if case["dtype"] == "int8":
+        golden_util.compare(case, got, expected, what)
+    elif "igemm" in kernel_name:
+        golden_util.compare_f16_tol(got, expected, what)          # different summation order
+    else:
+        golden_util.compare(case, got, expected, what)            # reference order: bit-exact
+
+
+def _run(gpu, case, device_tensors):
+    fe, hip, opt, dev = gpu
+    kept = []
+    got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev if device_tensors else None, keep_params=kept)
+    name = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
+    assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
+    return got, name
+
+
+@pytest.mark.parametrize("name", golden_util.GOLDEN_NAMES)
+def test_reference_golden_vectors_host_tensors(gpu, name):
+    case, expected = golden_util.load(name)
+    got, kname = _run(gpu, case, device_tensors=False)
+    _check(case, got, expected, "%s via %s" % (name, kname), kname)
+
+
+@pytest.mark.parametrize("name", golden_util.GOLDEN_NAMES)
+def test_reference_golden_vectors_hbm_tensors(gpu, name):
+    case, expected = golden_util.load(name)
+    got, kname = _run(gpu, case, device_tensors=True)
+    _check(case, got, expected, "%s via %s (DMABUF)" % (name, kname), kname)
+
+
+# shapes chosen to hit every tiling edge of the MFMA kernel: M and Co not multiples of 128,
+# several K steps, K chunks straddling taps (C=16,32,48), stride/dilation/asymmetric padding,
+# batch > 1, plus the direct and depthwise kernels' own edges
+SHAPES = [
+    dict(c=16, co=16), dict(c=32, co=24, h=9, w=7), dict(c=48, co=130, h=5, w=5),
+    dict(c=64, co=64, h=28, w=28), dict(c=64, co=200, h=13, w=11, n=3),
+    dict(c=128, co=128, h=14, w=14, stride=(2, 2)), dict(c=64, co=32, dilation=(2, 2), pad=(2, 2, 2, 2)),
+    dict(c=32, co=64, k=(1, 1), pad=(0, 0, 0, 0), h=20, w=20), dict(c=256, co=64, k=(1, 1), pad=(0, 0, 0, 0), h=7, w=7, n=2),
+    dict(c=16, co=8, k=(5, 3), pad=(2, 1, 2, 1)), dict(c=80, co=48, pad=(0, 1, 2, 0), stride=(1, 2)),
+    dict(c=512, co=16, h=6, w=6), dict(c=3, co=32, h=32, w=32, stride=(2, 2)),
+    dict(c=20, co=20), dict(layout=NCHW, c=16, co=16), dict(layout=NCHW, c=64, co=48, n=2, h=9, w=9, stride=(2, 2)),
+    dict(depthwise=True, c=32, h=12, w=12), dict(depthwise=True, c=64, stride=(2, 2), h=15, w=15),
+    dict(depthwise=True, c=6), dict(depthwise=True, multiplier=2, c=8), dict(depthwise=True, layout=NCHW, c=24),
+    dict(depthwise=True, c=1024, h=7, w=7, n=2), dict(fc=True, n=1, c=1024, co=1000), dict(fc=True, n=16, c=256, co=100),
+    dict(fc=True, n=5, c=33, co=7), dict(act=1, c=32, co=32), dict(act=2, c=32, co=32),
+    dict(per_channel=True, c=32, co=40), dict(fuse_zp2bias=True, c=32, co=32), dict(has_bias=False, c=32, co=32),
+    dict(depthwise=True, act=1, per_channel=True, c=16), dict(depthwise=True, fuse_zp2bias=True, c=16),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(SHAPES)))
+@pytest.mark.parametrize("exact", [True, False])
+def test_int8_bit_exact_against_oracle(gpu, idx, exact):
+    case = cases.make_case(4000 + idx, exact=exact, **SHAPES[idx])
+    got, kname = _run(gpu, case, device_tensors=bool(idx % 2))
+    want = cases.oracle_run(case, "exact")
+    count, worst = cases.mismatch_report(got, want)
+    assert count == 0, "shape %d via %s: %d mismatches vs formulation X (max %d)" % (idx, kname, count, worst)
+    ref = cases.oracle_run(case, "ref")
+    golden_util.compare(case, got, ref, "shape %d via %s vs formulation R" % (idx, kname))
+
+
+F16_SHAPES = [
+    dict(c=16, co=16), dict(c=64, co=72, h=14, w=14, n=2), dict(c=8, co=8, stride=(2, 2)), dict(c=3, co=16),
+    dict(c=40, co=24, k=(1, 1), pad=(0, 0, 0, 0)), dict(layout=NCHW, c=16, co=16), dict(depthwise=True, c=32),
+    dict(depthwise=True, layout=NCHW, c=8), dict(depthwise=True, c=64, act=1, stride=(2, 2)), dict(fc=True, n=4, c=128, co=40),
+    dict(c=256, co=64, h=7, w=7, act=2), dict(c=1024, co=32, k=(1, 1), pad=(0, 0, 0, 0), h=4, w=4),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(F16_SHAPES)))
+def test_fp16_against_oracle(gpu, idx):
+    case = cases.make_case(5000 + idx, dtype="f16", **F16_SHAPES[idx])
+    got, kname = _run(gpu, case, device_tensors=bool(idx % 2))
+    want = cases.oracle_run(case, "f16")
+    _check(case, got, want, "fp16 shape %d via %s" % (idx, kname), kname)
+
+
+def _plan_forward(hip, dev, case, algo):
+    """Drive the C-ABI directly with a forced algorithm."""
+    d = pkg.ConvDesc()
+    d.layout = pkg.SHL_NHWC if case["layout"] == NHWC else pkg.SHL_NCHW
+    d.dtype = pkg.SHL_I8 if case["dtype"] == "int8" else pkg.SHL_F16
+    d.act, d.algo = case["act"], algo
+    d.batch, d.in_h, d.in_w, d.in_c = case["n"], case["h"], case["w"], case["c"]
+    d.out_h, d.out_w, d.out_c = case["ho"], case["wo"], case["co"]
+    d.kernel_h, d.kernel_w = case["kh"], case["kw"]
+    d.stride_h, d.stride_w = case["stride"]
+    d.pad_top, d.pad_left = case["pad"][0], case["pad"][1]
+    d.dilation_h, d.dilation_w = case["dilation"]
+    d.group = case["group"]
+    d.in_zp, d.out_zp, d.out_scale = case["in_zp"], case["out_zp"], case["out_scale"]
+    mult = (np.float32(case["in_scale"]) * np.broadcast_to(case["k_scale"], (case["co"],))).astype(np.float32)
+    bias = (case["bias"].astype(np.float32) * np.broadcast_to(case["b_scale"], (case["co"],))).astype(np.float32)
+    ker = np.ascontiguousarray(case["kernel"])
+    plan = C.c_void_p()
+    pkg.check(hip.shl_mi355x_conv_plan_create(C.byref(d), ker.ctypes.data, mult.ctypes.data, bias.ctypes.data,
+                                              None, C.byref(plan)), hip, "plan_create")
+    out = np.zeros(case["out_shape"], dtype=np.int8 if case["dtype"] == "int8" else np.float16)
+    din, dout = dev.alloc(case["input"].nbytes), dev.alloc(out.nbytes)
+    dev.upload(din, case["input"])
+    pkg.check(hip.shl_mi355x_conv_forward(plan, din, dout, 0, None), hip, "forward")
+    got = dev.download(dout, out.shape, out.dtype)
+    name = hip.shl_mi355x_conv_plan_kernel_name(plan).decode()
+    dev.free(din)
+    dev.free(dout)
+    pkg.check(hip.shl_mi355x_conv_plan_destroy(plan), hip, "destroy")
+    return got, name
+
+
+@pytest.mark.parametrize("kw", [dict(c=64, co=96, h=17, w=9, n=2, stride=(2, 1)), dict(c=32, co=32, k=(1, 1), pad=(0, 0, 0, 0)),
+                                dict(depthwise=True, c=48, h=11, w=11)])
+def test_kernels_agree_with_each_other(gpu, kw):
+    """The MFMA / depthwise kernels against the one-thread-per-output kernel, same plan API."""
+    fe, hip, opt, dev = gpu
+    case = cases.make_case(77, **kw)
+    fast, fast_name = _plan_forward(hip, dev, case, pkg.ALGO_AUTO)
+    slow, slow_name = _plan_forward(hip, dev, case, pkg.ALGO_DIRECT)
+    assert fast_name != slow_name and "direct" in slow_name
+    assert np.array_equal(fast, slow), "%s and %s disagree" % (fast_name, slow_name)
+
+
+def test_relu_kernels(gpu):
+    fe, hip, opt, dev = gpu
+    rng = np.random.default_rng(3)
+    x = rng.integers(-128, 128, 100003, dtype=np.int8)
+    lib = cases.oracle_lib()
+    for relu6 in (0, 1):
+        want = np.zeros_like(x)
+        lib.oracle_relu_i8(C.c_void_p(x.ctypes.data), C.c_void_p(want.ctypes.data), C.c_int64(x.size),
+                           C.c_float(0.0625), C.c_int32(-3), C.c_float(0.047), C.c_int32(5), C.c_int32(relu6))
+        din, dout = dev.alloc(x.nbytes), dev.alloc(x.nbytes)
+        dev.upload(din, x)
+        pkg.check(hip.shl_mi355x_relu_i8(din, dout, x.size, 0.0625, -3, 0.047, 5, relu6, None), hip, "relu")
+        got = dev.download(dout, x.shape, x.dtype)
+        assert np.array_equal(got, want)
+        dev.free(din)
+        dev.free(dout)
+
+
+# ---- full-size checks: BASELINE.json shapes, oracle where it finishes in seconds, otherwise
+# size-independent properties -------------------------------------------------------------------
+def test_mobilenet_first_layers_full_size(gpu):
+    """conv1 3->32 3x3 s2 @224, dw 3x3 @112 x32, pw 1x1 32->64 @112 (example/c906_mobilenetv1_f16.c
+    shapes, int8 NHWC) against the oracle."""
+    for seed, kw in enumerate([dict(h=224, w=224, c=3, co=32, stride=(2, 2), act=1),
+                               dict(h=112, w=112, c=32, depthwise=True, act=1),
+                               dict(h=112, w=112, c=32, co=64, k=(1, 1), pad=(0, 0, 0, 0), act=1)]):
+        case = cases.make_case(600 + seed, **kw)
+        got, kname = _run(gpu, case, device_tensors=True)
+        want = cases.oracle_run(case, "exact")
+        assert np.array_equal(got, want), kname
+
+
+def test_resnet_3x3_full_size_properties(gpu):
+    """ResNet-50 3x3 @56x56 64->64, batch 8 (M = 25088): image 0 against the oracle, then
+    (1) every image equals its own single-image run (no cross-image leakage in the M tiling),
+    (2) permuting input channels together with the weights leaves the output unchanged."""
+    fe, hip, opt, dev = gpu
+    case = cases.make_case(901, n=8, h=56, w=56, c=64, co=64)
+    got, kname = _run(gpu, case, device_tensors=True)
+    assert "igemm" in kname
+    one = dict(case, n=1, input=case["input"][:1], in_shape=(1,) + case["in_shape"][1:],
+               out_shape=(1,) + case["out_shape"][1:])
+    assert np.array_equal(got[:1], cases.oracle_run(one, "exact"))
+    for i in (3, 7):
+        sub = dict(one, input=case["input"][i:i + 1])
+        single, _ = _run(gpu, sub, device_tensors=True)
+        assert np.array_equal(single, got[i:i + 1])
+    perm = np.random.default_rng(1).permutation(64)
+    shuffled = dict(case, input=np.ascontiguousarray(case["input"][..., perm]),
+                    kernel=np.ascontiguousarray(case["kernel"][..., perm]))
+    again, _ = _run(gpu, shuffled, device_tensors=True)
+    assert np.array_equal(again, got)
+
+
+def test_zero_weights_give_requantised_bias(gpu):
+    case = cases.make_case(902, n=2, h=28, w=28, c=128, co=128)
+    case["kernel"] = np.zeros_like(case["kernel"])
+    got, _ = _run(gpu, case, device_tensors=True)
+    lib = cases.oracle_lib()
+    per_oc = np.array([lib.oracle_float_to_int8(np.float32(np.float32(b) * np.float32(case["b_scale"][0])),
+                                                np.float32(case["out_scale"]), case["out_zp"])
+                       for b in case["bias"]], dtype=np.int8)
+    assert np.array_equal(got, np.broadcast_to(per_oc, got.shape))
+
+
+# ---- behaviour around the boundary ----------------------------------------------------------------
+def test_exec_without_init_fails_loudly(gpu):
+    fe, hip, opt, dev = gpu
+    keep = pkg.Keep()
+    sess = pkg.layer_session(fe, pkg.API_MI355X, keep)
+    case = cases.make_case(1)
+    t = pkg.make_tensor(fe, keep, case["in_shape"], pkg.DTYPE_INT8, pkg.LAYOUT_NHWC, data=case["input"], sess=sess)
+    o = pkg.make_tensor(fe, keep, case["out_shape"], pkg.DTYPE_INT8, pkg.LAYOUT_NHWC,
+                        data=np.zeros(case["out_shape"], np.int8), sess=sess)
+    w = pkg.make_tensor(fe, keep, case["w_shape"], pkg.DTYPE_INT8, pkg.LAYOUT_OHWI, data=case["kernel"], sess=sess)
+    b = pkg.make_tensor(fe, keep, (case["co"],), pkg.DTYPE_INT32, pkg.LAYOUT_O, data=case["bias"], sess=sess)
+    params = pkg.conv_params(fe, keep, pkg.API_MI355X, pkg.LAYOUT_NHWC, pad=(1, 1, 1, 1), sess=sess)
+    # map callbacks by hand, skipping init
+    import ctypes
+    opt.shl_cb_map_mi355x.restype = ctypes.POINTER(pkg.Callback)
+    cb = opt.shl_cb_map_mi355x(pkg.OP_CONV2D, pkg.DTYPE_INT8)
+    ctypes.memmove(ctypes.cast(params, ctypes.POINTER(pkg.Conv2dParams)).contents.base.cb, cb, ctypes.sizeof(pkg.Callback))
+    assert fe.csinn_conv2d(t, o, w, b, params) != pkg.CSINN_TRUE
+
+
+def test_unsupported_requests_are_refused(gpu):
+    fe, hip, opt, dev = gpu
+    case = cases.make_case(5, c=32, co=32)
+    case["k_zp"] = np.array([3], dtype=np.int32)       # asymmetric weights
+    with pytest.raises(pkg.MI355XError):
+        cases.csinn_run(fe, pkg.API_MI355X, case)
+    before = opt.shl_mi355x_live_plans(None)
+    grouped = cases.make_case(6, c=32, co=32)
+    grouped["group"] = 4                                 # grouped conv: refused
+    grouped["kernel"] = grouped["kernel"][..., :8].copy()
+    grouped["w_shape"] = grouped["kernel"].shape
+    with pytest.raises(pkg.MI355XError):
+        cases.csinn_run(fe, pkg.API_MI355X, grouped)
+    assert opt.shl_mi355x_live_plans(None) == before
+
+
+DROPIN = r"""
+import sys
+sys.path.insert(0, %(tests)r)
+import numpy as np
+import cases
+from cases import pkg
+fe = pkg.load_frontend("reference")          # genuine libshl_ref_x86.so, unmodified
+hip, opt = pkg.load_backend(fe)              # backend registers itself in slot CSINN_ASP (14)
+dev = cases.HipDevice(hip)
+bad = 0
+for i, kw in enumerate([dict(c=64, co=64, h=28, w=28), dict(layout="NCHW", c=16, co=24),
+                        dict(depthwise=True, c=32, act=1), dict(fc=True, n=4, c=256, co=100),
+                        dict(c=32, co=48, stride=(2, 2), per_channel=True, act=2)]):
+    case = cases.make_case(300 + i, **kw)
+    want = cases.csinn_run(fe, pkg.API_REF, case)             # reference C backend, same library
+    got = cases.csinn_run(fe, pkg.API_MI355X, case)           # same front-end, MI355X backend
+    got_dev = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev)
+    n1, _ = cases.mismatch_report(got, want)
+    n2, _ = cases.mismatch_report(got_dev, want)
+    print("case", i, "mismatches", n1, n2)
+    bad += n1 + n2
+print("DROPIN_OK" if bad == 0 else "DROPIN_FAIL")
+"""
+
+
+@pytest.mark.skipif(not cases.have_reference(), reason="oracle/_ref/libshl_ref_x86.so not present")
+def test_drop_in_behind_the_genuine_front_end(gpu):
+    """The compiled backend, loaded next to the UNMODIFIED reference library, is reached through
+    the reference's own csinn_conv2d_init / csinn_conv2d and agrees bit-for-bit with CSINN_REF."""
+    code = DROPIN % dict(tests=os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "DROPIN_OK" in res.stdout, res.stdout + res.stderr
