@@ -43,9 +43,22 @@ struct ConvArgs {
     int32_t act;
     float out_scale;
     float out_zp_f;
-    float inv_out_scale;  // f16 only: 1/out_scale, applied when out_scale != 1
+    float inv_out_scale;  // 1/out_scale (f16: applied when out_scale != 1; int8: see div_exact)
     int32_t scale_out;    // f16 only: out_scale differs from 1
+    // int8 epilogue shortcuts, all bit-identical to the literal formula (derived and verified on
+    // the host at plan time, conv_plan.hip):
+    int32_t div_exact;    // out_scale is a power of two: f / s == f * inv_out_scale exactly
+    int32_t act_clamp;    // saturation + relu/relu6 collapse into clamp(r, clamp_lo, clamp_hi)
+    int32_t out_zp;
+    float clamp_lo;       // act_clamp (or no activation): lower / upper bound applied to
+    float clamp_hi;       //   r = rint(f / s_out) + zp_out before the conversion to int8
+    int32_t debug;        // ablation switches for tools/kbench.py (SHL_MI355X_DEBUG): 1 skip K loop, 2 skip stores
+    const void *pad_page; // PAD_PAGE_BYTES of HBM filled with the padding value (zp_in / 0)
 };
+
+// The pad page is 4 KiB so that concurrent readers can be spread over 32 cache lines instead of
+// hammering one L2 channel (out-of-image taps of every block read it).
+constexpr int PAD_PAGE_BYTES = 4096;
 
 // ---- int8 epilogue ---------------------------------------------------------------------
 __device__ __forceinline__ int sat8_from_float(float r)
@@ -70,6 +83,52 @@ __device__ __forceinline__ int requant_i8(int32_t S, float mult, float bias_f, f
         q = sat8_from_float(r);
     }
     return q;
+}
+
+// Epilogue code selected at compile time: EPI = 3 * div_exact + act_mode with act_mode
+//   0  no activation                 (clamp to [-128, 127])
+//   1  relu / relu6 as a clamp       (clamp to [requant(0), requant(6) or 127]; valid when the
+//                                     plan verified all 256 int8 inputs against the literal code)
+//   2  literal dequantise-relu-requantise
+__host__ __device__ inline int epi_code(const ConvArgs &a)
+{
+    const int act_mode = a.act == SHL_MI355X_ACT_NONE ? 0 : (a.act_clamp ? 1 : 2);
+    return (a.div_exact ? 3 : 0) + act_mode;
+}
+
+template <int EPI>
+__device__ __forceinline__ int requant_i8_t(int32_t S, float mult, float bias_f, const ConvArgs &a)
+{
+    const float f = __fadd_rn(__fmul_rn((float)S, mult), bias_f);
+    const float quot = (EPI >= 3) ? __fmul_rn(f, a.inv_out_scale) : __fdiv_rn(f, a.out_scale);
+    const float r = __fadd_rn(rintf(quot), a.out_zp_f);
+    constexpr int kAct = EPI % 3;
+    if constexpr (kAct != 2) {
+        // one v_med3_f32: saturation (and the activation) in the float domain, then truncate
+        return (int)__builtin_amdgcn_fmed3f(r, a.clamp_lo, a.clamp_hi);
+    } else {
+        int q = sat8_from_float(r);
+        float x = __fmul_rn(__fsub_rn((float)q, a.out_zp_f), a.out_scale);
+        x = x > 0.0f ? x : 0.0f;
+        if (a.act == SHL_MI355X_ACT_RELU6) x = fminf(x, 6.0f);
+        return sat8_from_float(__fadd_rn(rintf(__fdiv_rn(x, a.out_scale)), a.out_zp_f));
+    }
+}
+
+// run-time dispatch of the same code (kernels that are not specialised on EPI)
+__device__ __forceinline__ int requant_i8_fast(int32_t S, float mult, float bias_f, const ConvArgs &a)
+{
+    if (a.act != SHL_MI355X_ACT_NONE && !a.act_clamp)
+        return a.div_exact ? requant_i8_t<5>(S, mult, bias_f, a) : requant_i8_t<2>(S, mult, bias_f, a);
+    return a.div_exact ? requant_i8_t<3>(S, mult, bias_f, a) : requant_i8_t<0>(S, mult, bias_f, a);
+}
+
+// four saturated int8 values -> one dword (v_perm_b32 x3)
+__device__ __forceinline__ uint32_t pack4_i8(int q0, int q1, int q2, int q3)
+{
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)q3, (uint32_t)q2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
 // ---- binary16 <-> fp32 with the reference's rounding ----------------------------------------
@@ -130,6 +189,7 @@ int launch_conv_direct(const ConvArgs &a, int dtype, int layout, int dw_nhwc_wei
 int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 bool igemm_supports(const shl_mi355x_conv_desc &d);
+const char *igemm_variant(int64_t M, int64_t Co);  // "tile" | "regs" | "wave"
 bool dwconv_supports(const shl_mi355x_conv_desc &d);
 
 }  // namespace shl

@@ -1,4 +1,4 @@
-// conv_igemm.hip -- LDS-staged implicit-GEMM convolution on gfx950 matrix cores.
+// conv_igemm.hip -- implicit-GEMM convolution on gfx950 matrix cores.
 //
 //   int8 : v_mfma_i32_32x32x32_i8   (gfx950 double-K form; 16 int8 per lane per operand)
 //   f16  : v_mfma_f32_32x32x16_f16  (8 binary16 per lane per operand)
@@ -11,61 +11,462 @@
 //        ONE tap of ONE pixel (requires C*esize % 16 == 0), i.e. one aligned 16-byte load from
 //        an NHWC tensor.  Weights are repacked once at plan time to [Co][K] rows padded with
 //        zeros to a multiple of 64 B, whatever the source layout (OHWI / OIHW).
+//   Out-of-image taps read the plan's "pad page" (zp_in bytes for int8, zeros for f16), which
+//   keeps the zero-point fold a per-channel constant (acc_init = -zp_in * sum_k w[oc,k]).
+//   The MFMA "A" operand (rows -> accumulator registers) is the WEIGHT tile, so a lane ends up
+//   with 4 consecutive output channels of one pixel: one 4-byte (int8) or 8-byte (f16) NHWC store.
 //
-// Block = 256 threads (4 waves) computes a 128(pixel) x 128(cout) tile, K-step 64 bytes.
-//   * global -> register -> LDS staging, double-buffered: the loads of step s+1 are issued
-//     before the MFMAs of step s and written to the other LDS buffer afterwards, one barrier
-//     per step.  Out-of-image taps are materialised as the input zero point (int8) or 0 (f16),
-//     which keeps the zero-point fold a per-channel constant (acc_init).
-//   * LDS rows are 64 B of payload + 16 B pad (80 B stride): conflict-free ds_read_b128 for the
-//     32-rows-per-half-wave fragment pattern (MI355X LDS: 64 banks x 4 B, b128 served in
-//     16-lane groups).
-//   * each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles, 64 accumulator registers.
-//   * the MFMA "A" operand (rows -> accumulator registers) is the WEIGHT tile for NHWC so that a
-//     lane ends up with 4 consecutive output channels of one pixel (one 4- or 8-byte store), and
-//     the PIXEL tile for NCHW so that a lane ends up with 4 consecutive pixels of one channel.
+// Three kernels share that formulation:
+//   conv_igemm_tile_kernel   128(pixel) x 128(cout) block tile, 4 waves x (64x64), K step 64 B.
+//                            Operands stream HBM/L2 -> LDS with global_load_lds_dwordx4 (no
+//                            VGPR round trip) through a 3-stage ring: two K steps are in flight
+//                            while one is consumed, waits are counted (s_waitcnt vmcnt(4)) and
+//                            the only synchronisation is one raw s_barrier per step.  LDS rows are
+//                            unpadded 64 B (the DMA destination is lane-linear); bank conflicts
+//                            of the ds_read_b128 fragment reads are removed by XOR-ing the chunk
+//                            slot with (row >> 2) & 3 on the SOURCE side of the DMA and on the read.
+//   conv_igemm_regs_kernel   same tile, register-staged double buffer (the first correct version;
+//                            kept as an A/B baseline, SHL_MI355X_IGEMM=regs).
+//   conv_igemm_wave_kernel   no LDS, no barriers: every wave owns one 32x32 output tile and loads
+//                            its MFMA fragments straight from global memory with a two-group
+//                            software pipeline.  For small problems (MobileNetV1 at batch 1:
+//                            M*Co of a few 10^5) where a 128x128 grid would leave most of the 256
+//                            CUs idle and latency, not bandwidth, is the limit.
 //
 // Replaces shl_ref_conv2d_nhwc_f32 / shl_ref_conv2d_nchw_f32 + conv_im2col_sgemm_avx
 // (source/reference/convolution.c:28-139, conv_avx.h:109-1008) inside shl_ref_conv2d_quant.
+#include <stdlib.h>
+#include <string.h>
+
 #include <type_traits>
 
 #include "common.h"
 
 namespace shl {
 
-constexpr int BM = 128;       // pixels per block
-constexpr int BN = 128;       // output channels per block
-constexpr int BKB = 64;       // K bytes per step
-constexpr int ROWB = 80;      // LDS row stride in bytes (64 + 16 pad)
-constexpr int TILE_B = 128 * ROWB;
+constexpr int BM = 128;   // pixels per block
+constexpr int BN = 128;   // output channels per block
+constexpr int BKB = 64;   // K bytes per step
 
-struct RowState {  // one pixel row of the activation tile handled by this thread
-    int64_t base;  // byte offset of pixel (n, 0, 0, 0) in the input tensor
-    int y0, x0;    // top-left input coordinate of the receptive field
+template <bool kI8>
+struct AccT {
+    using type = typename std::conditional<kI8, v16i, v16f>::type;
+};
+
+template <bool kI8>
+__device__ __forceinline__ typename AccT<kI8>::type mfma(const v4i &a, const v4i &b,
+                                                         typename AccT<kI8>::type c)
+{
+    if constexpr (kI8) {
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a),
+                                                      __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+    }
+}
+
+// ---- receptive-field bookkeeping shared by all loaders ----------------------------------------
+struct PixelRow {
+    const char *base;  // address of input pixel (n, 0, 0, 0)
+    int y0, x0;        // input coordinate of tap (0, 0)
 };
 
 template <int ESIZE>
-__device__ __forceinline__ uint4 load_act_chunk(const ConvArgs &a, const RowState &r, int tap_y,
-                                                int tap_x, int cc, bool k_valid, uint32_t fill)
+__device__ __forceinline__ PixelRow make_row(const ConvArgs &a, int p)
 {
-    const int y = r.y0 + tap_y * a.dh;
-    const int x = r.x0 + tap_x * a.dw;
-    if (k_valid && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
-        const char *p = static_cast<const char *>(a.in) + r.base +
-                        ((int64_t)y * a.W + x) * ((int64_t)a.C * ESIZE) + (int64_t)cc * 16;
-        return *reinterpret_cast<const uint4 *>(p);
-    }
-    return make_uint4(fill, fill, fill, fill);
+    p = p < a.M ? p : a.M - 1;  // rows past M are computed on a clamped pixel and never stored
+    const int ox = p % a.Wo, t = p / a.Wo;
+    const int oy = t % a.Ho, n = t / a.Ho;
+    PixelRow r;
+    r.base = static_cast<const char *>(a.in) + (int64_t)n * a.H * a.W * a.C * ESIZE;
+    r.y0 = oy * a.sh - a.pt;
+    r.x0 = ox * a.sw - a.pl;
+    return r;
 }
 
-// kI8: int8 (else binary16).  kNHWC: output layout / operand roles.
-template <bool kI8, bool kNHWC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a)
+// walks the K sequence in 16-byte chunks: (tap_y, tap_x, cc) of chunk index kc
+struct KCursor {
+    int kc, cc, tap_y, tap_x;
+    __device__ __forceinline__ void init(const ConvArgs &a, int first)
+    {
+        kc = first;
+        const int tap = first / a.cchunks;
+        cc = first - tap * a.cchunks;
+        tap_y = tap / a.Kw;
+        tap_x = tap - tap_y * a.Kw;
+    }
+    __device__ __forceinline__ void advance(const ConvArgs &a, int n)
+    {
+        kc += n;
+        cc += n;
+        while (cc >= a.cchunks) {
+            cc -= a.cchunks;
+            if (++tap_x == a.Kw) {
+                tap_x = 0;
+                ++tap_y;
+            }
+        }
+    }
+};
+
+template <int ESIZE>
+__device__ __forceinline__ const char *chunk_addr(const ConvArgs &a, const PixelRow &r, const KCursor &k)
+{
+    const int y = r.y0 + k.tap_y * a.dh;
+    const int x = r.x0 + k.tap_x * a.dw;
+    const bool ok = k.kc < a.kchunks && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    const char *p = r.base + ((int64_t)y * a.W + x) * ((int64_t)a.C * ESIZE) + (int64_t)k.cc * 16;
+    // spread the readers of the pad page over its 32 lines (per workgroup) x 8 slots (per lane)
+    const char *pad = static_cast<const char *>(a.pad_page) + ((blockIdx.x & 31) << 7) + ((threadIdx.x & 7) << 4);
+    return ok ? p : pad;
+}
+
+// ---- epilogue of one 32x32 MFMA tile (A rows = output channels, B column = pixel) ---------------
+// C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// `tab_*` point at the table entries of the tile's first output channel (LDS or global).
+template <bool kI8, int EPI, typename Acc>
+__device__ __forceinline__ void store_tile(const ConvArgs &a, const Acc &acc, int p, int oc_tile,
+                                           int lhalf, const int32_t *tab_acc, const float *tab_mult,
+                                           const float *tab_bias)
+{
+    if (p >= a.M) return;
+    const bool vec_ok = (a.Co & 3) == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int r0 = 8 * g + 4 * lhalf;  // first of this lane's 4 consecutive channels
+        const int oc = oc_tile + r0;
+        if (oc >= a.Co) continue;
+        const int64_t o = (int64_t)p * a.Co + oc;
+        const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + r0);
+        if constexpr (kI8) {
+            const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + r0);
+            const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + r0);
+            const int q0 = requant_i8_t<EPI>(acc[4 * g + 0] + ai.x, mu.x, bi.x, a);
+            const int q1 = requant_i8_t<EPI>(acc[4 * g + 1] + ai.y, mu.y, bi.y, a);
+            const int q2 = requant_i8_t<EPI>(acc[4 * g + 2] + ai.z, mu.z, bi.z, a);
+            const int q3 = requant_i8_t<EPI>(acc[4 * g + 3] + ai.w, mu.w, bi.w, a);
+            const uint32_t packed = pack4_i8(q0, q1, q2, q3);
+            int8_t *out = static_cast<int8_t *>(a.out);
+            if (vec_ok) {
+                *reinterpret_cast<uint32_t *>(out + o) = packed;
+            } else {
+                for (int e = 0; e < 4 && oc + e < a.Co; ++e) out[o + e] = (int8_t)(packed >> (8 * e));
+            }
+        } else {
+            const uint32_t h0 = finish_f16(acc[4 * g + 0], bi.x, a);
+            const uint32_t h1 = finish_f16(acc[4 * g + 1], bi.y, a);
+            const uint32_t h2 = finish_f16(acc[4 * g + 2], bi.z, a);
+            const uint32_t h3 = finish_f16(acc[4 * g + 3], bi.w, a);
+            uint16_t *out = static_cast<uint16_t *>(a.out);
+            if (vec_ok) {
+                *reinterpret_cast<uint2 *>(out + o) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+            } else {
+                const uint32_t h[4] = {h0, h1, h2, h3};
+                for (int e = 0; e < 4 && oc + e < a.Co; ++e) out[o + e] = (uint16_t)h[e];
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// conv_igemm_tile_kernel: global_load_lds 3-stage ring
+//   WR = 2: block tile 128 pixels x 128 channels (waves 2 x 2)
+//   WR = 1: block tile 256 pixels x  64 channels (waves 1 x 4) -- for Cout <= 64, where a 128-wide
+//           channel tile would spend half of its MFMAs on clamped duplicate rows
+//   kUniformTap: C*esize % 64 == 0, so a 64-byte K step lies inside ONE filter tap.  The tap's
+//           address delta is then wave-uniform (SALU) and a lane only adds it to its pixel base and
+//           tests one bit of a per-pixel tap-validity mask built in the prologue: ~7 VALU per DMA
+//           row instead of ~35 for the general cursor.
+// =================================================================================================
+__device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
+{
+    // 64 lanes x 16 B -> LDS[base + lane*16]; the destination is wave-uniform by construction
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// NST = ring depth: NST-1 K steps are in flight while one is consumed.  What a block can pull
+// from L2/HBM is (bytes in flight) / latency, so the ring is made as deep as the LDS budget of the
+// intended blocks-per-CU allows: 3 stages when the grid fills every CU three times over, 6 when
+// there is at most one block per CU.
+template <int WR, int NST>
+struct TileGeom {
+    static constexpr int WC = 4 / WR;
+    static constexpr int TBN = 64 * WR;            // channels per block
+    static constexpr int TBM = 64 * WC;            // pixels per block
+    static constexpr int ACT_B = TBM * BKB;        // activation tile bytes per stage
+    static constexpr int WGT_B = TBN * BKB;
+    static constexpr int STAGE_B = ACT_B + WGT_B;
+    static constexpr int TAB_OFF = NST * STAGE_B;
+    static constexpr int LDS_B = TAB_OFF + 3 * TBN * 4;
+    static constexpr int NA = TBM / 64;            // DMA instructions per wave per stage: activations
+    static constexpr int NW = TBN / 64;            //                                       weights
+};
+
+template <bool kI8, int EPI, int WR, bool kUniformTap, int NST>
+__global__ __launch_bounds__(256) void conv_igemm_tile_kernel(ConvArgs a)
+{
+    using G = TileGeom<WR, NST>;
+    constexpr int LA = NST - 1;  // look-ahead in K steps
+    constexpr int ESIZE = kI8 ? 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (a.Co + G::TBN - 1) / G::TBN;
+    const int tile_n = blockIdx.x % n_tiles;
+    const int tile_m = blockIdx.x / n_tiles;
+    const int pix0 = tile_m * G::TBM;
+    const int co0 = tile_n * G::TBN;
+
+    // per-channel tables: requested first, parked in registers, written to LDS once the first
+    // DMA wait has retired them (VMEM returns in order) -- no dedicated stall
+    int32_t t_acc = 0;
+    float t_mult = 0.f, t_bias = 0.f;
+    if (tid < G::TBN) {  // tables are padded to a multiple of 128 entries by the plan
+        t_acc = a.acc_init[co0 + tid];
+        t_mult = a.mult[co0 + tid];
+        t_bias = a.bias[co0 + tid];
+    }
+
+    // ---- DMA role.  Wave w fills rows [w*TBM/4, +TBM/4) of the activation tile and rows
+    // [w*TBN/4, +TBN/4) of the weight tile, 16 rows x 4 chunk slots per instruction.  LDS position
+    // (row r, slot s) receives global chunk s ^ ((r >> 2) & 3) of that row.
+    const int drow = lane >> 2;
+    const int dslot = lane & 3;
+    PixelRow arow[G::NA];
+    KCursor acur[G::NA];           // general addressing
+    uint32_t aymask[G::NA], axmask[G::NA];  // uniform-tap addressing: valid ky / kx bit sets
+    const char *wptr[G::NW];
+#pragma unroll
+    for (int j = 0; j < G::NA; ++j) {
+        const int r = wave * (G::TBM / 4) + j * 16 + drow;
+        const int chunk = dslot ^ ((r >> 2) & 3);
+        arow[j] = make_row<ESIZE>(a, pix0 + r);
+        if constexpr (kUniformTap) {
+            uint32_t my = 0, mx = 0;
+            for (int ky = 0; ky < a.Kh; ++ky)
+                if ((unsigned)(arow[j].y0 + ky * a.dh) < (unsigned)a.H) my |= 1u << ky;
+            for (int kx = 0; kx < a.Kw; ++kx)
+                if ((unsigned)(arow[j].x0 + kx * a.dw) < (unsigned)a.W) mx |= 1u << kx;
+            aymask[j] = my;
+            axmask[j] = mx;
+            // fold the lane's fixed chunk slot and the tap (0,0) position into the base pointer
+            arow[j].base += ((int64_t)arow[j].y0 * a.W + arow[j].x0) * ((int64_t)a.C * ESIZE) + chunk * 16;
+        } else {
+            acur[j].init(a, chunk);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NW; ++j) {
+        const int r = wave * (G::TBN / 4) + j * 16 + drow;
+        int oc = co0 + r;
+        oc = oc < a.Co ? oc : a.Co - 1;
+        wptr[j] = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + (dslot ^ ((r >> 2) & 3)) * 16;
+    }
+    const int nsteps = (a.debug & 1) ? 1 : a.kstride / BKB;
+    const char *pad = static_cast<const char *>(a.pad_page) + ((blockIdx.x & 31) << 7) + ((lane & 7) << 4);
+    // uniform-tap scalar state: current tap and position inside it (64-byte groups)
+    int u_tx = 0, u_ty = 0, u_cc = 0;
+    const int groups_per_tap = a.cchunks >> 2;
+    const int pix_bytes = a.C * ESIZE;
+
+    auto issue = [&](auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
+        char *sa = smem + stage * G::STAGE_B + wave * (G::TBM / 4) * BKB;
+        char *sw = smem + stage * G::STAGE_B + G::ACT_B + wave * (G::TBN / 4) * BKB;
+        if constexpr (kUniformTap) {
+            const int delta = (u_ty * a.dh * a.W + u_tx * a.dw) * pix_bytes + u_cc * BKB;
+#pragma unroll
+            for (int j = 0; j < G::NA; ++j) {
+                const bool ok = ((aymask[j] >> u_ty) & (axmask[j] >> u_tx) & 1u) != 0;
+                glds16(ok ? arow[j].base + delta : pad, sa + j * 16 * BKB);
+            }
+            if (++u_cc == groups_per_tap) {
+                u_cc = 0;
+                if (++u_tx == a.Kw) {
+                    u_tx = 0;
+                    ++u_ty;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::NA; ++j) {
+                glds16(chunk_addr<ESIZE>(a, arow[j], acur[j]), sa + j * 16 * BKB);
+                acur[j].advance(a, 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G::NW; ++j) {
+            glds16(wptr[j], sw + j * 16 * BKB);
+            wptr[j] += BKB;
+        }
+    };
+    constexpr int PER_STAGE = G::NA + G::NW;  // DMA instructions per wave per stage
+
+    // ---- compute role: wave (wr, wc) owns channels [64wr, +64) x pixels [64wc, +64)
+    const int wr = wave / G::WC;
+    const int wc = wave % G::WC;
+    const int frow = lane & 31;
+    const int fhalf = lane >> 5;
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ra = wr * 64 + i * 32 + frow;
+            const int rb = wc * 64 + i * 32 + frow;
+            offA[i][kk] = G::ACT_B + ra * BKB + (((2 * kk + fhalf) ^ ((ra >> 2) & 3)) << 4);
+            offB[i][kk] = rb * BKB + (((2 * kk + fhalf) ^ ((rb >> 2) & 3)) << 4);
+        }
+
+    using acc_t = typename AccT<kI8>::type;
+    acc_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    // prologue: fill the ring
+    auto prefill = [&](auto self, auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+        if constexpr (st < LA) {
+            if (st < nsteps) issue(st_c);
+            self(self, std::integral_constant<int, st + 1>{});
+        }
+    };
+    prefill(prefill, std::integral_constant<int, 0>{});
+
+    // one K step on a compile-time stage: LDS offsets and DMA targets fold into immediates
+    auto body = [&](auto stage_c, int step) {
+        constexpr int stage = decltype(stage_c)::value;
+        // this wave's DMA pieces of `step` (and everything older, e.g. the table loads) have
+        // landed once at most the pieces of step+1 remain outstanding
+        if (step + LA <= nsteps) {  // steady state: LA-1 younger stages stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (LA - 1)) : "memory");
+        } else {                    // tail: fewer stages were issued; drain
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (step == 0) {
+            if (tid < G::TBN) {
+                reinterpret_cast<int32_t *>(smem + G::TAB_OFF)[tid] = t_acc;
+                reinterpret_cast<float *>(smem + G::TAB_OFF)[G::TBN + tid] = t_mult;
+                reinterpret_cast<float *>(smem + G::TAB_OFF)[2 * G::TBN + tid] = t_bias;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // every wave's pieces landed, and every wave has finished reading the stage of step-1,
+        // which is the one the next DMA overwrites
+        __builtin_amdgcn_s_barrier();
+        if (step + LA < nsteps) issue(std::integral_constant<int, (stage + LA) % NST>{});
+        const char *sb = smem + stage * G::STAGE_B;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v4i fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const v4i *>(sb + offA[i][kk]);
+                fb[i] = *reinterpret_cast<const v4i *>(sb + offB[i][kk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma<kI8>(fa[i], fb[j], acc[i][j]);
+        }
+    };
+    auto round = [&](auto self, auto st_c, int step0) {
+        constexpr int st = decltype(st_c)::value;
+        if constexpr (st < NST) {
+            if (step0 + st < nsteps) {
+                body(st_c, step0 + st);
+                self(self, std::integral_constant<int, st + 1>{}, step0);
+            }
+        }
+    };
+    for (int step = 0; step < nsteps; step += NST) round(round, std::integral_constant<int, 0>{}, step);
+    if (a.debug & 2) return;
+
+    // ---- epilogue
+    const int32_t *tab_acc = reinterpret_cast<const int32_t *>(smem + G::TAB_OFF);
+    const float *tab_mult = reinterpret_cast<const float *>(smem + G::TAB_OFF) + G::TBN;
+    const float *tab_bias = reinterpret_cast<const float *>(smem + G::TAB_OFF) + 2 * G::TBN;
+    constexpr int ROW_B = 64 * ESIZE;       // one pixel's 64 channels of this wave
+    constexpr int PITCH = ROW_B + 16;       // padded LDS row: spreads the 4-byte writes over banks
+    const bool staged = ((a.Co * ESIZE) & 15) == 0;
+    if (staged) {
+        // Stage the wave's 64 pixel x 64 channel block through LDS (the ring is free now) so that
+        // every lane stores 16 contiguous bytes of one pixel: whole 64-byte (int8) / 128-byte (f16)
+        // channel runs per pixel instead of 4-byte pieces scattered over 32 cache lines.
+        __builtin_amdgcn_s_barrier();  // all waves are done reading the last stage
+        char *ws = smem + wave * 64 * PITCH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = i * 32 + 8 * g + 4 * fhalf;  // first of 4 channels, within the wave's 64
+                    const int ch = wr * 64 + c;
+                    const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + ch);
+                    char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
+                    if constexpr (kI8) {
+                        const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + ch);
+                        const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + ch);
+                        const int q0 = requant_i8_t<EPI>(acc[i][j][4 * g + 0] + ai.x, mu.x, bi.x, a);
+                        const int q1 = requant_i8_t<EPI>(acc[i][j][4 * g + 1] + ai.y, mu.y, bi.y, a);
+                        const int q2 = requant_i8_t<EPI>(acc[i][j][4 * g + 2] + ai.z, mu.z, bi.z, a);
+                        const int q3 = requant_i8_t<EPI>(acc[i][j][4 * g + 3] + ai.w, mu.w, bi.w, a);
+                        *reinterpret_cast<uint32_t *>(dst) = pack4_i8(q0, q1, q2, q3);
+                    } else {
+                        const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
+                        const uint32_t h1 = finish_f16(acc[i][j][4 * g + 1], bi.y, a);
+                        const uint32_t h2 = finish_f16(acc[i][j][4 * g + 2], bi.z, a);
+                        const uint32_t h3 = finish_f16(acc[i][j][4 * g + 3], bi.w, a);
+                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                    }
+                }
+        // wave-local hand-over: same wave wrote and reads, LDS ops complete in order
+        constexpr int CPR = ROW_B / 16;        // 16-byte chunks per row
+        constexpr int RPI = 64 / CPR;          // rows per store instruction
+        const int srow = lane / CPR, schunk = lane % CPR;
+        const int oc_first = co0 + wr * 64 + schunk * (16 / ESIZE);
+        char *out = static_cast<char *>(a.out);
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = it * RPI + srow;
+            const int p = pix0 + wc * 64 + row;
+            const uint4 v = *reinterpret_cast<const uint4 *>(ws + row * PITCH + schunk * 16);
+            if (p < a.M && oc_first < a.Co)
+                *reinterpret_cast<uint4 *>(out + ((int64_t)p * a.Co + oc_first) * ESIZE) = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ch = wr * 64 + i * 32;
+                store_tile<kI8, EPI>(a, acc[i][j], pix0 + wc * 64 + j * 32 + frow, co0 + ch, fhalf,
+                                     tab_acc + ch, tab_mult + ch, tab_bias + ch);
+            }
+    }
+}
+
+// =================================================================================================
+// conv_igemm_regs_kernel: register-staged double buffer (A/B baseline)
+// =================================================================================================
+constexpr int ROWB = 80;  // LDS row stride: 64 B + 16 B pad (conflict-free ds_read_b128)
+constexpr int RTILE_B = 128 * ROWB;
+
+template <bool kI8, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_regs_kernel(ConvArgs a)
 {
     constexpr int ESIZE = kI8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *lds_act = smem;                 // [2][128][ROWB]
-    char *lds_wgt = smem + 2 * TILE_B;    // [2][128][ROWB]
+    char *lds_act = smem;                // [2][128][ROWB]
+    char *lds_wgt = smem + 2 * RTILE_B;  // [2][128][ROWB]
+    char *lds_tab = smem + 4 * RTILE_B;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,78 +476,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a)
     const int tile_m = blockIdx.x / n_tiles;
     const int pix0 = tile_m * BM;
     const int co0 = tile_n * BN;
+    if (tid < 128) {
+        reinterpret_cast<int32_t *>(lds_tab)[tid] = a.acc_init[co0 + tid];
+        reinterpret_cast<float *>(lds_tab)[128 + tid] = a.mult[co0 + tid];
+        reinterpret_cast<float *>(lds_tab)[256 + tid] = a.bias[co0 + tid];
+    }
 
-    // ---- loader role: rows (tid>>2) and (tid>>2)+64, chunk slot tid&3 of each K-step.
-    // (scalars, not arrays: indexed arrays captured by a lambda end up in scratch memory)
     const int lrow = tid >> 2;
     const int lslot = tid & 3;
-    RowState row0, row1;
-    const char *wrow0, *wrow1;
-    {
-        int p = pix0 + lrow;
-        p = p < a.M ? p : a.M - 1;  // clamp: rows past M are computed but never stored
-        int ox = p % a.Wo, t = p / a.Wo;
-        int oy = t % a.Ho, n = t / a.Ho;
-        row0.base = (int64_t)n * a.H * a.W * a.C * ESIZE;
-        row0.y0 = oy * a.sh - a.pt;
-        row0.x0 = ox * a.sw - a.pl;
-        p = pix0 + lrow + 64;
-        p = p < a.M ? p : a.M - 1;
-        ox = p % a.Wo, t = p / a.Wo;
-        oy = t % a.Ho, n = t / a.Ho;
-        row1.base = (int64_t)n * a.H * a.W * a.C * ESIZE;
-        row1.y0 = oy * a.sh - a.pt;
-        row1.x0 = ox * a.sw - a.pl;
-        int oc = co0 + lrow;
-        oc = oc < a.Co ? oc : a.Co - 1;
-        wrow0 = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + lslot * 16;
-        oc = co0 + lrow + 64;
-        oc = oc < a.Co ? oc : a.Co - 1;
-        wrow1 = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + lslot * 16;
-    }
-    // position of this thread's chunk inside the K sequence: chunk index kc = step*4 + lslot
-    int kc = lslot;
-    int tap = kc / a.cchunks;
-    int cc = kc - tap * a.cchunks;
-    int tap_y = tap / a.Kw;
-    int tap_x = tap - tap_y * a.Kw;
-    const uint32_t fill = kI8 ? (uint32_t)(a.in_zp & 0xFF) * 0x01010101u : 0u;
+    const PixelRow row0 = make_row<ESIZE>(a, pix0 + lrow);
+    const PixelRow row1 = make_row<ESIZE>(a, pix0 + lrow + 64);
+    int oc0 = co0 + lrow, oc1 = co0 + lrow + 64;
+    oc0 = oc0 < a.Co ? oc0 : a.Co - 1;
+    oc1 = oc1 < a.Co ? oc1 : a.Co - 1;
+    const char *wrow0 = static_cast<const char *>(a.w) + (int64_t)oc0 * a.kstride + lslot * 16;
+    const char *wrow1 = static_cast<const char *>(a.w) + (int64_t)oc1 * a.kstride + lslot * 16;
+    KCursor kc;
+    kc.init(a, lslot);
     const int nsteps = a.kstride / BKB;
 
     uint4 ra0, ra1, rw0, rw1;
     auto issue_loads = [&](int step) {
-        const bool kv = kc < a.kchunks;
-        ra0 = load_act_chunk<ESIZE>(a, row0, tap_y, tap_x, cc, kv, fill);
-        ra1 = load_act_chunk<ESIZE>(a, row1, tap_y, tap_x, cc, kv, fill);
+        ra0 = *reinterpret_cast<const uint4 *>(chunk_addr<ESIZE>(a, row0, kc));
+        ra1 = *reinterpret_cast<const uint4 *>(chunk_addr<ESIZE>(a, row1, kc));
         rw0 = *reinterpret_cast<const uint4 *>(wrow0 + (int64_t)step * BKB);
         rw1 = *reinterpret_cast<const uint4 *>(wrow1 + (int64_t)step * BKB);
-        // advance to the chunk this thread loads in the next step (kc += 4)
-        kc += 4;
-        cc += 4;
-        while (cc >= a.cchunks) {
-            cc -= a.cchunks;
-            if (++tap_x == a.Kw) {
-                tap_x = 0;
-                ++tap_y;
-            }
-        }
+        kc.advance(a, 4);
     };
     auto commit = [&](int buf) {
-        const int off = buf * TILE_B + lrow * ROWB + lslot * 16;
+        const int off = buf * RTILE_B + lrow * ROWB + lslot * 16;
         *reinterpret_cast<uint4 *>(lds_act + off) = ra0;
         *reinterpret_cast<uint4 *>(lds_wgt + off) = rw0;
         *reinterpret_cast<uint4 *>(lds_act + off + 64 * ROWB) = ra1;
         *reinterpret_cast<uint4 *>(lds_wgt + off + 64 * ROWB) = rw1;
     };
 
-    // ---- compute role: wave (wr, wc) owns rows [wr*64, +64) of operand A and [wc*64, +64) of B
     const int wr = wave >> 1;
     const int wc = wave & 1;
-    const char *lds_a = kNHWC ? lds_wgt : lds_act;  // operand A: accumulator-register dimension
-    const char *lds_b = kNHWC ? lds_act : lds_wgt;  // operand B: lane dimension
     const int frag_off = (lane & 31) * ROWB + (lane >> 5) * 16;
-
-    using acc_t = typename std::conditional<kI8, v16i, v16f>::type;
+    using acc_t = typename AccT<kI8>::type;
     acc_t acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -158,7 +526,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a)
     issue_loads(0);
     commit(0);
     __syncthreads();
-
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
         if (step + 1 < nsteps) issue_loads(step + 1);
@@ -167,103 +534,140 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a)
             v4i fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const v4i *>(lds_a + buf * TILE_B +
-                                                       (wr * 64 + i * 32) * ROWB + frag_off + kk * 32);
-                fb[i] = *reinterpret_cast<const v4i *>(lds_b + buf * TILE_B +
-                                                       (wc * 64 + i * 32) * ROWB + frag_off + kk * 32);
+                fa[i] = *reinterpret_cast<const v4i *>(lds_wgt + buf * RTILE_B + (wr * 64 + i * 32) * ROWB +
+                                                       frag_off + kk * 32);
+                fb[i] = *reinterpret_cast<const v4i *>(lds_act + buf * RTILE_B + (wc * 64 + i * 32) * ROWB +
+                                                       frag_off + kk * 32);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (kI8) {
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            __builtin_bit_cast(v8h, fa[i]), __builtin_bit_cast(v8h, fb[j]), acc[i][j],
-                            0, 0, 0);
-                    }
-                }
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma<kI8>(fa[i], fb[j], acc[i][j]);
         }
         if (step + 1 < nsteps) commit(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31 (operand B row),
-    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (operand A row).
-    const int lcol = lane & 31;
-    const int lhalf = lane >> 5;
+    const int32_t *tab_acc = reinterpret_cast<const int32_t *>(lds_tab);
+    const float *tab_mult = reinterpret_cast<const float *>(lds_tab) + 128;
+    const float *tab_bias = reinterpret_cast<const float *>(lds_tab) + 256;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            const int ch = wr * 64 + i * 32;
+            store_tile<kI8, EPI>(a, acc[i][j], pix0 + wc * 64 + j * 32 + (lane & 31), co0 + ch, lane >> 5,
+                            tab_acc + ch, tab_mult + ch, tab_bias + ch);
+        }
+}
+
+// =================================================================================================
+// conv_igemm_wave_kernel: one 32x32 tile per wave, fragments straight from global memory
+// =================================================================================================
+constexpr int WU = 4;  // K sub-steps (32 B each) per pipeline group
+
+template <bool kI8, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
+{
+    constexpr int ESIZE = kI8 ? 1 : 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n_tiles = (a.Co + 31) / 32;
+    const int m_tiles = (a.M + 31) / 32;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles * m_tiles) return;  // wave-uniform: there are no barriers in this kernel
+    const int tn = tile % n_tiles;           // the 4 waves of a block share their pixels (L1 reuse)
+    const int tm = tile / n_tiles;
+    const int frow = lane & 31;
+    const int fhalf = lane >> 5;
+
+    // epilogue tables for this lane's 16 channels, requested first so that they arrive under
+    // the K loop (tables are padded to a multiple of 128 channels)
+    const int ch0 = tn * 32 + 4 * fhalf;
+    int4 ai[4];
+    float4 mu[4], bi[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int arow = wr * 64 + i * 32 + 8 * g + 4 * lhalf;  // first of 4 A rows
-                const int bcol = wc * 64 + j * 32 + lcol;
-                if constexpr (kNHWC) {
-                    // A rows = output channels, B col = pixel
-                    const int oc = co0 + arow;
-                    const int p = pix0 + bcol;
-                    if (p >= a.M || oc >= a.Co) continue;
-                    const int64_t o = (int64_t)p * a.Co + oc;
-                    if constexpr (kI8) {
-                        uint32_t packed = 0;
+    for (int g = 0; g < 4; ++g) {
+        ai[g] = *reinterpret_cast<const int4 *>(a.acc_init + ch0 + 8 * g);
+        mu[g] = *reinterpret_cast<const float4 *>(a.mult + ch0 + 8 * g);
+        bi[g] = *reinterpret_cast<const float4 *>(a.bias + ch0 + 8 * g);
+    }
+
+    const PixelRow row = make_row<ESIZE>(a, tm * 32 + frow);
+    int oc = tn * 32 + frow;
+    oc = oc < a.Co ? oc : a.Co - 1;
+    const char *wp = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16;
+    KCursor kc;
+    kc.init(a, fhalf);  // sub-step s uses chunks 2s (lanes 0-31) and 2s+1 (lanes 32-63)
+    const int nsub = a.kstride / 32;  // kstride is a multiple of 64 -> even
+
+    using acc_t = typename AccT<kI8>::type;
+    acc_t acc;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int c = oc + e < a.Co ? oc + e : a.Co - 1;
-                            const int q = requant_i8(acc[i][j][4 * g + e] + a.acc_init[c], a.mult[c],
-                                                     a.bias[c], a.out_scale, a.out_zp_f, a.act);
-                            packed |= (uint32_t)(q & 0xFF) << (8 * e);
-                        }
-                        int8_t *out = static_cast<int8_t *>(a.out);
-                        if (oc + 3 < a.Co && (a.Co & 3) == 0) {
-                            *reinterpret_cast<uint32_t *>(out + o) = packed;
-                        } else {
-                            for (int e = 0; e < 4 && oc + e < a.Co; ++e)
-                                out[o + e] = (int8_t)(packed >> (8 * e));
-                        }
-                    } else {
-                        uint16_t h[4];
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+
+    v4i fa0[WU], fb0[WU], fa1[WU], fb1[WU];
+#define SHL_LOAD_GROUP(FA, FB, FIRST)                                                     \
+    _Pragma("unroll") for (int u = 0; u < WU; ++u)                                        \
+    {                                                                                     \
+        if ((FIRST) + u < nsub) {                                                         \
+            FA[u] = *reinterpret_cast<const v4i *>(wp);                                   \
+            FB[u] = *reinterpret_cast<const v4i *>(chunk_addr<ESIZE>(a, row, kc));        \
+        }                                                                                 \
+        wp += 32;                                                                         \
+        kc.advance(a, 2);                                                                 \
+    }
+    SHL_LOAD_GROUP(fa0, fb0, 0)
+    for (int s0 = 0; s0 < nsub; s0 += 2 * WU) {
+        SHL_LOAD_GROUP(fa1, fb1, s0 + WU)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int c = oc + e < a.Co ? oc + e : a.Co - 1;
-                            h[e] = finish_f16(acc[i][j][4 * g + e], a.bias[c], a);
-                        }
-                        uint16_t *out = static_cast<uint16_t *>(a.out);
-                        if (oc + 3 < a.Co && (a.Co & 3) == 0) {
-                            *reinterpret_cast<uint2 *>(out + o) =
-                                make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-                        } else {
-                            for (int e = 0; e < 4 && oc + e < a.Co; ++e) out[o + e] = h[e];
-                        }
-                    }
-                } else {
-                    // A rows = pixels, B col = output channel; NCHW output
-                    const int oc = co0 + bcol;
-                    if (oc >= a.Co) continue;
-                    const int hw = a.Ho * a.Wo;
+        for (int u = 0; u < WU; ++u)
+            if (s0 + u < nsub) acc = mfma<kI8>(fa0[u], fb0[u], acc);
+        SHL_LOAD_GROUP(fa0, fb0, s0 + 2 * WU)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int p = pix0 + arow + e;
-                        if (p >= a.M) continue;
-                        const int n = p / hw;
-                        const int64_t o = ((int64_t)n * a.Co + oc) * hw + (p - n * hw);
-                        if constexpr (kI8) {
-                            const int q = requant_i8(acc[i][j][4 * g + e] + a.acc_init[oc], a.mult[oc],
-                                                     a.bias[oc], a.out_scale, a.out_zp_f, a.act);
-                            static_cast<int8_t *>(a.out)[o] = (int8_t)q;
-                        } else {
-                            static_cast<uint16_t *>(a.out)[o] =
-                                finish_f16(acc[i][j][4 * g + e], a.bias[oc], a);
-                        }
-                    }
-                }
+        for (int u = 0; u < WU; ++u)
+            if (s0 + WU + u < nsub) acc = mfma<kI8>(fa1[u], fb1[u], acc);
+    }
+#undef SHL_LOAD_GROUP
+
+    // ---- epilogue from registers
+    const int p = tm * 32 + frow;
+    if (p >= a.M) return;
+    const bool vec_ok = (a.Co & 3) == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int occ = ch0 + 8 * g;
+        if (occ >= a.Co) continue;
+        const int64_t o = (int64_t)p * a.Co + occ;
+        if constexpr (kI8) {
+            const int q0 = requant_i8_t<EPI>(acc[4 * g + 0] + ai[g].x, mu[g].x, bi[g].x, a);
+            const int q1 = requant_i8_t<EPI>(acc[4 * g + 1] + ai[g].y, mu[g].y, bi[g].y, a);
+            const int q2 = requant_i8_t<EPI>(acc[4 * g + 2] + ai[g].z, mu[g].z, bi[g].z, a);
+            const int q3 = requant_i8_t<EPI>(acc[4 * g + 3] + ai[g].w, mu[g].w, bi[g].w, a);
+            const uint32_t packed = pack4_i8(q0, q1, q2, q3);
+            int8_t *out = static_cast<int8_t *>(a.out);
+            if (vec_ok) {
+                *reinterpret_cast<uint32_t *>(out + o) = packed;
+            } else {
+                for (int e = 0; e < 4 && occ + e < a.Co; ++e) out[o + e] = (int8_t)(packed >> (8 * e));
+            }
+        } else {
+            const uint32_t h0 = finish_f16(acc[4 * g + 0], bi[g].x, a);
+            const uint32_t h1 = finish_f16(acc[4 * g + 1], bi[g].y, a);
+            const uint32_t h2 = finish_f16(acc[4 * g + 2], bi[g].z, a);
+            const uint32_t h3 = finish_f16(acc[4 * g + 3], bi[g].w, a);
+            uint16_t *out = static_cast<uint16_t *>(a.out);
+            if (vec_ok) {
+                *reinterpret_cast<uint2 *>(out + o) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+            } else {
+                const uint32_t h[4] = {h0, h1, h2, h3};
+                for (int e = 0; e < 4 && occ + e < a.Co; ++e) out[o + e] = (uint16_t)h[e];
             }
         }
     }
 }
 
+// =================================================================================================
 bool igemm_supports(const shl_mi355x_conv_desc &d)
 {
     if (d.group != 1) return false;
@@ -274,21 +678,113 @@ bool igemm_supports(const shl_mi355x_conv_desc &d)
     return true;
 }
 
+// one launcher per kernel instantiation: kernels that need more than 64 KiB of dynamic LDS must be
+// opted in once through hipFuncSetAttribute
+template <void (*KERNEL)(ConvArgs)>
+static void launch_kernel(dim3 grid, size_t lds, hipStream_t s, const ConvArgs &a)
+{
+    static bool opted_in = false;
+    if (lds > 64 * 1024 && !opted_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        opted_in = true;
+    }
+    hipLaunchKernelGGL(KERNEL, grid, dim3(256), lds, s, a);
+}
+
+// "tile" | "regs" | "wave" | "" (automatic) -- read once; for A/B measurements only
+static const char *variant_override()
+{
+    static const char *v = getenv("SHL_MI355X_IGEMM");
+    return v ? v : "";
+}
+
+const char *igemm_variant(int64_t M, int64_t Co)
+{
+    const char *ov = variant_override();
+    if (ov[0]) return ov;
+    // block-tile grid vs wave-tile grid: prefer the LDS tile kernel once it can put at least two
+    // blocks on every CU; below that, latency dominates and the barrier-free wave kernel wins
+    const int64_t blocks128 = ((M + BM - 1) / BM) * ((Co + BN - 1) / BN);
+    return blocks128 >= 512 ? "tile" : "wave";
+}
+
 int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
 {
     if (a.M == 0 || a.Co == 0) return SHL_MI355X_OK;
-    const int m_tiles = (a.M + BM - 1) / BM;
-    const int n_tiles = (a.Co + BN - 1) / BN;
-    const dim3 grid((unsigned)(m_tiles * n_tiles));
-    const size_t lds = 4 * TILE_B;
     if (layout != SHL_MI355X_NHWC) {
         set_error("igemm: NCHW activations are not supported by this kernel");
         return SHL_MI355X_ENOTSUP;
     }
-    if (dtype == SHL_MI355X_I8)
-        hipLaunchKernelGGL((conv_igemm_kernel<true, true>), grid, dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<false, true>), grid, dim3(256), lds, s, a);
+    const char *v = igemm_variant(a.M, a.Co);
+    const bool i8 = dtype == SHL_MI355X_I8;
+    const int epi = i8 ? epi_code(a) : 0;
+    const int esize = i8 ? 1 : 2;
+    dim3 grid;
+    size_t lds = 0;
+    int kind;  // 0 wave, 1 regs, 2 tile
+    bool deep = false;
+    // tile flavours: 256x64 for narrow outputs; uniform-tap addressing when a K step stays in a tap
+    const bool narrow = a.Co <= 64;
+    const bool utap = (a.C * esize) % 64 == 0 && a.Kh * a.Kw <= 32;
+    if (!strcmp(v, "wave")) {
+        const int64_t tiles = (int64_t)((a.M + 31) / 32) * ((a.Co + 31) / 32);
+        grid = dim3((unsigned)((tiles + 3) / 4));
+        kind = 0;
+    } else if (!strcmp(v, "regs")) {
+        grid = dim3((unsigned)(((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN)));
+        kind = 1;
+        lds = 4 * RTILE_B + 3 * 128 * 4;
+    } else {
+        const int tbm = narrow ? 256 : 128, tbn = narrow ? 64 : 128;
+        grid = dim3((unsigned)(((a.M + tbm - 1) / tbm) * ((a.Co + tbn - 1) / tbn)));
+        kind = 2;
+        // A deeper ring (6 stages, one block per CU) was measured on the ResNet-50 3x3 set at batch
+        // 128: no gain on the 196-block layers, 30-50 % slower elsewhere (profiles/r01_notes.md):
+        // the K step is bound by DMA/ds_read ISSUE, not by bytes in flight.  Kept for A/B only.
+        deep = false;
+        static const char *nst_env = getenv("SHL_MI355X_NST");
+        if (nst_env) deep = atoi(nst_env) > 3;
+        lds = narrow ? (deep ? TileGeom<1, 6>::LDS_B : TileGeom<1, 3>::LDS_B)
+                     : (deep ? TileGeom<2, 6>::LDS_B : TileGeom<2, 3>::LDS_B);
+    }
+#define SHL_LAUNCH(...) launch_kernel<__VA_ARGS__>(grid, lds, s, a)
+#define SHL_LAUNCH_EPI(KERNEL, ...)                                   \
+    switch (epi) {                                                    \
+        case 0: SHL_LAUNCH(KERNEL<true, 0 __VA_ARGS__>); break;       \
+        case 1: SHL_LAUNCH(KERNEL<true, 1 __VA_ARGS__>); break;       \
+        case 2: SHL_LAUNCH(KERNEL<true, 2 __VA_ARGS__>); break;       \
+        case 3: SHL_LAUNCH(KERNEL<true, 3 __VA_ARGS__>); break;       \
+        case 4: SHL_LAUNCH(KERNEL<true, 4 __VA_ARGS__>); break;       \
+        default: SHL_LAUNCH(KERNEL<true, 5 __VA_ARGS__>); break;      \
+    }
+#define SHL_COMMA ,
+    if (kind == 0) {
+        if (i8) { SHL_LAUNCH_EPI(conv_igemm_wave_kernel) } else { SHL_LAUNCH(conv_igemm_wave_kernel<false, 0>); }
+    } else if (kind == 1) {
+        if (i8) { SHL_LAUNCH_EPI(conv_igemm_regs_kernel) } else { SHL_LAUNCH(conv_igemm_regs_kernel<false, 0>); }
+    } else if (i8) {
+#define SHL_TILE_I8(WRV, UT)                                                                   \
+    if (deep) { SHL_LAUNCH_EPI(conv_igemm_tile_kernel, SHL_COMMA WRV SHL_COMMA UT SHL_COMMA 6) } \
+    else { SHL_LAUNCH_EPI(conv_igemm_tile_kernel, SHL_COMMA WRV SHL_COMMA UT SHL_COMMA 3) }
+        if (narrow && utap) { SHL_TILE_I8(1, true) }
+        else if (narrow) { SHL_TILE_I8(1, false) }
+        else if (utap) { SHL_TILE_I8(2, true) }
+        else { SHL_TILE_I8(2, false) }
+#undef SHL_TILE_I8
+    } else {
+#define SHL_TILE_F16(WRV, UT)                                                  \
+    if (deep) SHL_LAUNCH(conv_igemm_tile_kernel<false, 0, WRV, UT, 6>);        \
+    else SHL_LAUNCH(conv_igemm_tile_kernel<false, 0, WRV, UT, 3>);
+        if (narrow && utap) { SHL_TILE_F16(1, true) }
+        else if (narrow) { SHL_TILE_F16(1, false) }
+        else if (utap) { SHL_TILE_F16(2, true) }
+        else { SHL_TILE_F16(2, false) }
+#undef SHL_TILE_F16
+    }
+#undef SHL_COMMA
+#undef SHL_LAUNCH_EPI
+#undef SHL_LAUNCH
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }

@@ -17,7 +17,10 @@ struct shl_mi355x_conv_plan {
     int algo;
     char *block;       // device
     size_t block_bytes;
-    size_t off_w, off_acc, off_mult, off_bias;
+    size_t off_w, off_acc, off_mult, off_bias, off_pad;
+    // int8 epilogue shortcuts (see ConvArgs)
+    int32_t div_exact, act_clamp;
+    float clamp_lo, clamp_hi, inv_out_scale;
     int32_t kstride;   // igemm: packed row bytes
     int32_t kchunks;
     int32_t cchunks;
@@ -49,6 +52,47 @@ static int validate(const shl_mi355x_conv_desc &d)
     if ((int64_t)(d.out_w - 1) * d.stride_w - d.pad_left >= d.in_w) return SHL_MI355X_EINVAL;
     if (d.dtype == SHL_MI355X_I8 && !(d.out_scale > 0.0f)) return SHL_MI355X_EINVAL;
     return SHL_MI355X_OK;
+}
+
+// ---- host replicas of the literal int8 epilogue (this file is compiled with -ffp-contract=off)
+static int host_sat8(float r)
+{
+    r = r > 127.0f ? 127.0f : r;
+    r = r < -128.0f ? -128.0f : r;
+    return (int)r;
+}
+
+static int host_requant(float x, float s, int zp) { return host_sat8(__builtin_rintf(x / s) + (float)zp); }
+
+// "dequantise, relu(6), requantise with the same record" on a saturated q is a monotone map of
+// 256 values; when it equals clamp(q, requant(0), requant(6) | 127) for every q -- checked here
+// against the literal formula -- the kernels fold it, together with the int8 saturation, into one
+// clamp of r = rint(f / s) + zp.  Returns false when the scale is too exotic for the shortcut
+// (the kernels then run the literal code).
+static bool derive_act_clamp(const shl_mi355x_conv_desc &d, float *lo, float *hi)
+{
+    const float s = d.out_scale;
+    const int zp = d.out_zp;
+    const int qlo = host_requant(0.0f, s, zp);
+    const int qhi = d.act == SHL_MI355X_ACT_RELU6 ? host_requant(6.0f, s, zp) : 127;
+    if (qlo > qhi) return false;
+    for (int q = -128; q <= 127; ++q) {
+        float x = ((float)q - (float)zp) * s;
+        x = x > 0.0f ? x : 0.0f;
+        if (d.act == SHL_MI355X_ACT_RELU6) x = x < 6.0f ? x : 6.0f;
+        const int literal = host_requant(x, s, zp);
+        const int fast = q < qlo ? qlo : (q > qhi ? qhi : q);
+        if (literal != fast) return false;
+    }
+    *lo = (float)qlo;
+    *hi = (float)qhi;
+    return true;
+}
+
+static bool is_pow2_scale(float s)
+{
+    int e;
+    return s > 0.0f && __builtin_frexpf(s, &e) == 0.5f && e > -100 && e < 100;
 }
 
 static int choose_algo(const shl_mi355x_conv_desc &d)
@@ -138,17 +182,34 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         p->kchunks = Kb / 16;
         p->cchunks = d.in_c * es / 16;
         w_bytes = (size_t)d.out_c * p->kstride;
-        p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_igemm_i8_mfma32x32x32" : "conv_igemm_f16_mfma32x32x16";
+        const char *v = igemm_variant((int64_t)d.batch * d.out_h * d.out_w, d.out_c);
+        const bool i8 = d.dtype == SHL_MI355X_I8;
+        if (!strcmp(v, "wave"))
+            p->kernel_name = i8 ? "conv_igemm_wave_i8_mfma32x32x32" : "conv_igemm_wave_f16_mfma32x32x16";
+        else if (!strcmp(v, "regs"))
+            p->kernel_name = i8 ? "conv_igemm_regs_i8_mfma32x32x32" : "conv_igemm_regs_f16_mfma32x32x16";
+        else
+            p->kernel_name = i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
     } else if (algo == SHL_MI355X_ALGO_DW) {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "dwconv_nhwc_i8" : "dwconv_nhwc_f16";
     } else {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_direct_i8" : "conv_direct_f16";
     }
+    // tables are padded to a multiple of 128 channels so that kernels may fetch whole tile rows
+    const size_t tab_bytes = align_up((size_t)d.out_c, 128) * 4;
     p->off_w = 0;
     p->off_acc = align_up(w_bytes, 256);
-    p->off_mult = p->off_acc + align_up((size_t)d.out_c * 4, 256);
-    p->off_bias = p->off_mult + align_up((size_t)d.out_c * 4, 256);
-    p->block_bytes = p->off_bias + align_up((size_t)d.out_c * 4, 256);
+    p->off_mult = p->off_acc + tab_bytes;
+    p->off_bias = p->off_mult + tab_bytes;
+    p->off_pad = p->off_bias + tab_bytes;
+    p->block_bytes = p->off_pad + PAD_PAGE_BYTES;
+    p->inv_out_scale = 1.0f / d.out_scale;
+    if (d.dtype == SHL_MI355X_I8) {
+        p->div_exact = is_pow2_scale(d.out_scale);
+        p->clamp_lo = -128.0f;
+        p->clamp_hi = 127.0f;
+        p->act_clamp = d.act != SHL_MI355X_ACT_NONE && derive_act_clamp(d, &p->clamp_lo, &p->clamp_hi);
+    }
 
     hipError_t e = hipMalloc((void **)&p->block, p->block_bytes);
     if (e != hipSuccess) {
@@ -157,6 +218,8 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     }
 
     std::vector<char> host(p->block_bytes, 0);
+    // padding value: the input zero point (int8) / 0.0 (f16)
+    memset(host.data() + p->off_pad, d.dtype == SHL_MI355X_I8 ? (d.in_zp & 0xFF) : 0, PAD_PAGE_BYTES);
     if (kernel_host) {
         const char *src = static_cast<const char *>(kernel_host);
         if (algo == SHL_MI355X_ALGO_IGEMM)
@@ -257,9 +320,19 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
     a.act = d.act;
     a.out_scale = d.out_scale;
     a.out_zp_f = (float)d.out_zp;
+    a.out_zp = d.out_zp;
     const float os = d.out_scale;
     a.scale_out = (d.dtype == SHL_MI355X_F16) && (os - 1.0f > 1.1920929e-07f || 1.0f - os > 1.1920929e-07f);
-    a.inv_out_scale = a.scale_out ? 1.0f / os : 1.0f;
+    a.inv_out_scale = plan->inv_out_scale;
+    a.div_exact = plan->div_exact;
+    a.act_clamp = plan->act_clamp;
+    a.clamp_lo = plan->clamp_lo;
+    a.clamp_hi = plan->clamp_hi;
+    a.pad_page = plan->block + plan->off_pad;
+    {
+        static const char *dbg = getenv("SHL_MI355X_DEBUG");
+        a.debug = dbg ? atoi(dbg) : 0;
+    }
     if (a.M == 0) return SHL_MI355X_OK;
     hipStream_t s = (hipStream_t)stream;
     switch (plan->algo) {

@@ -1,96 +1,128 @@
-// dwconv.hip -- depthwise convolution for NHWC tensors on gfx950 (VALU, HBM-bound).
+// dwconv.hip -- depthwise convolution for NHWC tensors on gfx950 (VALU, HBM/latency-bound).
 //
 // One thread produces VEC consecutive channels of one output pixel.  Depthwise has no
 // reduction across channels, so the work is a streaming multiply-add over Kh*Kw taps at
 // 2*Kh*Kw ops per output byte -- far below the machine balance; the kernel is organised for
-// coalescing instead: consecutive lanes cover consecutive channel groups of the same pixel, then
-// the next pixel, so every wave load/store touches contiguous NHWC bytes.  Weights [Kh,Kw,C]
-// (1HWO) are read with the same channel-group pattern and stay in L1/L2.
+// coalescing and for memory-level parallelism instead:
+//   * consecutive lanes cover consecutive channel groups of the same pixel, then the next
+//     pixel, so every wave load/store touches contiguous NHWC bytes;
+//   * the 3x3 specialisation issues all nine input loads and all nine weight loads before the
+//     first multiply (out-of-image taps are redirected to the plan's pad page, which holds the
+//     input zero point and therefore contributes (zp - zp) * w = 0), so a thread pays ONE
+//     memory round trip instead of nine dependent ones -- at MobileNetV1 batch-1 sizes the
+//     kernel is pure latency;
+//   * weights [Kh,Kw,C] (1HWO) are read with the same channel-group pattern and stay in L1/L2.
 //
 // Replaces shl_ref_depthwise_conv2d_nhwc_f32 (source/reference/convolution.c:141-204) inside
 // shl_ref_depthwise_conv2d_quant (:416-460).  depth_multiplier == 1 only; other cases use the
 // direct kernel.
+#include <type_traits>
+
 #include "common.h"
 
 namespace shl {
 
 template <bool kI8>
+struct DwVec {  // VEC = 4 channels: one dword of int8, two dwords of binary16
+    using type = typename std::conditional<kI8, uint32_t, uint2>::type;
+};
+
+template <bool kI8>
+__device__ __forceinline__ void dw_accumulate(const typename DwVec<kI8>::type &iv,
+                                              const typename DwVec<kI8>::type &wv, int in_zp,
+                                              int32_t (&acc_i)[4], float (&acc_f)[4])
+{
+    if constexpr (kI8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int32_t q = (int32_t)(int8_t)(iv >> (8 * e)) - in_zp;
+            const int32_t w = (int32_t)(int8_t)(wv >> (8 * e));
+            acc_i[e] += q * w;
+        }
+    } else {
+        const uint16_t ih[4] = {(uint16_t)iv.x, (uint16_t)(iv.x >> 16), (uint16_t)iv.y, (uint16_t)(iv.y >> 16)};
+        const uint16_t wh[4] = {(uint16_t)wv.x, (uint16_t)(wv.x >> 16), (uint16_t)wv.y, (uint16_t)(wv.y >> 16)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc_f[e] = __fadd_rn(acc_f[e], __fmul_rn(f16_bits_to_float(wh[e]), f16_bits_to_float(ih[e])));
+    }
+}
+
+// KS == 3: 3x3 taps fully unrolled, loads batched.  KS == 0: any kernel size, loop form.
+template <bool kI8, int KS>
 __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(ConvArgs a)
 {
     constexpr int VEC = 4;
+    constexpr int ESIZE = kI8 ? 1 : 2;
+    using vec_t = typename DwVec<kI8>::type;
     const int cgroups = a.C / VEC;
     const int64_t total = (int64_t)a.M * cgroups;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int cg = (int)(idx % cgroups);
-        int64_t p = idx / cgroups;
+        const int64_t p = idx / cgroups;
         const int ox = (int)(p % a.Wo);
-        int64_t t = p / a.Wo;
+        const int64_t t = p / a.Wo;
         const int oy = (int)(t % a.Ho);
         const int n = (int)(t / a.Ho);
         const int c = cg * VEC;
         const int y0 = oy * a.sh - a.pt;
         const int x0 = ox * a.sw - a.pl;
+        const char *in = static_cast<const char *>(a.in);
+        const char *w = static_cast<const char *>(a.w);
 
         int32_t acc_i[VEC] = {0, 0, 0, 0};
         float acc_f[VEC] = {0.f, 0.f, 0.f, 0.f};
-        for (int ky = 0; ky < a.Kh; ++ky) {
-            const int y = y0 + ky * a.dh;
-            if (y < 0 || y >= a.H) continue;
-            for (int kx = 0; kx < a.Kw; ++kx) {
-                const int x = x0 + kx * a.dw;
-                if (x < 0 || x >= a.W) continue;
-                const int64_t ii = (((int64_t)n * a.H + y) * a.W + x) * a.C + c;
-                const int64_t wi = ((int64_t)ky * a.Kw + kx) * a.C + c;
-                if constexpr (kI8) {
-                    const uint32_t iv = *reinterpret_cast<const uint32_t *>(
-                        static_cast<const int8_t *>(a.in) + ii);
-                    const uint32_t wv = *reinterpret_cast<const uint32_t *>(
-                        static_cast<const int8_t *>(a.w) + wi);
+        if constexpr (KS == 3) {
+            vec_t iv[9], wv[9];
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int32_t q = (int32_t)(int8_t)(iv >> (8 * e)) - a.in_zp;
-                        const int32_t w = (int32_t)(int8_t)(wv >> (8 * e));
-                        acc_i[e] += q * w;
-                    }
-                } else {
-                    const uint2 iv = *reinterpret_cast<const uint2 *>(
-                        static_cast<const uint16_t *>(a.in) + ii);
-                    const uint2 wv = *reinterpret_cast<const uint2 *>(
-                        static_cast<const uint16_t *>(a.w) + wi);
-                    const uint16_t ih[4] = {(uint16_t)iv.x, (uint16_t)(iv.x >> 16), (uint16_t)iv.y,
-                                            (uint16_t)(iv.y >> 16)};
-                    const uint16_t wh[4] = {(uint16_t)wv.x, (uint16_t)(wv.x >> 16), (uint16_t)wv.y,
-                                            (uint16_t)(wv.y >> 16)};
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        acc_f[e] = __fadd_rn(
-                            acc_f[e], __fmul_rn(f16_bits_to_float(wh[e]), f16_bits_to_float(ih[e])));
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int y = y0 + ky * a.dh, x = x0 + kx * a.dw;
+                    const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                    const char *ip = in + ((((int64_t)n * a.H + y) * a.W + x) * a.C + c) * ESIZE;
+                    iv[ky * 3 + kx] = *reinterpret_cast<const vec_t *>(ok ? ip : static_cast<const char *>(a.pad_page));
+                    wv[ky * 3 + kx] = *reinterpret_cast<const vec_t *>(w + ((int64_t)(ky * 3 + kx) * a.C + c) * ESIZE);
+                }
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) dw_accumulate<kI8>(iv[tp], wv[tp], a.in_zp, acc_i, acc_f);
+        } else {
+            for (int ky = 0; ky < a.Kh; ++ky) {
+                const int y = y0 + ky * a.dh;
+                if (y < 0 || y >= a.H) continue;
+                for (int kx = 0; kx < a.Kw; ++kx) {
+                    const int x = x0 + kx * a.dw;
+                    if (x < 0 || x >= a.W) continue;
+                    const vec_t iv = *reinterpret_cast<const vec_t *>(
+                        in + ((((int64_t)n * a.H + y) * a.W + x) * a.C + c) * ESIZE);
+                    const vec_t wv = *reinterpret_cast<const vec_t *>(
+                        w + (((int64_t)ky * a.Kw + kx) * a.C + c) * ESIZE);
+                    dw_accumulate<kI8>(iv, wv, a.in_zp, acc_i, acc_f);
                 }
             }
         }
         const int64_t o = p * a.C + c;
+        const float4 bi = *reinterpret_cast<const float4 *>(a.bias + c);
         if constexpr (kI8) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int q = requant_i8(acc_i[e], a.mult[c + e], a.bias[c + e], a.out_scale,
-                                         a.out_zp_f, a.act);
-                packed |= (uint32_t)(q & 0xFF) << (8 * e);
-            }
-            *reinterpret_cast<uint32_t *>(static_cast<int8_t *>(a.out) + o) = packed;
+            const float4 mu = *reinterpret_cast<const float4 *>(a.mult + c);
+            const int q0 = requant_i8_fast(acc_i[0], mu.x, bi.x, a);
+            const int q1 = requant_i8_fast(acc_i[1], mu.y, bi.y, a);
+            const int q2 = requant_i8_fast(acc_i[2], mu.z, bi.z, a);
+            const int q3 = requant_i8_fast(acc_i[3], mu.w, bi.w, a);
+            *reinterpret_cast<uint32_t *>(static_cast<int8_t *>(a.out) + o) = pack4_i8(q0, q1, q2, q3);
         } else {
-            uint16_t h[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) h[e] = finish_f16(acc_f[e], a.bias[c + e], a);
+            const uint32_t h0 = finish_f16(acc_f[0], bi.x, a), h1 = finish_f16(acc_f[1], bi.y, a);
+            const uint32_t h2 = finish_f16(acc_f[2], bi.z, a), h3 = finish_f16(acc_f[3], bi.w, a);
             *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(a.out) + o) =
-                make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+                make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
         }
     }
 }
 
 bool dwconv_supports(const shl_mi355x_conv_desc &d)
 {
+    if (d.dtype == SHL_MI355X_I8 && (d.in_zp < -128 || d.in_zp > 127)) return false;
     return d.layout == SHL_MI355X_NHWC && d.group == d.in_c && d.out_c == d.in_c &&
            d.in_c % 4 == 0 && d.group > 1;
 }
@@ -105,10 +137,19 @@ int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     if (total == 0) return SHL_MI355X_OK;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    if (dtype == SHL_MI355X_I8)
-        hipLaunchKernelGGL((dwconv_nhwc_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((dwconv_nhwc_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)blocks), block(256);
+    const bool k3 = a.Kh == 3 && a.Kw == 3;
+    if (dtype == SHL_MI355X_I8) {
+        if (k3)
+            hipLaunchKernelGGL((dwconv_nhwc_kernel<true, 3>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((dwconv_nhwc_kernel<true, 0>), grid, block, 0, s, a);
+    } else {
+        if (k3)
+            hipLaunchKernelGGL((dwconv_nhwc_kernel<false, 3>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((dwconv_nhwc_kernel<false, 0>), grid, block, 0, s, a);
+    }
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }
