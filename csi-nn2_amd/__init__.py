@@ -24,7 +24,7 @@ MEM_CPU, MEM_DMABUF, MEM_CPU_ACC = 0, 2, 5
 QUANT_INT8_ASYM_W_SYM, QUANT_FLOAT16 = 11, 7
 API_REF, API_GREF, API_MI355X = 0, 1, 14
 RM_LAYER, RM_CPU_GRAPH = 0, 1
-LAYOUT_NC, LAYOUT_NCHW, LAYOUT_O, LAYOUT_OI, LAYOUT_OIHW, LAYOUT_O1HW = 2, 4, 6, 7, 11, 13
+LAYOUT_N, LAYOUT_NC, LAYOUT_NCHW, LAYOUT_O, LAYOUT_OI, LAYOUT_OIHW, LAYOUT_O1HW = 1, 2, 4, 6, 7, 11, 13
 LAYOUT_NHWC, LAYOUT_OHWI, LAYOUT_1HWO = 15, 18, 22
 CSINN_TRUE = 1
 OP_CONV2D, OP_CONV2D_RELU, OP_CONV2D_RELU6 = 28, 29, 30
@@ -221,14 +221,17 @@ _CONV_OPS = ["csinn_conv2d", "csinn_conv2d_relu", "csinn_conv2d_relu6", "csinn_d
              "csinn_depthwise_conv2d_relu", "csinn_fullyconnected", "csinn_relu", "csinn_relu6"]
 
 
-def load_frontend(kind="standalone"):
+def load_frontend(kind="standalone", local=False):
     """kind: 'standalone' (this repo's libcsinn_nn2.so) or 'reference' (oracle/_ref genuine lib;
-    test infrastructure only)."""
+    test infrastructure only).  local=True keeps the library's symbols out of the global scope
+    (needed when both front-ends live in one process: the backend library binds its front-end
+    symbols to whichever was loaded globally first)."""
+    mode = C.RTLD_LOCAL if local else C.RTLD_GLOBAL
     if kind == "standalone":
-        lib = _cdll(lib_path("libcsinn_nn2.so"))
+        lib = _cdll(lib_path("libcsinn_nn2.so"), mode)
     elif kind == "reference":
         C.CDLL("libgomp.so.1", mode=C.RTLD_GLOBAL)
-        lib = _cdll(reference_lib_path())
+        lib = _cdll(reference_lib_path(), mode)
     else:
         raise ValueError(kind)
     if getattr(lib, "_typed", False):

@@ -256,7 +256,7 @@ def have_reference():
 def reference_run(case):
     """Genuine reference (CSINN_REF, layer mode).  The x86 NCHW path only computes image 0
     (SURVEY 0.5), so NCHW batches are driven one image at a time."""
-    fe = pkg.load_frontend("reference")
+    fe = pkg.load_frontend("reference", local=True)
     if case["layout"] == NCHW and case["n"] > 1 and not case["depthwise"]:
         outs = []
         for i in range(case["n"]):

@@ -1,0 +1,81 @@
+"""Multi-GPU support code on CPU: batch partitioning, bucket planning and the weight broadcast of
+csi-nn2_amd/sharding.py under a real 2-process gloo group (the same code runs under nccl = RCCL on
+the GPU node).  No GPU needed."""
+import importlib
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+import cases
+
+sharding = importlib.import_module("csi-nn2_amd.sharding")
+
+
+def test_shard_batch_covers_the_batch_exactly():
+    for total in (0, 1, 7, 8, 128, 1024, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_batch(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))          # contiguous, ordered
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1                                   # ragged by at most one
+    assert sharding.shard_batch(1024, 8, 3) == (384, 512)                         # BASELINE configs[4]
+
+
+def test_bucket_planning():
+    assert sharding.plan_buckets([]) == []
+    assert sharding.plan_buckets([10, 20, 30], bucket_bytes=1000) == [[0, 1, 2]]
+    assert sharding.plan_buckets([600, 600, 600], bucket_bytes=1000) == [[0], [1], [2]]
+    assert sharding.plan_buckets([400, 500, 200, 900], bucket_bytes=1000) == [[0, 1], [2], [3]]
+    big = sharding.plan_buckets([5000], bucket_bytes=1000)                        # oversize block: own bucket
+    assert big == [[0]]
+
+
+WORKER = textwrap.dedent("""
+    import importlib, os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    sharding = importlib.import_module("csi-nn2_amd.sharding")
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank = dist.get_rank()
+    sizes = [300, 4096, 17, 1000, 70000]
+    rng = np.random.default_rng(1234 if rank == 0 else 99)        # only rank 0 holds the real bytes
+    blocks = [rng.integers(0, 256, n, dtype=np.uint8) for n in sizes]
+    truth = [np.random.default_rng(1234).integers(0, 256, n, dtype=np.uint8) for n in [0]]  # warm the generator API
+    ref_rng = np.random.default_rng(1234)
+    expected = [ref_rng.integers(0, 256, n, dtype=np.uint8) for n in sizes]
+
+    def read_block(i, view):
+        view.copy_(torch.from_numpy(blocks[i]))
+
+    def write_block(i, view):
+        blocks[i][:] = view.numpy()
+
+    issued = sharding.broadcast_blocks(sizes, read_block, write_block, lambda n: torch.empty(n, dtype=torch.uint8),
+                                       dist, src=0, bucket_bytes=8192)
+    ok = all(np.array_equal(b, e) for b, e in zip(blocks, expected))
+    t = torch.tensor([int(ok)])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    start, stop = sharding.shard_batch(1024, dist.get_world_size(), rank)
+    cover = torch.tensor([stop - start])
+    dist.all_reduce(cover)
+    if rank == 0:
+        print("RESULT ok=%%d collectives=%%d covered=%%d" %% (int(t.item()), issued, int(cover.item())))
+    dist.destroy_process_group()
+""")
+
+
+def test_weight_broadcast_under_gloo_world_size_2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(root=cases.ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0]
+    # 5 blocks, 8 KiB buckets: [300, 4096, 17, 1000] share one bucket, 70000 gets its own -> 2 collectives
+    assert line == "RESULT ok=1 collectives=2 covered=1024", line
