@@ -181,6 +181,7 @@ def load_hip():
         "shl_mi355x_conv_plan_const_block": (vp, [vp, C.POINTER(sz)]),
         "shl_mi355x_conv_forward": (C.c_int, [vp, vp, vp, i32, vp]),
         "shl_mi355x_relu_i8": (C.c_int, [vp, vp, sz, f32, i32, f32, i32, i32, vp]),
+        "shl_mi355x_layout_convert": (C.c_int, [vp, vp, C.c_int64, i32, i32, i32, i32, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

@@ -191,5 +191,7 @@ int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 bool igemm_supports(const shl_mi355x_conv_desc &d);
 const char *igemm_variant(int64_t M, int64_t Co);  // "tile" | "regs" | "wave"
 bool dwconv_supports(const shl_mi355x_conv_desc &d);
+// [N][R][S] -> [N][S][R] for 1- or 2-byte elements (layout.hip)
+int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s);
 
 }  // namespace shl

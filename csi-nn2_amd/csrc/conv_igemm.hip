@@ -169,15 +169,24 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const Acc &acc, in
 }
 
 // =================================================================================================
-// conv_igemm_tile_kernel: global_load_lds 3-stage ring
-//   WR = 2: block tile 128 pixels x 128 channels (waves 2 x 2)
-//   WR = 1: block tile 256 pixels x  64 channels (waves 1 x 4) -- for Cout <= 64, where a 128-wide
-//           channel tile would spend half of its MFMAs on clamped duplicate rows
+// conv_igemm_tile_kernel: global_load_lds 3-stage ring, block tile = (64*WC pixels) x (32*MI*WR
+// channels), WR*WC waves, each wave MI x 2 MFMA tiles (32*MI channels x 64 pixels).
+//   <MI=2, WR=2, WC=2>  128 x 128, 4 waves   general purpose
+//   <MI=2, WR=1, WC=4>  256 x  64, 4 waves   Cout <= 64 (a wider channel tile would multiply zeros)
+//   <MI=4, WR=1, WC=4>  256 x 128, 4 waves   16 MFMAs per wave per K step for 6 DMA + 12 ds_read
+//   <MI=4, WR=2, WC=4>  256 x 256, 8 waves   16 MFMAs for 4 DMA + 12 ds_read, 2 waves per SIMD
+// The K step is bound by instruction ISSUE (an LDS-DMA costs ~100 cycles of issue, a ds_read_b128
+// ~16-32), not by bytes in flight (profiles/r01_notes.md); bigger wave tiles buy more MFMA cycles
+// per issued DMA / ds_read but need grids the ResNet-50 layers do not have at batch 128 (measured
+// slower there), so the two 256-wide-channel flavours are only chosen for very large grids.
+// (Issuing the DMAs of step+2 between the MFMAs of the current step was measured too: 5-10 %
+// slower on deep-K layers than issuing them right after the barrier.)
 //   kUniformTap: C*esize % 64 == 0, so a 64-byte K step lies inside ONE filter tap.  The tap's
 //           address delta is then wave-uniform (SALU) and a lane only adds it to its pixel base and
-//           tests one bit of a per-pixel tap-validity mask built in the prologue: ~7 VALU per DMA
-//           row instead of ~35 for the general cursor.
+//           tests two bits of per-pixel ky / kx validity masks built in the prologue.
 // =================================================================================================
+constexpr int NST = 3;  // ring depth (a 6-deep ring was measured: no gain, see notes)
+
 __device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
 {
     // 64 lanes x 16 B -> LDS[base + lane*16]; the destination is wave-uniform by construction
@@ -185,30 +194,30 @@ __device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// NST = ring depth: NST-1 K steps are in flight while one is consumed.  What a block can pull
-// from L2/HBM is (bytes in flight) / latency, so the ring is made as deep as the LDS budget of the
-// intended blocks-per-CU allows: 3 stages when the grid fills every CU three times over, 6 when
-// there is at most one block per CU.
-template <int WR, int NST>
+template <int MI, int WR, int WC>
 struct TileGeom {
-    static constexpr int WC = 4 / WR;
-    static constexpr int TBN = 64 * WR;            // channels per block
+    static constexpr int NWAVES = WR * WC;
+    static constexpr int THREADS = 64 * NWAVES;
+    static constexpr int TBN = 32 * MI * WR;       // channels per block
     static constexpr int TBM = 64 * WC;            // pixels per block
     static constexpr int ACT_B = TBM * BKB;        // activation tile bytes per stage
     static constexpr int WGT_B = TBN * BKB;
     static constexpr int STAGE_B = ACT_B + WGT_B;
     static constexpr int TAB_OFF = NST * STAGE_B;
     static constexpr int LDS_B = TAB_OFF + 3 * TBN * 4;
-    static constexpr int NA = TBM / 64;            // DMA instructions per wave per stage: activations
-    static constexpr int NW = TBN / 64;            //                                       weights
+    static constexpr int NA = TBM / 16 / NWAVES;   // DMA instructions per wave per stage: activations
+    static constexpr int NW = TBN / 16 / NWAVES;   //                                       weights
+    static constexpr int PER_STAGE = NA + NW;
+    static constexpr int NMFMA = MI * 2 * 2;       // MFMAs per wave per K step
+    static_assert(TBM % (16 * NWAVES) == 0 && TBN % (16 * NWAVES) == 0, "DMA rows must divide evenly");
 };
 
-template <bool kI8, int EPI, int WR, bool kUniformTap, int NST>
-__global__ __launch_bounds__(256) void conv_igemm_tile_kernel(ConvArgs a)
+template <bool kI8, int EPI, int MI, int WR, int WC, bool kUniformTap>
+__global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs a)
 {
-    using G = TileGeom<WR, NST>;
-    constexpr int LA = NST - 1;  // look-ahead in K steps
+    using G = TileGeom<MI, WR, WC>;
     constexpr int ESIZE = kI8 ? 1 : 2;
+    constexpr int LA = NST - 1;  // look-ahead in K steps
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -229,18 +238,18 @@ __global__ __launch_bounds__(256) void conv_igemm_tile_kernel(ConvArgs a)
         t_bias = a.bias[co0 + tid];
     }
 
-    // ---- DMA role.  Wave w fills rows [w*TBM/4, +TBM/4) of the activation tile and rows
-    // [w*TBN/4, +TBN/4) of the weight tile, 16 rows x 4 chunk slots per instruction.  LDS position
-    // (row r, slot s) receives global chunk s ^ ((r >> 2) & 3) of that row.
+    // ---- DMA role.  Wave w fills NA*16 rows of the activation tile and NW*16 rows of the weight
+    // tile, 16 rows x 4 chunk slots per instruction.  LDS position (row r, slot s) receives global
+    // chunk s ^ ((r >> 2) & 3) of that row.
     const int drow = lane >> 2;
     const int dslot = lane & 3;
     PixelRow arow[G::NA];
-    KCursor acur[G::NA];           // general addressing
+    KCursor acur[G::NA];                    // general addressing
     uint32_t aymask[G::NA], axmask[G::NA];  // uniform-tap addressing: valid ky / kx bit sets
     const char *wptr[G::NW];
 #pragma unroll
     for (int j = 0; j < G::NA; ++j) {
-        const int r = wave * (G::TBM / 4) + j * 16 + drow;
+        const int r = (wave * G::NA + j) * 16 + drow;
         const int chunk = dslot ^ ((r >> 2) & 3);
         arow[j] = make_row<ESIZE>(a, pix0 + r);
         if constexpr (kUniformTap) {
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_igemm_tile_kernel(ConvArgs a)
     }
 #pragma unroll
     for (int j = 0; j < G::NW; ++j) {
-        const int r = wave * (G::TBN / 4) + j * 16 + drow;
+        const int r = (wave * G::NW + j) * 16 + drow;
         int oc = co0 + r;
         oc = oc < a.Co ? oc : a.Co - 1;
         wptr[j] = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + (dslot ^ ((r >> 2) & 3)) * 16;
@@ -271,16 +280,15 @@ __global__ __launch_bounds__(256) void conv_igemm_tile_kernel(ConvArgs a)
     const int groups_per_tap = a.cchunks >> 2;
     const int pix_bytes = a.C * ESIZE;
 
-    auto issue = [&](auto stage_c) {
-        constexpr int stage = decltype(stage_c)::value;
-        char *sa = smem + stage * G::STAGE_B + wave * (G::TBM / 4) * BKB;
-        char *sw = smem + stage * G::STAGE_B + G::ACT_B + wave * (G::TBN / 4) * BKB;
+    // source addresses of this wave's DMA pieces for the next stage to be issued
+    const char *src[G::PER_STAGE];
+    auto prepare = [&]() {
         if constexpr (kUniformTap) {
             const int delta = (u_ty * a.dh * a.W + u_tx * a.dw) * pix_bytes + u_cc * BKB;
 #pragma unroll
             for (int j = 0; j < G::NA; ++j) {
                 const bool ok = ((aymask[j] >> u_ty) & (axmask[j] >> u_tx) & 1u) != 0;
-                glds16(ok ? arow[j].base + delta : pad, sa + j * 16 * BKB);
+                src[j] = ok ? arow[j].base + delta : pad;
             }
             if (++u_cc == groups_per_tap) {
                 u_cc = 0;
@@ -292,61 +300,70 @@ __global__ __launch_bounds__(256) void conv_igemm_tile_kernel(ConvArgs a)
         } else {
 #pragma unroll
             for (int j = 0; j < G::NA; ++j) {
-                glds16(chunk_addr<ESIZE>(a, arow[j], acur[j]), sa + j * 16 * BKB);
+                src[j] = chunk_addr<ESIZE>(a, arow[j], acur[j]);
                 acur[j].advance(a, 4);
             }
         }
 #pragma unroll
         for (int j = 0; j < G::NW; ++j) {
-            glds16(wptr[j], sw + j * 16 * BKB);
+            src[G::NA + j] = wptr[j];
             wptr[j] += BKB;
         }
     };
-    constexpr int PER_STAGE = G::NA + G::NW;  // DMA instructions per wave per stage
+    // LDS destination of piece d of a stage (wave-uniform)
+    auto dst_of = [&](int stage, int d) -> char * {
+        if (d < G::NA) return smem + stage * G::STAGE_B + (wave * G::NA + d) * 16 * BKB;
+        return smem + stage * G::STAGE_B + G::ACT_B + (wave * G::NW + (d - G::NA)) * 16 * BKB;
+    };
 
-    // ---- compute role: wave (wr, wc) owns channels [64wr, +64) x pixels [64wc, +64)
-    const int wr = wave / G::WC;
-    const int wc = wave % G::WC;
+    // ---- compute role: wave (wr, wc) owns channels [32*MI*wr, +32*MI) x pixels [64wc, +64)
+    const int wr = wave / WC;
+    const int wc = wave % WC;
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
-    int offA[2][2], offB[2][2];
+    int offA[MI][2], offB[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ra = wr * 64 + i * 32 + frow;
-            const int rb = wc * 64 + i * 32 + frow;
+        for (int i = 0; i < MI; ++i) {
+            const int ra = wr * 32 * MI + i * 32 + frow;
             offA[i][kk] = G::ACT_B + ra * BKB + (((2 * kk + fhalf) ^ ((ra >> 2) & 3)) << 4);
-            offB[i][kk] = rb * BKB + (((2 * kk + fhalf) ^ ((rb >> 2) & 3)) << 4);
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rb = wc * 64 + j * 32 + frow;
+            offB[j][kk] = rb * BKB + (((2 * kk + fhalf) ^ ((rb >> 2) & 3)) << 4);
+        }
+    }
 
     using acc_t = typename AccT<kI8>::type;
-    acc_t acc[2][2];
+    acc_t acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
     // prologue: fill the ring
-    auto prefill = [&](auto self, auto st_c) {
-        constexpr int st = decltype(st_c)::value;
-        if constexpr (st < LA) {
-            if (st < nsteps) issue(st_c);
-            self(self, std::integral_constant<int, st + 1>{});
+#pragma unroll
+    for (int st = 0; st < LA; ++st) {
+        if (st < nsteps) {
+            prepare();
+#pragma unroll
+            for (int d = 0; d < G::PER_STAGE; ++d) glds16(src[d], dst_of(st, d));
         }
-    };
-    prefill(prefill, std::integral_constant<int, 0>{});
+    }
 
     // one K step on a compile-time stage: LDS offsets and DMA targets fold into immediates
     auto body = [&](auto stage_c, int step) {
         constexpr int stage = decltype(stage_c)::value;
+        constexpr int nstage = (stage + LA) % NST;  // stage refilled during this step
         // this wave's DMA pieces of `step` (and everything older, e.g. the table loads) have
-        // landed once at most the pieces of step+1 remain outstanding
-        if (step + LA <= nsteps) {  // steady state: LA-1 younger stages stay in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (LA - 1)) : "memory");
-        } else {                    // tail: fewer stages were issued; drain
+        // landed once at most the pieces of the LA-1 younger stages remain outstanding
+        if (step + LA <= nsteps) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE * (LA - 1)) : "memory");
+        } else {  // tail: fewer stages were issued; drain
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (step == 0) {
@@ -358,95 +375,98 @@ __global__ __launch_bounds__(256) void conv_igemm_tile_kernel(ConvArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         // every wave's pieces landed, and every wave has finished reading the stage of step-1,
-        // which is the one the next DMA overwrites
+        // which is the one refilled below
         __builtin_amdgcn_s_barrier();
-        if (step + LA < nsteps) issue(std::integral_constant<int, (stage + LA) % NST>{});
+        if (step + LA < nsteps) {
+            prepare();
+#pragma unroll
+            for (int d = 0; d < G::PER_STAGE; ++d) glds16(src[d], dst_of(nstage, d));
+        }
         const char *sb = smem + stage * G::STAGE_B;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            v4i fa[2], fb[2];
+            v4i fa[MI], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const v4i *>(sb + offA[i][kk]);
-                fb[i] = *reinterpret_cast<const v4i *>(sb + offB[i][kk]);
-            }
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const v4i *>(sb + offA[i][kk]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i *>(sb + offB[j][kk]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma<kI8>(fa[i], fb[j], acc[i][j]);
         }
     };
-    auto round = [&](auto self, auto st_c, int step0) {
-        constexpr int st = decltype(st_c)::value;
-        if constexpr (st < NST) {
-            if (step0 + st < nsteps) {
-                body(st_c, step0 + st);
-                self(self, std::integral_constant<int, st + 1>{}, step0);
-            }
-        }
-    };
-    for (int step = 0; step < nsteps; step += NST) round(round, std::integral_constant<int, 0>{}, step);
+    for (int step = 0; step < nsteps; step += NST) {
+        body(std::integral_constant<int, 0>{}, step);
+        if (step + 1 < nsteps) body(std::integral_constant<int, 1>{}, step + 1);
+        if (step + 2 < nsteps) body(std::integral_constant<int, 2>{}, step + 2);
+    }
     if (a.debug & 2) return;
 
     // ---- epilogue
     const int32_t *tab_acc = reinterpret_cast<const int32_t *>(smem + G::TAB_OFF);
     const float *tab_mult = reinterpret_cast<const float *>(smem + G::TAB_OFF) + G::TBN;
     const float *tab_bias = reinterpret_cast<const float *>(smem + G::TAB_OFF) + 2 * G::TBN;
-    constexpr int ROW_B = 64 * ESIZE;       // one pixel's 64 channels of this wave
-    constexpr int PITCH = ROW_B + 16;       // padded LDS row: spreads the 4-byte writes over banks
+    constexpr int ROW_B = 64 * ESIZE;  // one pixel's 64 channels (two MFMA row blocks)
+    constexpr int PITCH = ROW_B + 16;  // padded LDS row: spreads the 4-byte writes over banks
+    static_assert(G::NWAVES * 64 * PITCH <= NST * G::STAGE_B, "epilogue staging must fit in the ring");
     const bool staged = ((a.Co * ESIZE) & 15) == 0;
     if (staged) {
-        // Stage the wave's 64 pixel x 64 channel block through LDS (the ring is free now) so that
-        // every lane stores 16 contiguous bytes of one pixel: whole 64-byte (int8) / 128-byte (f16)
-        // channel runs per pixel instead of 4-byte pieces scattered over 32 cache lines.
+        // Stage 64 pixel x 64 channel blocks through LDS (the ring is free now) so that every lane
+        // stores 16 contiguous bytes of one pixel: whole 64-byte (int8) / 128-byte (f16) channel
+        // runs per pixel instead of 4-byte pieces scattered over 32 cache lines.
         __builtin_amdgcn_s_barrier();  // all waves are done reading the last stage
         char *ws = smem + wave * 64 * PITCH;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = i * 32 + 8 * g + 4 * fhalf;  // first of 4 channels, within the wave's 64
-                    const int ch = wr * 64 + c;
-                    const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + ch);
-                    char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
-                    if constexpr (kI8) {
-                        const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + ch);
-                        const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + ch);
-                        const int q0 = requant_i8_t<EPI>(acc[i][j][4 * g + 0] + ai.x, mu.x, bi.x, a);
-                        const int q1 = requant_i8_t<EPI>(acc[i][j][4 * g + 1] + ai.y, mu.y, bi.y, a);
-                        const int q2 = requant_i8_t<EPI>(acc[i][j][4 * g + 2] + ai.z, mu.z, bi.z, a);
-                        const int q3 = requant_i8_t<EPI>(acc[i][j][4 * g + 3] + ai.w, mu.w, bi.w, a);
-                        *reinterpret_cast<uint32_t *>(dst) = pack4_i8(q0, q1, q2, q3);
-                    } else {
-                        const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
-                        const uint32_t h1 = finish_f16(acc[i][j][4 * g + 1], bi.y, a);
-                        const uint32_t h2 = finish_f16(acc[i][j][4 * g + 2], bi.z, a);
-                        const uint32_t h3 = finish_f16(acc[i][j][4 * g + 3], bi.w, a);
-                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                    }
-                }
-        // wave-local hand-over: same wave wrote and reads, LDS ops complete in order
-        constexpr int CPR = ROW_B / 16;        // 16-byte chunks per row
-        constexpr int RPI = 64 / CPR;          // rows per store instruction
+        constexpr int CPR = ROW_B / 16;  // 16-byte chunks per staged row
+        constexpr int RPI = 64 / CPR;    // rows per store instruction
         const int srow = lane / CPR, schunk = lane % CPR;
-        const int oc_first = co0 + wr * 64 + schunk * (16 / ESIZE);
         char *out = static_cast<char *>(a.out);
 #pragma unroll
-        for (int it = 0; it < 64 / RPI; ++it) {
-            const int row = it * RPI + srow;
-            const int p = pix0 + wc * 64 + row;
-            const uint4 v = *reinterpret_cast<const uint4 *>(ws + row * PITCH + schunk * 16);
-            if (p < a.M && oc_first < a.Co)
-                *reinterpret_cast<uint4 *>(out + ((int64_t)p * a.Co + oc_first) * ESIZE) = v;
+        for (int ih = 0; ih < MI / 2; ++ih) {  // 64 channels at a time; the region is wave-private
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int i = ih * 2 + i2;
+                        const int c = i2 * 32 + 8 * g + 4 * fhalf;  // first of 4 channels within the 64
+                        const int ch = wr * 32 * MI + ih * 64 + c;   // within the block's TBN
+                        const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + ch);
+                        char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
+                        if constexpr (kI8) {
+                            const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + ch);
+                            const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + ch);
+                            const int q0 = requant_i8_t<EPI>(acc[i][j][4 * g + 0] + ai.x, mu.x, bi.x, a);
+                            const int q1 = requant_i8_t<EPI>(acc[i][j][4 * g + 1] + ai.y, mu.y, bi.y, a);
+                            const int q2 = requant_i8_t<EPI>(acc[i][j][4 * g + 2] + ai.z, mu.z, bi.z, a);
+                            const int q3 = requant_i8_t<EPI>(acc[i][j][4 * g + 3] + ai.w, mu.w, bi.w, a);
+                            *reinterpret_cast<uint32_t *>(dst) = pack4_i8(q0, q1, q2, q3);
+                        } else {
+                            const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
+                            const uint32_t h1 = finish_f16(acc[i][j][4 * g + 1], bi.y, a);
+                            const uint32_t h2 = finish_f16(acc[i][j][4 * g + 2], bi.z, a);
+                            const uint32_t h3 = finish_f16(acc[i][j][4 * g + 3], bi.w, a);
+                            *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                        }
+                    }
+            // wave-local hand-over: the same wave wrote and reads; LDS operations complete in order
+            const int oc_first = co0 + wr * 32 * MI + ih * 64 + schunk * (16 / ESIZE);
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int row = it * RPI + srow;
+                const int p = pix0 + wc * 64 + row;
+                const uint4 v = *reinterpret_cast<const uint4 *>(ws + row * PITCH + schunk * 16);
+                if (p < a.M && oc_first < a.Co)
+                    *reinterpret_cast<uint4 *>(out + ((int64_t)p * a.Co + oc_first) * ESIZE) = v;
+            }
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int ch = wr * 64 + i * 32;
+                const int ch = wr * 32 * MI + i * 32;
                 store_tile<kI8, EPI>(a, acc[i][j], pix0 + wc * 64 + j * 32 + frow, co0 + ch, fhalf,
                                      tab_acc + ch, tab_mult + ch, tab_bias + ch);
             }
@@ -671,7 +691,7 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
 bool igemm_supports(const shl_mi355x_conv_desc &d)
 {
     if (d.group != 1) return false;
-    if (d.layout != SHL_MI355X_NHWC) return false;  // NCHW input needs the transposing loader
+    // NCHW tensors are re-laid out to NHWC scratch around the kernel (conv_plan.hip, layout.hip)
     const int esize = d.dtype == SHL_MI355X_I8 ? 1 : 2;
     if ((d.in_c * esize) % 16 != 0) return false;
     if (d.dtype == SHL_MI355X_I8 && (d.in_zp < -128 || d.in_zp > 127)) return false;
@@ -681,7 +701,7 @@ bool igemm_supports(const shl_mi355x_conv_desc &d)
 // one launcher per kernel instantiation: kernels that need more than 64 KiB of dynamic LDS must be
 // opted in once through hipFuncSetAttribute
 template <void (*KERNEL)(ConvArgs)>
-static void launch_kernel(dim3 grid, size_t lds, hipStream_t s, const ConvArgs &a)
+static void launch_kernel(dim3 grid, size_t lds, hipStream_t s, const ConvArgs &a, int threads = 256)
 {
     static bool opted_in = false;
     if (lds > 64 * 1024 && !opted_in) {
@@ -689,7 +709,7 @@ static void launch_kernel(dim3 grid, size_t lds, hipStream_t s, const ConvArgs &
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         opted_in = true;
     }
-    hipLaunchKernelGGL(KERNEL, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(KERNEL, grid, dim3(threads), lds, s, a);
 }
 
 // "tile" | "regs" | "wave" | "" (automatic) -- read once; for A/B measurements only
@@ -703,30 +723,27 @@ const char *igemm_variant(int64_t M, int64_t Co)
 {
     const char *ov = variant_override();
     if (ov[0]) return ov;
-    // block-tile grid vs wave-tile grid: prefer the LDS tile kernel once it can put at least two
-    // blocks on every CU; below that, latency dominates and the barrier-free wave kernel wins
+    // LDS tile kernel once there is at least ~one 128x128 tile for every other CU; below that
+    // (MobileNetV1 at batch 1: 1-98 tiles) latency dominates and the barrier-free wave kernel wins
     const int64_t blocks128 = ((M + BM - 1) / BM) * ((Co + BN - 1) / BN);
-    return blocks128 >= 512 ? "tile" : "wave";
+    return blocks128 >= 128 ? "tile" : "wave";
 }
 
 int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
 {
     if (a.M == 0 || a.Co == 0) return SHL_MI355X_OK;
-    if (layout != SHL_MI355X_NHWC) {
-        set_error("igemm: NCHW activations are not supported by this kernel");
-        return SHL_MI355X_ENOTSUP;
-    }
+    (void)layout;  // the kernels see NHWC; NCHW callers were re-laid out by the plan
     const char *v = igemm_variant(a.M, a.Co);
     const bool i8 = dtype == SHL_MI355X_I8;
     const int epi = i8 ? epi_code(a) : 0;
     const int esize = i8 ? 1 : 2;
     dim3 grid;
     size_t lds = 0;
+    int threads = 256;
     int kind;  // 0 wave, 1 regs, 2 tile
-    bool deep = false;
-    // tile flavours: 256x64 for narrow outputs; uniform-tap addressing when a K step stays in a tap
-    const bool narrow = a.Co <= 64;
+    // tile flavours (see the kernel header); uniform-tap addressing when a K step stays in a tap
     const bool utap = (a.C * esize) % 64 == 0 && a.Kh * a.Kw <= 32;
+    enum { T128, T256x64, T256x128, T256x256 } tile = T128;
     if (!strcmp(v, "wave")) {
         const int64_t tiles = (int64_t)((a.M + 31) / 32) * ((a.Co + 31) / 32);
         grid = dim3((unsigned)((tiles + 3) / 4));
@@ -736,19 +753,32 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         kind = 1;
         lds = 4 * RTILE_B + 3 * 128 * 4;
     } else {
-        const int tbm = narrow ? 256 : 128, tbn = narrow ? 64 : 128;
-        grid = dim3((unsigned)(((a.M + tbm - 1) / tbm) * ((a.Co + tbn - 1) / tbn)));
         kind = 2;
-        // A deeper ring (6 stages, one block per CU) was measured on the ResNet-50 3x3 set at batch
-        // 128: no gain on the 196-block layers, 30-50 % slower elsewhere (profiles/r01_notes.md):
-        // the K step is bound by DMA/ds_read ISSUE, not by bytes in flight.  Kept for A/B only.
-        deep = false;
-        static const char *nst_env = getenv("SHL_MI355X_NST");
-        if (nst_env) deep = atoi(nst_env) > 3;
-        lds = narrow ? (deep ? TileGeom<1, 6>::LDS_B : TileGeom<1, 3>::LDS_B)
-                     : (deep ? TileGeom<2, 6>::LDS_B : TileGeom<2, 3>::LDS_B);
+        const int64_t m256 = (a.M + 255) / 256;
+        if (a.Co <= 64) {
+            tile = T256x64;
+        } else if (utap && a.Co >= 256 && m256 * ((a.Co + 255) / 256) >= 1024) {
+            tile = T256x256;  // only when the grid still covers every CU four times
+        } else if (utap && m256 * ((a.Co + 127) / 128) >= 2048) {
+            tile = T256x128;
+        }
+        static const char *tile_env = getenv("SHL_MI355X_TILE");  // A/B override
+        if (tile_env) {
+            if (!strcmp(tile_env, "128")) tile = T128;
+            else if (!strcmp(tile_env, "256x64")) tile = T256x64;
+            else if (!strcmp(tile_env, "256x128") && utap) tile = T256x128;
+            else if (!strcmp(tile_env, "256x256") && utap) tile = T256x256;
+        }
+        int tbm = 128, tbn = 128;
+        switch (tile) {
+            case T256x64: tbm = 256; tbn = 64; lds = TileGeom<2, 1, 4>::LDS_B; break;
+            case T256x128: tbm = 256; tbn = 128; lds = TileGeom<4, 1, 4>::LDS_B; break;
+            case T256x256: tbm = 256; tbn = 256; lds = TileGeom<4, 2, 4>::LDS_B; threads = 512; break;
+            default: lds = TileGeom<2, 2, 2>::LDS_B; break;
+        }
+        grid = dim3((unsigned)(((a.M + tbm - 1) / tbm) * ((a.Co + tbn - 1) / tbn)));
     }
-#define SHL_LAUNCH(...) launch_kernel<__VA_ARGS__>(grid, lds, s, a)
+#define SHL_LAUNCH(...) launch_kernel<__VA_ARGS__>(grid, lds, s, a, threads)
 #define SHL_LAUNCH_EPI(KERNEL, ...)                                   \
     switch (epi) {                                                    \
         case 0: SHL_LAUNCH(KERNEL<true, 0 __VA_ARGS__>); break;       \
@@ -759,29 +789,23 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         default: SHL_LAUNCH(KERNEL<true, 5 __VA_ARGS__>); break;      \
     }
 #define SHL_COMMA ,
+#define SHL_TILE(MI, WRV, WCV, UT)                                                                          \
+    if (i8) { SHL_LAUNCH_EPI(conv_igemm_tile_kernel, SHL_COMMA MI SHL_COMMA WRV SHL_COMMA WCV SHL_COMMA UT) } \
+    else { SHL_LAUNCH(conv_igemm_tile_kernel<false, 0, MI, WRV, WCV, UT>); }
     if (kind == 0) {
         if (i8) { SHL_LAUNCH_EPI(conv_igemm_wave_kernel) } else { SHL_LAUNCH(conv_igemm_wave_kernel<false, 0>); }
     } else if (kind == 1) {
         if (i8) { SHL_LAUNCH_EPI(conv_igemm_regs_kernel) } else { SHL_LAUNCH(conv_igemm_regs_kernel<false, 0>); }
-    } else if (i8) {
-#define SHL_TILE_I8(WRV, UT)                                                                   \
-    if (deep) { SHL_LAUNCH_EPI(conv_igemm_tile_kernel, SHL_COMMA WRV SHL_COMMA UT SHL_COMMA 6) } \
-    else { SHL_LAUNCH_EPI(conv_igemm_tile_kernel, SHL_COMMA WRV SHL_COMMA UT SHL_COMMA 3) }
-        if (narrow && utap) { SHL_TILE_I8(1, true) }
-        else if (narrow) { SHL_TILE_I8(1, false) }
-        else if (utap) { SHL_TILE_I8(2, true) }
-        else { SHL_TILE_I8(2, false) }
-#undef SHL_TILE_I8
+    } else if (tile == T256x256) {
+        SHL_TILE(4, 2, 4, true)
+    } else if (tile == T256x128) {
+        SHL_TILE(4, 1, 4, true)
+    } else if (tile == T256x64) {
+        if (utap) { SHL_TILE(2, 1, 4, true) } else { SHL_TILE(2, 1, 4, false) }
     } else {
-#define SHL_TILE_F16(WRV, UT)                                                  \
-    if (deep) SHL_LAUNCH(conv_igemm_tile_kernel<false, 0, WRV, UT, 6>);        \
-    else SHL_LAUNCH(conv_igemm_tile_kernel<false, 0, WRV, UT, 3>);
-        if (narrow && utap) { SHL_TILE_F16(1, true) }
-        else if (narrow) { SHL_TILE_F16(1, false) }
-        else if (utap) { SHL_TILE_F16(2, true) }
-        else { SHL_TILE_F16(2, false) }
-#undef SHL_TILE_F16
+        if (utap) { SHL_TILE(2, 2, 2, true) } else { SHL_TILE(2, 2, 2, false) }
     }
+#undef SHL_TILE
 #undef SHL_COMMA
 #undef SHL_LAUNCH_EPI
 #undef SHL_LAUNCH

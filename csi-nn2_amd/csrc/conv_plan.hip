@@ -21,6 +21,9 @@ struct shl_mi355x_conv_plan {
     // int8 epilogue shortcuts (see ConvArgs)
     int32_t div_exact, act_clamp;
     float clamp_lo, clamp_hi, inv_out_scale;
+    // NCHW through the NHWC MFMA kernel: scratch images of the input and output, sized for
+    // desc.batch at plan time (no allocation may happen inside a captured forward)
+    char *scratch_in, *scratch_out;
     int32_t kstride;   // igemm: packed row bytes
     int32_t kchunks;
     int32_t cchunks;
@@ -246,6 +249,19 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             }
         }
     }
+    if (algo == SHL_MI355X_ALGO_IGEMM && d.layout == SHL_MI355X_NCHW && d.batch > 0) {
+        const size_t in_b = (size_t)d.batch * d.in_c * d.in_h * d.in_w * es;
+        const size_t out_b = (size_t)d.batch * d.out_c * d.out_h * d.out_w * es;
+        if (hipMalloc((void **)&p->scratch_in, in_b) != hipSuccess ||
+            hipMalloc((void **)&p->scratch_out, out_b) != hipSuccess) {
+            (void)hipFree(p->scratch_in);
+            (void)hipFree(p->block);
+            free(p);
+            set_error("conv_plan_create: cannot allocate the NCHW re-layout scratch");
+            (void)hipGetLastError();
+            return SHL_MI355X_ENOMEM;
+        }
+    }
     e = hipMemcpyAsync(p->block, host.data(), p->block_bytes, hipMemcpyHostToDevice,
                        (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);  // host staging dies here
@@ -261,6 +277,8 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
 int shl_mi355x_conv_plan_destroy(shl_mi355x_conv_plan *plan)
 {
     if (!plan) return SHL_MI355X_OK;
+    (void)hipFree(plan->scratch_in);
+    (void)hipFree(plan->scratch_out);
     hipError_t e = hipFree(plan->block);
     free(plan);
     if (e != hipSuccess) return hip_fail(e, "hipFree(plan block)");
@@ -274,7 +292,17 @@ const char *shl_mi355x_conv_plan_kernel_name(const shl_mi355x_conv_plan *plan)
     return plan ? plan->kernel_name : "";
 }
 
-size_t shl_mi355x_conv_plan_bytes(const shl_mi355x_conv_plan *plan) { return plan ? plan->block_bytes : 0; }
+size_t shl_mi355x_conv_plan_bytes(const shl_mi355x_conv_plan *plan)
+{
+    if (!plan) return 0;
+    size_t n = plan->block_bytes;
+    if (plan->scratch_in) {
+        const shl_mi355x_conv_desc &d = plan->desc;
+        const size_t es = d.dtype == SHL_MI355X_I8 ? 1 : 2;
+        n += ((size_t)d.batch * d.in_c * d.in_h * d.in_w + (size_t)d.batch * d.out_c * d.out_h * d.out_w) * es;
+    }
+    return n;
+}
 
 void *shl_mi355x_conv_plan_const_block(shl_mi355x_conv_plan *plan, size_t *bytes)
 {
@@ -336,8 +364,22 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
     if (a.M == 0) return SHL_MI355X_OK;
     hipStream_t s = (hipStream_t)stream;
     switch (plan->algo) {
-        case SHL_MI355X_ALGO_IGEMM:
-            return launch_conv_igemm(a, d.dtype, d.layout, s);
+        case SHL_MI355X_ALGO_IGEMM: {
+            if (d.layout == SHL_MI355X_NHWC) return launch_conv_igemm(a, d.dtype, d.layout, s);
+            // NCHW: [C][HW] -> [HW][C] scratch, NHWC kernel, [HoWo][Co] -> [Co][HoWo]
+            if (a.N > d.batch || !plan->scratch_in) {
+                set_error("conv_forward: NCHW plan was created for batch %d, got %d", d.batch, a.N);
+                return SHL_MI355X_EINVAL;
+            }
+            const int es = d.dtype == SHL_MI355X_I8 ? 1 : 2;
+            int rc = launch_transpose(input_dev, plan->scratch_in, a.N, a.C, a.H * a.W, es, s);
+            if (rc != SHL_MI355X_OK) return rc;
+            a.in = plan->scratch_in;
+            a.out = plan->scratch_out;
+            rc = launch_conv_igemm(a, d.dtype, SHL_MI355X_NHWC, s);
+            if (rc != SHL_MI355X_OK) return rc;
+            return launch_transpose(plan->scratch_out, output_dev, a.N, a.Ho * a.Wo, a.Co, es, s);
+        }
         case SHL_MI355X_ALGO_DW:
             return launch_dwconv(a, d.dtype, d.layout, s);
         default:

@@ -1,0 +1,168 @@
+// layout.hip -- NCHW <-> NHWC re-layout of activations in HBM (int8 and binary16).
+//
+// The MFMA convolution consumes channel-fastest activations (a 16-byte K chunk = 16 consecutive
+// channels of one pixel).  NCHW tensors reach it through these kernels: per image a [C][HW] matrix
+// is transposed to [HW][C] and back.  HBM-bound; organised so that BOTH sides of the copy are
+// coalesced:
+//   fast kernels (HW % 4 == 0, C % 4 == 0): a 64 x 64 element tile goes through LDS; global reads
+//     and writes are 4..16 bytes per lane along the contiguous dimension of each layout, the
+//     transpose itself is 4x4 (int8) / 2x2 (f16) in registers (v_perm_b32) plus the LDS pass;
+//   generic kernel (any shape): one element per thread, write-coalesced.
+// Plays the role of shl_ref_nchw_to_nhwc_* / shl_ref_nhwc_to_nchw_* (source/reference/utils.c)
+// used by the reference's own NCHW convolution on non-x86 builds (convolution.c:123-135).
+#include "common.h"
+
+namespace shl {
+
+constexpr int TP = 64;        // tile edge in elements
+constexpr int PITCH8 = 80;    // LDS row pitch (bytes) for 64 int8 + pad, 16-byte aligned
+
+// 4x4 byte transpose: in[i] holds bytes (row i, col 0..3); out[j] holds (row 0..3, col j)
+__device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&in)[4], uint32_t (&out)[4])
+{
+    const uint32_t t0 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u);  // r0c0 r1c0 r0c1 r1c1
+    const uint32_t t1 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u);  // r2c0 r3c0 r2c1 r3c1
+    const uint32_t t2 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);  // r0c2 r1c2 r0c3 r1c3
+    const uint32_t t3 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
+    out[1] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
+    out[2] = __builtin_amdgcn_perm(t3, t2, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(t3, t2, 0x07060302u);
+}
+
+// src [N][R][S] -> dst [N][S][R], 1-byte elements, R % 4 == 0 and S % 4 == 0.
+// (R, S) = (C, HW) for NCHW->NHWC and (HW, C) for NHWC->NCHW.
+__global__ __launch_bounds__(256) void transpose_i8_kernel(const uint8_t *__restrict__ src,
+                                                           uint8_t *__restrict__ dst, int R, int S,
+                                                           int r_tiles, int s_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TP * PITCH8];  // [s][r]
+    int b = blockIdx.x;
+    const int ts = b % s_tiles;
+    b /= s_tiles;
+    const int tr = b % r_tiles;
+    const int n = b / r_tiles;
+    const int r0 = tr * TP, s0 = ts * TP;
+    const uint8_t *in = src + (int64_t)n * R * S;
+    uint8_t *out = dst + (int64_t)n * R * S;
+    // phase 1: each thread takes a 4(r) x 4(s) patch: 4 dword loads along s, transposes, and
+    // writes 4 dwords "4 consecutive r of one s" into the tile
+    const int pr = (threadIdx.x >> 4) * 4;  // 0..60
+    const int ps = (threadIdx.x & 15) * 4;  // 0..60
+    if (r0 + pr < R && s0 + ps < S) {
+        uint32_t rows[4], cols[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rows[i] = *reinterpret_cast<const uint32_t *>(in + (int64_t)(r0 + pr + i) * S + s0 + ps);
+        transpose4x4_bytes(rows, cols);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t *>(tile + (ps + j) * PITCH8 + pr) = cols[j];
+    }
+    __syncthreads();
+    // phase 2: 16 bytes (16 consecutive r) of one s per thread
+    const int qs = threadIdx.x >> 2;        // 0..63
+    const int qr = (threadIdx.x & 3) * 16;  // 0,16,32,48
+    if (s0 + qs < S) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(tile + qs * PITCH8 + qr);
+        uint8_t *o = out + (int64_t)(s0 + qs) * R + r0 + qr;
+        if (r0 + qr + 16 <= R && (R & 15) == 0) {
+            *reinterpret_cast<uint4 *>(o) = v;
+        } else {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (r0 + qr + 4 * k < R) *reinterpret_cast<uint32_t *>(o + 4 * k) = w[k];
+        }
+    }
+}
+
+// src [N][R][S] -> dst [N][S][R], any element size (1 or 2 bytes), any shape; write-coalesced
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_generic_kernel(const T *__restrict__ src, T *__restrict__ dst,
+                                                                int64_t total, int R, int S)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i % R);
+        const int64_t t = i / R;
+        const int s = (int)(t % S);
+        const int64_t n = t / S;
+        dst[i] = src[(n * R + r) * S + s];
+    }
+}
+
+// 2-byte elements through a 64 x 64 LDS tile (pitch 65 halves: conflict-light column reads)
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const uint16_t *__restrict__ src,
+                                                            uint16_t *__restrict__ dst, int R, int S,
+                                                            int r_tiles, int s_tiles)
+{
+    __shared__ uint16_t tile[TP * (TP + 2)];  // [r][s], pitch 66 halves = 33 dwords
+    int b = blockIdx.x;
+    const int ts = b % s_tiles;
+    b /= s_tiles;
+    const int tr = b % r_tiles;
+    const int n = b / r_tiles;
+    const int r0 = tr * TP, s0 = ts * TP;
+    const uint16_t *in = src + (int64_t)n * R * S;
+    uint16_t *out = dst + (int64_t)n * R * S;
+    // load: 2 halves (one dword) per thread per pass, rows of 64 halves = 32 dwords
+    const int lx = (threadIdx.x & 31) * 2;
+    const int ly = threadIdx.x >> 5;  // 0..7
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int r = ly + pass * 8;
+        if (r0 + r < R && s0 + lx < S) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(in + (int64_t)(r0 + r) * S + s0 + lx);
+            *reinterpret_cast<uint32_t *>(tile + r * (TP + 2) + lx) = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int s = ly + pass * 8;
+        if (s0 + s < S && r0 + lx < R) {
+            const uint32_t v = (uint32_t)tile[lx * (TP + 2) + s] | ((uint32_t)tile[(lx + 1) * (TP + 2) + s] << 16);
+            *reinterpret_cast<uint32_t *>(out + (int64_t)(s0 + s) * R + r0 + lx) = v;
+        }
+    }
+}
+
+// [N][R][S] -> [N][S][R]
+int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s)
+{
+    const int64_t total = n * R * S;
+    if (total == 0) return SHL_MI355X_OK;
+    const int r_tiles = (R + TP - 1) / TP, s_tiles = (S + TP - 1) / TP;
+    const int64_t blocks = n * r_tiles * s_tiles;
+    if (esize == 1 && (R & 3) == 0 && (S & 3) == 0 && blocks < 0x7FFFFFFF) {
+        hipLaunchKernelGGL(transpose_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), R, S, r_tiles, s_tiles);
+    } else if (esize == 2 && (R & 1) == 0 && (S & 1) == 0 && blocks < 0x7FFFFFFF) {
+        hipLaunchKernelGGL(transpose_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<const uint16_t *>(src), static_cast<uint16_t *>(dst), R, S, r_tiles, s_tiles);
+    } else {
+        int64_t g = (total + 255) / 256;
+        if (g > 256 * 64) g = 256 * 64;
+        if (esize == 1)
+            hipLaunchKernelGGL((transpose_generic_kernel<uint8_t>), dim3((unsigned)g), dim3(256), 0, s,
+                               static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), total, R, S);
+        else
+            hipLaunchKernelGGL((transpose_generic_kernel<uint16_t>), dim3((unsigned)g), dim3(256), 0, s,
+                               static_cast<const uint16_t *>(src), static_cast<uint16_t *>(dst), total, R, S);
+    }
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}
+
+}  // namespace shl
+
+extern "C" int shl_mi355x_layout_convert(const void *src_dev, void *dst_dev, int64_t batch, int32_t channels,
+                                         int32_t pixels, int32_t elem_bytes, int32_t to_nhwc, void *stream)
+{
+    if (!src_dev || !dst_dev || batch < 0 || channels <= 0 || pixels <= 0 || (elem_bytes != 1 && elem_bytes != 2)) {
+        shl::set_error("layout_convert: invalid argument");
+        return SHL_MI355X_EINVAL;
+    }
+    // NCHW -> NHWC transposes [C][HW]; NHWC -> NCHW transposes [HW][C]
+    return to_nhwc ? shl::launch_transpose(src_dev, dst_dev, batch, channels, pixels, elem_bytes, (hipStream_t)stream)
+                   : shl::launch_transpose(src_dev, dst_dev, batch, pixels, channels, elem_bytes, (hipStream_t)stream);
+}

@@ -190,6 +190,13 @@ int shl_mi355x_relu_i8(const int8_t *input_dev, int8_t *output_dev, size_t count
                        float in_scale, int32_t in_zp, float out_scale, int32_t out_zp,
                        int32_t relu6, void *stream);
 
+/* NCHW <-> NHWC re-layout of an activation tensor in HBM (int8: elem_bytes 1, fp16: 2):
+ * shl_ref_nchw_to_nhwc_* / shl_ref_nhwc_to_nchw_* of source/reference/utils.c, which the
+ * reference's own NCHW convolution uses on non-x86 builds (convolution.c:123-135).
+ * `pixels` = H*W.  to_nhwc != 0: [N,C,HW] -> [N,HW,C]; to_nhwc == 0: the inverse. */
+int shl_mi355x_layout_convert(const void *src_dev, void *dst_dev, int64_t batch, int32_t channels,
+                              int32_t pixels, int32_t elem_bytes, int32_t to_nhwc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -176,6 +176,27 @@ def test_relu_kernels(gpu):
         dev.free(dout)
 
 
+@pytest.mark.parametrize("n,c,hw,dt", [(2, 64, 56 * 56, np.int8), (3, 20, 36, np.int8), (1, 7, 49, np.int8),
+                                       (2, 128, 196, np.int8), (2, 64, 28 * 28, np.float16), (1, 6, 10, np.float16),
+                                       (1, 5, 7, np.float16), (1, 1024, 49, np.int8), (1, 48, 4, np.int8)])
+def test_layout_convert_round_trip(gpu, n, c, hw, dt):
+    """NCHW <-> NHWC re-layout kernels (fast tiled forms and the generic form) against numpy."""
+    fe, hip, opt, dev = gpu
+    rng = np.random.default_rng(c * hw)
+    x = rng.integers(-128, 128, (n, c, hw)).astype(dt) if dt == np.int8 else rng.standard_normal((n, c, hw)).astype(dt)
+    es = np.dtype(dt).itemsize
+    d_src, d_dst, d_back = dev.alloc(x.nbytes), dev.alloc(x.nbytes), dev.alloc(x.nbytes)
+    dev.upload(d_src, x)
+    pkg.check(hip.shl_mi355x_layout_convert(d_src, d_dst, n, c, hw, es, 1, None), hip, "to_nhwc")
+    nhwc = dev.download(d_dst, (n, hw, c), dt)
+    assert np.array_equal(nhwc.view(np.uint8), np.ascontiguousarray(x.transpose(0, 2, 1)).view(np.uint8))
+    pkg.check(hip.shl_mi355x_layout_convert(d_dst, d_back, n, c, hw, es, 0, None), hip, "to_nchw")
+    back = dev.download(d_back, (n, c, hw), dt)
+    assert np.array_equal(back.view(np.uint8), x.view(np.uint8))
+    for p in (d_src, d_dst, d_back):
+        dev.free(p)
+
+
 # ---- full-size checks: BASELINE.json shapes, oracle where it finishes in seconds, otherwise
 # size-independent properties -------------------------------------------------------------------
 def test_mobilenet_first_layers_full_size(gpu):
@@ -210,6 +231,23 @@ def test_resnet_3x3_full_size_properties(gpu):
                     kernel=np.ascontiguousarray(case["kernel"][..., perm]))
     again, _ = _run(gpu, shuffled, device_tensors=True)
     assert np.array_equal(again, got)
+
+
+def test_resnet_3x3_nchw_through_the_mfma_kernel(gpu):
+    """BASELINE configs[2] layout: NCHW / OIHW.  The plan re-lays the tensors out around the NHWC
+    MFMA kernel; results must equal the NHWC run of the same problem and the oracle on image 0."""
+    fe, hip, opt, dev = gpu
+    nchw = cases.make_case(903, layout=NCHW, n=4, h=28, w=28, c=128, co=128)
+    got, kname = _run(gpu, nchw, device_tensors=True)
+    assert "igemm" in kname, kname
+    nhwc = dict(nchw, layout=NHWC, input=np.ascontiguousarray(nchw["input"].transpose(0, 2, 3, 1)),
+                kernel=np.ascontiguousarray(nchw["kernel"].transpose(0, 2, 3, 1)),
+                in_shape=(4, 28, 28, 128), w_shape=(128, 3, 3, 128), out_shape=(4, 28, 28, 128))
+    ref, _ = _run(gpu, nhwc, device_tensors=True)
+    assert np.array_equal(got, ref.transpose(0, 3, 1, 2))
+    one = dict(nchw, n=1, input=nchw["input"][:1], in_shape=(1,) + nchw["in_shape"][1:],
+               out_shape=(1,) + nchw["out_shape"][1:])
+    assert np.array_equal(got[:1], cases.oracle_run(one, "exact"))
 
 
 def test_zero_weights_give_requantised_bias(gpu):
