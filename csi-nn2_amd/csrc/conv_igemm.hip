@@ -185,7 +185,14 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const Acc &acc, in
 //           address delta is then wave-uniform (SALU) and a lane only adds it to its pixel base and
 //           tests two bits of per-pixel ky / kx validity masks built in the prologue.
 // =================================================================================================
-constexpr int NST = 3;  // ring depth (a 6-deep ring was measured: no gain, see notes)
+// Two loop structures share the kernel:
+//   PIPE = false  3-stage ring.  Step t: wait DMA(t), barrier, issue DMA(t+2), read fragments, MFMA.
+//   PIPE = true   4-stage ring, software pipelined.  The barrier of step t certifies stage t+1, so
+//                 the fragments of (t+1, kk0) are fetched from LDS while the MFMAs of (t, kk1) run
+//                 and every MFMA group starts with its operands already in registers: a wave's
+//                 K step is then paced by the matrix pipe (256 cycles) instead of by
+//                 barrier + LDS latency + MFMA in series (600-700 cycles measured with one wave
+//                 per SIMD, profiles/r01_notes.md).
 
 __device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
 {
@@ -194,8 +201,9 @@ __device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MI, int WR, int WC>
+template <int MI, int WR, int WC, bool PIPE>
 struct TileGeom {
+    static constexpr int NST = PIPE ? 4 : 3;  // ring depth
     static constexpr int NWAVES = WR * WC;
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int TBN = 32 * MI * WR;       // channels per block
@@ -212,11 +220,12 @@ struct TileGeom {
     static_assert(TBM % (16 * NWAVES) == 0 && TBN % (16 * NWAVES) == 0, "DMA rows must divide evenly");
 };
 
-template <bool kI8, int EPI, int MI, int WR, int WC, bool kUniformTap>
+template <bool kI8, int EPI, int MI, int WR, int WC, bool kUniformTap, bool PIPE>
 __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs a)
 {
-    using G = TileGeom<MI, WR, WC>;
+    using G = TileGeom<MI, WR, WC, PIPE>;
     constexpr int ESIZE = kI8 ? 1 : 2;
+    constexpr int NST = G::NST;
     constexpr int LA = NST - 1;  // look-ahead in K steps
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -377,12 +386,13 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
         // every wave's pieces landed, and every wave has finished reading the stage of step-1,
         // which is the one refilled below
         __builtin_amdgcn_s_barrier();
-        if (step + LA < nsteps) {
+        if (step + LA < nsteps && !(a.debug & 4)) {
             prepare();
 #pragma unroll
             for (int d = 0; d < G::PER_STAGE; ++d) glds16(src[d], dst_of(nstage, d));
         }
         const char *sb = smem + stage * G::STAGE_B;
+        if (a.debug & 8) return;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             v4i fa[MI], fb[2];
@@ -396,10 +406,73 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma<kI8>(fa[i], fb[j], acc[i][j]);
         }
     };
-    for (int step = 0; step < nsteps; step += NST) {
-        body(std::integral_constant<int, 0>{}, step);
-        if (step + 1 < nsteps) body(std::integral_constant<int, 1>{}, step + 1);
-        if (step + 2 < nsteps) body(std::integral_constant<int, 2>{}, step + 2);
+    // ---- software-pipelined form ---------------------------------------------------------
+    v4i fa0[MI], fb0[2], fa1[MI], fb1[2];  // fragments of kk = 0 / kk = 1 (PIPE only)
+    auto read_frags = [&](int stage, int kk, v4i (&fa)[MI], v4i (&fb)[2]) {
+        const char *sb = smem + stage * G::STAGE_B;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const v4i *>(sb + offA[i][kk]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i *>(sb + offB[j][kk]);
+    };
+    auto mfma_group = [&](const v4i (&fa)[MI], const v4i (&fb)[2]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma<kI8>(fa[i], fb[j], acc[i][j]);
+    };
+    auto pipe_body = [&](auto stage_c, int step) {
+        constexpr int stage = decltype(stage_c)::value;
+        constexpr int next = (stage + 1) % NST;
+        constexpr int refill = (stage + LA) % NST;  // == (stage - 1) mod NST: the stage of step-1
+        // certify stage step+1: of the stages issued so far only step+2 may still be in flight
+        if (step + 2 < nsteps) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (step + LA < nsteps && !(a.debug & 4)) {
+            prepare();
+#pragma unroll
+            for (int d = 0; d < G::PER_STAGE; ++d) glds16(src[d], dst_of(refill, d));
+        }
+        if (a.debug & 8) return;
+        read_frags(stage, 1, fa1, fb1);
+        mfma_group(fa0, fb0);
+        if (step + 1 < nsteps) read_frags(next, 0, fa0, fb0);
+        mfma_group(fa1, fb1);
+    };
+
+    if constexpr (PIPE) {
+        // certify stage 0 (tables included), publish the tables, fetch the first fragments
+        if (nsteps > 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PER_STAGE) : "memory");
+        } else if (nsteps == 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (tid < G::TBN) {
+            reinterpret_cast<int32_t *>(smem + G::TAB_OFF)[tid] = t_acc;
+            reinterpret_cast<float *>(smem + G::TAB_OFF)[G::TBN + tid] = t_mult;
+            reinterpret_cast<float *>(smem + G::TAB_OFF)[2 * G::TBN + tid] = t_bias;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, 0, fa0, fb0);
+        for (int step = 0; step < nsteps; step += NST) {
+            pipe_body(std::integral_constant<int, 0>{}, step);
+            if (step + 1 < nsteps) pipe_body(std::integral_constant<int, 1>{}, step + 1);
+            if (step + 2 < nsteps) pipe_body(std::integral_constant<int, 2>{}, step + 2);
+            if (step + 3 < nsteps) pipe_body(std::integral_constant<int, 3 % NST>{}, step + 3);
+        }
+    } else {
+        for (int step = 0; step < nsteps; step += NST) {
+            body(std::integral_constant<int, 0>{}, step);
+            if (step + 1 < nsteps) body(std::integral_constant<int, 1>{}, step + 1);
+            if (step + 2 < nsteps) body(std::integral_constant<int, 2>{}, step + 2);
+        }
     }
     if (a.debug & 2) return;
 
@@ -741,6 +814,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     size_t lds = 0;
     int threads = 256;
     int kind;  // 0 wave, 1 regs, 2 tile
+    bool pipe = false;
     // tile flavours (see the kernel header); uniform-tap addressing when a K step stays in a tap
     const bool utap = (a.C * esize) % 64 == 0 && a.Kh * a.Kw <= 32;
     enum { T128, T256x64, T256x128, T256x256 } tile = T128;
@@ -762,6 +836,10 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         } else if (utap && m256 * ((a.Co + 127) / 128) >= 2048) {
             tile = T256x128;
         }
+        // The software-pipelined form measured equal or slower than the plain 3-stage ring on the
+        // ResNet-50 3x3 set (profiles/r01_notes.md): kept as an A/B switch, off by default.
+        static const char *pipe_env = getenv("SHL_MI355X_PIPE");
+        pipe = pipe_env && pipe_env[0] == '1';
         static const char *tile_env = getenv("SHL_MI355X_TILE");  // A/B override
         if (tile_env) {
             if (!strcmp(tile_env, "128")) tile = T128;
@@ -771,10 +849,10 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         }
         int tbm = 128, tbn = 128;
         switch (tile) {
-            case T256x64: tbm = 256; tbn = 64; lds = TileGeom<2, 1, 4>::LDS_B; break;
-            case T256x128: tbm = 256; tbn = 128; lds = TileGeom<4, 1, 4>::LDS_B; break;
-            case T256x256: tbm = 256; tbn = 256; lds = TileGeom<4, 2, 4>::LDS_B; threads = 512; break;
-            default: lds = TileGeom<2, 2, 2>::LDS_B; break;
+            case T256x64: tbm = 256; tbn = 64; lds = pipe ? TileGeom<2, 1, 4, true>::LDS_B : TileGeom<2, 1, 4, false>::LDS_B; break;
+            case T256x128: tbm = 256; tbn = 128; lds = TileGeom<4, 1, 4, false>::LDS_B; pipe = false; break;
+            case T256x256: tbm = 256; tbn = 256; lds = TileGeom<4, 2, 4, false>::LDS_B; threads = 512; pipe = false; break;
+            default: lds = pipe ? TileGeom<2, 2, 2, true>::LDS_B : TileGeom<2, 2, 2, false>::LDS_B; break;
         }
         grid = dim3((unsigned)(((a.M + tbm - 1) / tbm) * ((a.Co + tbn - 1) / tbn)));
     }
@@ -789,23 +867,26 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         default: SHL_LAUNCH(KERNEL<true, 5 __VA_ARGS__>); break;      \
     }
 #define SHL_COMMA ,
-#define SHL_TILE(MI, WRV, WCV, UT)                                                                          \
-    if (i8) { SHL_LAUNCH_EPI(conv_igemm_tile_kernel, SHL_COMMA MI SHL_COMMA WRV SHL_COMMA WCV SHL_COMMA UT) } \
-    else { SHL_LAUNCH(conv_igemm_tile_kernel<false, 0, MI, WRV, WCV, UT>); }
+#define SHL_TILE_P(MI, WRV, WCV, UT, PP)                                                                              \
+    if (i8) { SHL_LAUNCH_EPI(conv_igemm_tile_kernel, SHL_COMMA MI SHL_COMMA WRV SHL_COMMA WCV SHL_COMMA UT SHL_COMMA PP) } \
+    else { SHL_LAUNCH(conv_igemm_tile_kernel<false, 0, MI, WRV, WCV, UT, PP>); }
+#define SHL_TILE(MI, WRV, WCV, UT) \
+    if (pipe) { SHL_TILE_P(MI, WRV, WCV, UT, true) } else { SHL_TILE_P(MI, WRV, WCV, UT, false) }
     if (kind == 0) {
         if (i8) { SHL_LAUNCH_EPI(conv_igemm_wave_kernel) } else { SHL_LAUNCH(conv_igemm_wave_kernel<false, 0>); }
     } else if (kind == 1) {
         if (i8) { SHL_LAUNCH_EPI(conv_igemm_regs_kernel) } else { SHL_LAUNCH(conv_igemm_regs_kernel<false, 0>); }
     } else if (tile == T256x256) {
-        SHL_TILE(4, 2, 4, true)
+        SHL_TILE_P(4, 2, 4, true, false)
     } else if (tile == T256x128) {
-        SHL_TILE(4, 1, 4, true)
+        SHL_TILE_P(4, 1, 4, true, false)
     } else if (tile == T256x64) {
         if (utap) { SHL_TILE(2, 1, 4, true) } else { SHL_TILE(2, 1, 4, false) }
     } else {
         if (utap) { SHL_TILE(2, 2, 2, true) } else { SHL_TILE(2, 2, 2, false) }
     }
 #undef SHL_TILE
+#undef SHL_TILE_P
 #undef SHL_COMMA
 #undef SHL_LAUNCH_EPI
 #undef SHL_LAUNCH
