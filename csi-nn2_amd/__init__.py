@@ -33,7 +33,7 @@ OP_DEPTHWISE_CONV2D, OP_FULLYCONNECTED = 35, 71
 SHL_NHWC, SHL_NCHW = 0, 1
 SHL_I8, SHL_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
-ALGO_AUTO, ALGO_DIRECT, ALGO_IGEMM, ALGO_DW, ALGO_GEMV = 0, 1, 2, 3, 4
+ALGO_AUTO, ALGO_DIRECT, ALGO_IGEMM, ALGO_DW, ALGO_GEMV, ALGO_STEM = 0, 1, 2, 3, 4, 5
 
 
 class MI355XError(RuntimeError):

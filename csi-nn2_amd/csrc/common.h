@@ -191,6 +191,10 @@ int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 bool igemm_supports(const shl_mi355x_conv_desc &d);
 const char *igemm_variant(int64_t M, int64_t Co);  // "tile" | "regs" | "wave"
 bool dwconv_supports(const shl_mi355x_conv_desc &d);
+bool stem_supports(const shl_mi355x_conv_desc &d);
+void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
+size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);
+int launch_conv_stem(const ConvArgs &a, hipStream_t s);
 // [N][R][S] -> [N][S][R] for 1- or 2-byte elements (layout.hip)
 int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s);
 

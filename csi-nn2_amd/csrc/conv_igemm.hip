@@ -655,21 +655,29 @@ __global__ __launch_bounds__(256) void conv_igemm_regs_kernel(ConvArgs a)
 }
 
 // =================================================================================================
-// conv_igemm_wave_kernel: one 32x32 tile per wave, fragments straight from global memory
+// conv_igemm_wave_kernel: 32x32 output tiles, MFMA fragments straight from global memory.
+//   KS = 1  one tile per wave (4 tiles per block); the 4 waves of a block share their pixel rows
+//   KS = 4  one tile per BLOCK: the 4 waves split K four ways and reduce through LDS.  For layers
+//           with fewer tiles than CUs and a deep K (MobileNetV1 tail at batch 1: 64-112 tiles,
+//           K = 512-1024) this turns 4 dependent memory round trips into 1 and occupies 4x the CUs.
+// Every wave keeps two groups of WU K sub-steps (32 B each) in flight.  The wave index is read with
+// readfirstlane so that every K-loop bound is an SGPR: MFMA ignores EXEC, so control flow around it
+// must be scalar (a VGPR-derived trip count produced wrong sums for K ranges > 2*WU sub-steps).
 // =================================================================================================
-constexpr int WU = 4;  // K sub-steps (32 B each) per pipeline group
+constexpr int WU = 8;  // K sub-steps per pipeline group: 2 x 8 x 2 x 16 B = 512 B per lane in flight
 
-template <bool kI8, int EPI>
+template <bool kI8, int EPI, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
 {
     constexpr int ESIZE = kI8 ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) int32_t red[KS == 4 ? 3 * 16 * 64 : 1];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: scalar K-loop control
     const int n_tiles = (a.Co + 31) / 32;
     const int m_tiles = (a.M + 31) / 32;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= n_tiles * m_tiles) return;  // wave-uniform: there are no barriers in this kernel
-    const int tn = tile % n_tiles;           // the 4 waves of a block share their pixels (L1 reuse)
+    const int tile = KS == 4 ? blockIdx.x : blockIdx.x * 4 + wave;
+    if (tile >= n_tiles * m_tiles) return;  // KS == 1: wave-uniform and barrier-free; KS == 4: never
+    const int tn = tile % n_tiles;
     const int tm = tile / n_tiles;
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
@@ -679,20 +687,29 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
     const int ch0 = tn * 32 + 4 * fhalf;
     int4 ai[4];
     float4 mu[4], bi[4];
+    if (KS == 1 || wave == 0) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        ai[g] = *reinterpret_cast<const int4 *>(a.acc_init + ch0 + 8 * g);
-        mu[g] = *reinterpret_cast<const float4 *>(a.mult + ch0 + 8 * g);
-        bi[g] = *reinterpret_cast<const float4 *>(a.bias + ch0 + 8 * g);
+        for (int g = 0; g < 4; ++g) {
+            ai[g] = *reinterpret_cast<const int4 *>(a.acc_init + ch0 + 8 * g);
+            mu[g] = *reinterpret_cast<const float4 *>(a.mult + ch0 + 8 * g);
+            bi[g] = *reinterpret_cast<const float4 *>(a.bias + ch0 + 8 * g);
+        }
     }
 
     const PixelRow row = make_row<ESIZE>(a, tm * 32 + frow);
     int oc = tn * 32 + frow;
     oc = oc < a.Co ? oc : a.Co - 1;
-    const char *wp = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16;
+    const int nsub_all = a.kstride / 32;  // kstride is a multiple of 64 -> even
+    int sub0 = 0, nsub = nsub_all;        // this wave's range of K sub-steps
+    if (KS == 4) {
+        const int per = (nsub_all + 3) / 4;
+        sub0 = wave * per;
+        nsub = nsub_all - sub0 < per ? nsub_all - sub0 : per;
+        if (nsub < 0) nsub = 0;
+    }
+    const char *wp = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16 + (int64_t)sub0 * 32;
     KCursor kc;
-    kc.init(a, fhalf);  // sub-step s uses chunks 2s (lanes 0-31) and 2s+1 (lanes 32-63)
-    const int nsub = a.kstride / 32;  // kstride is a multiple of 64 -> even
+    kc.init(a, fhalf + 2 * sub0);  // sub-step s uses chunks 2s (lanes 0-31) and 2s+1 (lanes 32-63)
 
     using acc_t = typename AccT<kI8>::type;
     acc_t acc;
@@ -722,6 +739,30 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
             if (s0 + WU + u < nsub) acc = mfma<kI8>(fa1[u], fb1[u], acc);
     }
 #undef SHL_LOAD_GROUP
+
+    if constexpr (KS == 4) {
+        // waves 1..3 hand their partial sums to wave 0 (register r of lane l at [w-1][r][l])
+        if (wave != 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (kI8)
+                    red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+                else
+                    red[((wave - 1) * 16 + r) * 64 + lane] = __float_as_int(acc[r]);
+            }
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (kI8)
+                    acc[r] += red[(w * 16 + r) * 64 + lane];
+                else
+                    acc[r] += __int_as_float(red[(w * 16 + r) * 64 + lane]);
+            }
+    }
 
     // ---- epilogue from registers
     const int p = tm * 32 + frow;
@@ -818,9 +859,14 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     // tile flavours (see the kernel header); uniform-tap addressing when a K step stays in a tap
     const bool utap = (a.C * esize) % 64 == 0 && a.Kh * a.Kw <= 32;
     enum { T128, T256x64, T256x128, T256x256 } tile = T128;
+    bool splitk = false;
     if (!strcmp(v, "wave")) {
         const int64_t tiles = (int64_t)((a.M + 31) / 32) * ((a.Co + 31) / 32);
-        grid = dim3((unsigned)((tiles + 3) / 4));
+        // fewer tiles than CUs and at least 8 sub-steps of K: one tile per block, K split 4 ways
+        splitk = tiles <= 256 && a.kstride >= 256;
+        static const char *ks_env = getenv("SHL_MI355X_SPLITK");  // A/B override
+        if (ks_env) splitk = ks_env[0] == '1' && a.kstride >= 128;
+        grid = dim3((unsigned)(splitk ? tiles : (tiles + 3) / 4));
         kind = 0;
     } else if (!strcmp(v, "regs")) {
         grid = dim3((unsigned)(((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN)));
@@ -873,7 +919,11 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
 #define SHL_TILE(MI, WRV, WCV, UT) \
     if (pipe) { SHL_TILE_P(MI, WRV, WCV, UT, true) } else { SHL_TILE_P(MI, WRV, WCV, UT, false) }
     if (kind == 0) {
-        if (i8) { SHL_LAUNCH_EPI(conv_igemm_wave_kernel) } else { SHL_LAUNCH(conv_igemm_wave_kernel<false, 0>); }
+        if (splitk) {
+            if (i8) { SHL_LAUNCH_EPI(conv_igemm_wave_kernel, SHL_COMMA 4) } else { SHL_LAUNCH(conv_igemm_wave_kernel<false, 0, 4>); }
+        } else {
+            if (i8) { SHL_LAUNCH_EPI(conv_igemm_wave_kernel, SHL_COMMA 1) } else { SHL_LAUNCH(conv_igemm_wave_kernel<false, 0, 1>); }
+        }
     } else if (kind == 1) {
         if (i8) { SHL_LAUNCH_EPI(conv_igemm_regs_kernel) } else { SHL_LAUNCH(conv_igemm_regs_kernel<false, 0>); }
     } else if (tile == T256x256) {

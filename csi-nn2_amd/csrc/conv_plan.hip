@@ -102,6 +102,7 @@ static int choose_algo(const shl_mi355x_conv_desc &d)
 {
     if (is_depthwise(d)) return dwconv_supports(d) ? SHL_MI355X_ALGO_DW : SHL_MI355X_ALGO_DIRECT;
     if (d.group != 1) return -1;  // grouped convolution: SURVEY 8f3
+    if (stem_supports(d)) return SHL_MI355X_ALGO_STEM;
     return igemm_supports(d) ? SHL_MI355X_ALGO_IGEMM : SHL_MI355X_ALGO_DIRECT;
 }
 
@@ -166,7 +167,12 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         set_error("conv_plan_create: DW kernel needs NHWC, multiplier 1 and C %% 4 == 0");
         return SHL_MI355X_ENOTSUP;
     }
-    if (algo != SHL_MI355X_ALGO_IGEMM && algo != SHL_MI355X_ALGO_DW && algo != SHL_MI355X_ALGO_DIRECT) {
+    if (algo == SHL_MI355X_ALGO_STEM && !stem_supports(d)) {
+        set_error("conv_plan_create: STEM kernel needs int8 NHWC 3x3 with 3 input channels, Cout <= 64");
+        return SHL_MI355X_ENOTSUP;
+    }
+    if (algo != SHL_MI355X_ALGO_IGEMM && algo != SHL_MI355X_ALGO_DW && algo != SHL_MI355X_ALGO_DIRECT &&
+        algo != SHL_MI355X_ALGO_STEM) {
         set_error("conv_plan_create: unknown algorithm %d", algo);
         return SHL_MI355X_EINVAL;
     }
@@ -193,6 +199,9 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             p->kernel_name = i8 ? "conv_igemm_regs_i8_mfma32x32x32" : "conv_igemm_regs_f16_mfma32x32x16";
         else
             p->kernel_name = i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
+    } else if (algo == SHL_MI355X_ALGO_STEM) {
+        w_bytes = stem_weight_bytes(d);
+        p->kernel_name = "conv_stem_i8_dot4";
     } else if (algo == SHL_MI355X_ALGO_DW) {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "dwconv_nhwc_i8" : "dwconv_nhwc_f16";
     } else {
@@ -227,6 +236,9 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         const char *src = static_cast<const char *>(kernel_host);
         if (algo == SHL_MI355X_ALGO_IGEMM)
             pack_igemm(d, src, host.data() + p->off_w, p->kstride);
+        else if (algo == SHL_MI355X_ALGO_STEM)
+            stem_pack_weights(d, reinterpret_cast<const int8_t *>(src),
+                              reinterpret_cast<int32_t *>(host.data() + p->off_w));
         else
             memcpy(host.data() + p->off_w, src, raw_w);
         int32_t *acc = reinterpret_cast<int32_t *>(host.data() + p->off_acc);
@@ -236,6 +248,15 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             mult[oc] = mult_host ? mult_host[oc] : 1.0f;
             bias[oc] = bias_host ? bias_host[oc] : 0.0f;
             acc[oc] = 0;
+        }
+        if (algo == SHL_MI355X_ALGO_STEM) {
+            // padding is materialised as zp_in here too
+            const int8_t *w8 = reinterpret_cast<const int8_t *>(src);
+            for (int oc = 0; oc < d.out_c; ++oc) {
+                int64_t sum = 0;
+                for (int k = 0; k < 27; ++k) sum += w8[oc * 27 + k];
+                acc[oc] = (int32_t)(-(int64_t)d.in_zp * sum);
+            }
         }
         if (algo == SHL_MI355X_ALGO_IGEMM && d.dtype == SHL_MI355X_I8) {
             // padding is materialised as zp_in, so sum(q*w) carries zp_in*sum(w) for EVERY tap
@@ -382,6 +403,8 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
         }
         case SHL_MI355X_ALGO_DW:
             return launch_dwconv(a, d.dtype, d.layout, s);
+        case SHL_MI355X_ALGO_STEM:
+            return launch_conv_stem(a, s);
         default:
             return launch_conv_direct(a, d.dtype, d.layout,
                                       is_depthwise(d) && d.layout == SHL_MI355X_NHWC, s);

@@ -61,7 +61,8 @@ enum shl_mi355x_algo {
     SHL_MI355X_ALGO_DIRECT = 1, /* one thread per output, any shape (VALU) */
     SHL_MI355X_ALGO_IGEMM = 2,  /* LDS-staged implicit GEMM on MFMA */
     SHL_MI355X_ALGO_DW = 3,     /* bandwidth-tuned depthwise kernel */
-    SHL_MI355X_ALGO_GEMV = 4    /* fullyconnected, small batch */
+    SHL_MI355X_ALGO_GEMV = 4,   /* fullyconnected, small batch (reserved) */
+    SHL_MI355X_ALGO_STEM = 5    /* 3x3 conv with 3 input channels (image stem), v_dot4 */
 };
 
 /* ------------------------------------------------------------------------------------

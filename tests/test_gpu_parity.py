@@ -83,6 +83,11 @@ SHAPES = [
     dict(fc=True, n=5, c=33, co=7), dict(act=1, c=32, co=32), dict(act=2, c=32, co=32),
     dict(per_channel=True, c=32, co=40), dict(fuse_zp2bias=True, c=32, co=32), dict(has_bias=False, c=32, co=32),
     dict(depthwise=True, act=1, per_channel=True, c=16), dict(depthwise=True, fuse_zp2bias=True, c=16),
+    # stem kernel (3x3, Cin = 3): strides, padding variants, Cout 24 / 32 / 40 / 64, activations
+    dict(c=3, co=32, h=33, w=31, stride=(2, 2), act=1), dict(c=3, co=64, h=20, w=20, per_channel=True),
+    dict(c=3, co=24, h=9, w=9, pad=(0, 2, 1, 0), n=2), dict(c=3, co=40, h=12, w=12, dilation=(2, 2), pad=(2, 2, 2, 2), act=2),
+    # split-K wave kernel edges: K not divisible by 4 sub-step groups, tiny M
+    dict(c=1024, co=96, k=(1, 1), pad=(0, 0, 0, 0), h=5, w=5), dict(c=256, co=16, h=6, w=6), dict(c=2048, co=40, k=(1, 1), pad=(0, 0, 0, 0), h=4, w=4), dict(c=208, co=64, h=6, w=6), dict(c=144, co=32, k=(1, 1), pad=(0, 0, 0, 0), h=3, w=3),
 ]
 
 
