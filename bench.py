@@ -57,6 +57,10 @@ def parse_args():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--detail", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--steps-only", action="store_true",
+                    help="run warmup + timed steps and stop (for rocprofv3 --pmc passes: only step launches are seen)")
+    ap.add_argument("--traffic-file", default="",
+                    help="JSON from tools/pmc_traffic.py (default profiles/traffic_<workload>_<dtype>_<layout>_b<batch>.json)")
     return ap.parse_args()
 
 
@@ -188,6 +192,21 @@ def summarise_kernels(chain, wl, per_layer_s, bound_hint):
     return roof, groups
 
 
+def attach_traffic(roof, path):
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (tools/pmc_traffic.py over two `rocprofv3 --pmc` runs of `bench.py --steps-only`); null when the
+    file is absent.  Counters cannot be collected from inside the timed process."""
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(roof["kernel"])
+    except (OSError, ValueError):
+        rec = None
+    if rec:
+        roof["traffic"] = rec["hbm_bytes_per_launch"]
+        roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s" % os.path.relpath(
+            path, os.path.dirname(os.path.abspath(__file__)))
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_worker:
@@ -269,11 +288,22 @@ def main():
                    "device": arch.value.decode(), "compute_units": cus.value},
     }
 
+    if args.steps_only:
+        if rank == 0:
+            print(json.dumps(result))
+        chain.release()
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if rank == 0:
         per_layer = time_groups(chain, hip, opt, stream)
         roof, groups = summarise_kernels(chain, wl, per_layer, bound)
         roof["mfma_frac_info"] = (chain.total_ops() / sum(per_layer) / 1e12) / (
             I8_MFMA_PEAK_TOPS if args.dtype == "int8" else F16_MFMA_PEAK_TFLOPS)
+        attach_traffic(roof, args.traffic_file or os.path.join(
+            os.path.dirname(os.path.abspath(__file__)), "profiles",
+            "traffic_%s_%s_%s_b%d.json" % (args.workload, args.dtype, layout, batch)))
         result["roofline"] = roof
         result["kernels"] = {k: {"launches": v["launches"], "us_total": v["time"] * 1e6,
                                  "GBps": v["bytes"] / v["time"] / 1e9, "TOPs": v["ops"] / v["time"] / 1e12}
