@@ -40,15 +40,27 @@ def _glob(d, exts):
 
 
 def build_hip(force=False):
+    """One object per .hip file (compiled in parallel, rebuilt only when stale), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     src = _glob(os.path.join(HERE, "csrc"), (".hip",))
-    deps = src + _glob(os.path.join(HERE, "csrc"), (".h",)) + [os.path.join(INC, "shl_mi355x.h")]
+    hdrs = _glob(os.path.join(HERE, "csrc"), (".h",)) + [os.path.join(INC, "shl_mi355x.h")]
     out = os.path.join(LIB, "libshl_mi355x.so")
-    if not force and not _newer(out, deps):
-        return out
+    objdir = os.path.join(LIB, "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-          "-fno-gpu-rdc", "-ffp-contract=off", "-I" + INC, "-I" + os.path.join(HERE, "csrc")]
-         + src + ["-o", out])
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off",
+             "-I" + INC, "-I" + os.path.join(HERE, "csrc")]
+    objs, stale = [], []
+    for f in src:
+        o = os.path.join(objdir, os.path.basename(f)[:-4] + ".o")
+        objs.append(o)
+        if force or _newer(o, [f] + hdrs):
+            stale.append((f, o))
+    if stale:
+        with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 4)) as pool:
+            list(pool.map(lambda fo: _run([hipcc] + flags + ["-c", fo[0], "-o", fo[1]]), stale))
+    if stale or force or _newer(out, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", out])
     return out
 
 

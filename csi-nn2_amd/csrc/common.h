@@ -54,6 +54,8 @@ struct ConvArgs {
     float clamp_hi;       //   r = rint(f / s_out) + zp_out before the conversion to int8
     int32_t debug;        // ablation switches for tools/kbench.py (SHL_MI355X_DEBUG): 1 skip K loop, 2 skip stores
     const void *pad_page; // PAD_PAGE_BYTES of HBM filled with the padding value (zp_in / 0)
+    int32_t halo_px;      // halo kernel: capacity of one LDS patch buffer in pixels (multiple of 16)
+    int32_t halo_pps;     // halo kernel: patch pieces a producer wave requests per K step
 };
 
 // The pad page is 4 KiB so that concurrent readers can be spread over 32 cache lines instead of

@@ -40,30 +40,12 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "igemm_common.h"
 
 namespace shl {
 
 constexpr int BM = 128;   // pixels per block
 constexpr int BN = 128;   // output channels per block
-constexpr int BKB = 64;   // K bytes per step
-
-template <bool kI8>
-struct AccT {
-    using type = typename std::conditional<kI8, v16i, v16f>::type;
-};
-
-template <bool kI8>
-__device__ __forceinline__ typename AccT<kI8>::type mfma(const v4i &a, const v4i &b,
-                                                         typename AccT<kI8>::type c)
-{
-    if constexpr (kI8) {
-        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
-    } else {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a),
-                                                      __builtin_bit_cast(v8h, b), c, 0, 0, 0);
-    }
-}
 
 // ---- receptive-field bookkeeping shared by all loaders ----------------------------------------
 struct PixelRow {
@@ -194,18 +176,11 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const Acc &acc, in
 //                 barrier + LDS latency + MFMA in series (600-700 cycles measured with one wave
 //                 per SIMD, profiles/r01_notes.md).
 
-__device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
-{
-    // 64 lanes x 16 B -> LDS[base + lane*16]; the destination is wave-uniform by construction
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
 template <int MI, int WR, int WC, bool PIPE>
 struct TileGeom {
     static constexpr int NST = PIPE ? 4 : 3;  // ring depth
-    static constexpr int NWAVES = WR * WC;
-    static constexpr int THREADS = 64 * NWAVES;
+    static constexpr int NWAVES = WR * WC;     // MFMA waves (PIPE adds as many DMA waves)
+    static constexpr int THREADS = 64 * NWAVES * (PIPE ? 2 : 1);
     static constexpr int TBN = 32 * MI * WR;       // channels per block
     static constexpr int TBM = 64 * WC;            // pixels per block
     static constexpr int ACT_B = TBM * BKB;        // activation tile bytes per stage
@@ -221,7 +196,7 @@ struct TileGeom {
 };
 
 template <bool kI8, int EPI, int MI, int WR, int WC, bool kUniformTap, bool PIPE>
-__global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs a)
+__global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile_kernel(ConvArgs a)
 {
     using G = TileGeom<MI, WR, WC, PIPE>;
     constexpr int ESIZE = kI8 ? 1 : 2;
@@ -250,6 +225,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
     // ---- DMA role.  Wave w fills NA*16 rows of the activation tile and NW*16 rows of the weight
     // tile, 16 rows x 4 chunk slots per instruction.  LDS position (row r, slot s) receives global
     // chunk s ^ ((r >> 2) & 3) of that row.
+    const int dwave = PIPE ? wave % G::NWAVES : wave;  // DMA role index (PIPE: waves NWAVES.. are the producers)
     const int drow = lane >> 2;
     const int dslot = lane & 3;
     PixelRow arow[G::NA];
@@ -258,7 +234,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
     const char *wptr[G::NW];
 #pragma unroll
     for (int j = 0; j < G::NA; ++j) {
-        const int r = (wave * G::NA + j) * 16 + drow;
+        const int r = (dwave * G::NA + j) * 16 + drow;
         const int chunk = dslot ^ ((r >> 2) & 3);
         arow[j] = make_row<ESIZE>(a, pix0 + r);
         if constexpr (kUniformTap) {
@@ -277,7 +253,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
     }
 #pragma unroll
     for (int j = 0; j < G::NW; ++j) {
-        const int r = (wave * G::NW + j) * 16 + drow;
+        const int r = (dwave * G::NW + j) * 16 + drow;
         int oc = co0 + r;
         oc = oc < a.Co ? oc : a.Co - 1;
         wptr[j] = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + (dslot ^ ((r >> 2) & 3)) * 16;
@@ -321,8 +297,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
     };
     // LDS destination of piece d of a stage (wave-uniform)
     auto dst_of = [&](int stage, int d) -> char * {
-        if (d < G::NA) return smem + stage * G::STAGE_B + (wave * G::NA + d) * 16 * BKB;
-        return smem + stage * G::STAGE_B + G::ACT_B + (wave * G::NW + (d - G::NA)) * 16 * BKB;
+        if (d < G::NA) return smem + stage * G::STAGE_B + (dwave * G::NA + d) * 16 * BKB;
+        return smem + stage * G::STAGE_B + G::ACT_B + (dwave * G::NW + (d - G::NA)) * 16 * BKB;
     };
 
     // ---- compute role: wave (wr, wc) owns channels [32*MI*wr, +32*MI) x pixels [64wc, +64)
@@ -354,10 +330,10 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-    // prologue: fill the ring
+    // prologue: fill the ring (PIPE: the producer waves do)
 #pragma unroll
     for (int st = 0; st < LA; ++st) {
-        if (st < nsteps) {
+        if (st < nsteps && (!PIPE || wave >= G::NWAVES)) {
             prepare();
 #pragma unroll
             for (int d = 0; d < G::PER_STAGE; ++d) glds16(src[d], dst_of(st, d));
@@ -408,12 +384,13 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
     };
     // ---- software-pipelined form ---------------------------------------------------------
     v4i fa0[MI], fb0[2], fa1[MI], fb1[2];  // fragments of kk = 0 / kk = 1 (PIPE only)
-    auto read_frags = [&](int stage, int kk, v4i (&fa)[MI], v4i (&fb)[2]) {
-        const char *sb = smem + stage * G::STAGE_B;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    auto read_frags = [&](auto stage_c, auto kk_c, v4i (&fa)[MI], v4i (&fb)[2]) {
+        constexpr int st = decltype(stage_c)::value, kk = decltype(kk_c)::value;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const v4i *>(sb + offA[i][kk]);
+        for (int i = 0; i < MI; ++i) lds_read128_async<st * G::STAGE_B>(fa[i], lds0 + offA[i][kk]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i *>(sb + offB[j][kk]);
+        for (int j = 0; j < 2; ++j) lds_read128_async<st * G::STAGE_B>(fb[j], lds0 + offB[j][kk]);
     };
     auto mfma_group = [&](const v4i (&fa)[MI], const v4i (&fb)[2]) {
 #pragma unroll
@@ -421,52 +398,72 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = mfma<kI8>(fa[i], fb[j], acc[i][j]);
     };
+    // consumer step of the specialised form: no VMEM, one barrier, MI+2 LDS reads always in flight
     auto pipe_body = [&](auto stage_c, int step) {
         constexpr int stage = decltype(stage_c)::value;
         constexpr int next = (stage + 1) % NST;
-        constexpr int refill = (stage + LA) % NST;  // == (stage - 1) mod NST: the stage of step-1
-        // certify stage step+1: of the stages issued so far only step+2 may still be in flight
-        if (step + 2 < nsteps) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        if (step + LA < nsteps && !(a.debug & 4)) {
-            prepare();
-#pragma unroll
-            for (int d = 0; d < G::PER_STAGE; ++d) glds16(src[d], dst_of(refill, d));
-        }
+        __builtin_amdgcn_s_barrier();  // stage step+1 is complete (the producers waited for it)
         if (a.debug & 8) return;
-        read_frags(stage, 1, fa1, fb1);
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        read_frags(std::integral_constant<int, stage>{}, I1{}, fa1, fb1);
+        lds_wait<MI + 2, MI>(fa0, fb0);
         mfma_group(fa0, fb0);
-        if (step + 1 < nsteps) read_frags(next, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        // unconditional: a stale stage on the last step is harmless (never consumed)
+        read_frags(std::integral_constant<int, next>{}, I0{}, fa0, fb0);
+        lds_wait<MI + 2, MI>(fa1, fb1);
         mfma_group(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
+    const bool staged = ((a.Co * ESIZE) & 15) == 0;  // epilogue flavour (decides its barrier)
     if constexpr (PIPE) {
-        // certify stage 0 (tables included), publish the tables, fetch the first fragments
-        if (nsteps > 2) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PER_STAGE) : "memory");
-        } else if (nsteps == 2) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave >= G::NWAVES) {
+            // ---- producer waves: nothing but DMA issue and counted waits.  Barrier sequence must
+            // mirror the consumers': one before the loop, one per step, one in the staged epilogue.
+            if (nsteps > 2) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PER_STAGE) : "memory");
+            } else if (nsteps == 2) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            for (int step = 0; step < nsteps; ++step) {
+                // certify stage step+1: of the stages issued so far only step+2 may still be in flight
+                if (step + 2 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();  // ... and the consumers are done with stage step-1
+                if (step + LA < nsteps && !(a.debug & 4)) {
+                    prepare();
+                    const int refill = (step + LA) % NST;
+#pragma unroll
+                    for (int d = 0; d < G::PER_STAGE; ++d) glds16(src[d], dst_of(refill, d));
+                }
+            }
+            if (!(a.debug & 2) && staged) __builtin_amdgcn_s_barrier();
+            return;
         }
+        // ---- consumer waves
         if (tid < G::TBN) {
             reinterpret_cast<int32_t *>(smem + G::TAB_OFF)[tid] = t_acc;
             reinterpret_cast<float *>(smem + G::TAB_OFF)[G::TBN + tid] = t_mult;
             reinterpret_cast<float *>(smem + G::TAB_OFF)[2 * G::TBN + tid] = t_bias;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        read_frags(0, 0, fa0, fb0);
+        __builtin_amdgcn_s_barrier();  // stage 0 is complete
+        read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fa0, fb0);
         for (int step = 0; step < nsteps; step += NST) {
             pipe_body(std::integral_constant<int, 0>{}, step);
             if (step + 1 < nsteps) pipe_body(std::integral_constant<int, 1>{}, step + 1);
             if (step + 2 < nsteps) pipe_body(std::integral_constant<int, 2>{}, step + 2);
             if (step + 3 < nsteps) pipe_body(std::integral_constant<int, 3 % NST>{}, step + 3);
         }
+        lds_wait<0, MI>(fa0, fb0);  // the prefetch of the step after the last one
     } else {
         for (int step = 0; step < nsteps; step += NST) {
             body(std::integral_constant<int, 0>{}, step);
@@ -483,7 +480,6 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_tile_kernel(ConvArgs 
     constexpr int ROW_B = 64 * ESIZE;  // one pixel's 64 channels (two MFMA row blocks)
     constexpr int PITCH = ROW_B + 16;  // padded LDS row: spreads the 4-byte writes over banks
     static_assert(G::NWAVES * 64 * PITCH <= NST * G::STAGE_B, "epilogue staging must fit in the ring");
-    const bool staged = ((a.Co * ESIZE) & 15) == 0;
     if (staged) {
         // Stage 64 pixel x 64 channel blocks through LDS (the ring is free now) so that every lane
         // stores 16 contiguous bytes of one pixel: whole 64-byte (int8) / 128-byte (f16) channel
@@ -882,10 +878,6 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         } else if (utap && m256 * ((a.Co + 127) / 128) >= 2048) {
             tile = T256x128;
         }
-        // The software-pipelined form measured equal or slower than the plain 3-stage ring on the
-        // ResNet-50 3x3 set (profiles/r01_notes.md): kept as an A/B switch, off by default.
-        static const char *pipe_env = getenv("SHL_MI355X_PIPE");
-        pipe = pipe_env && pipe_env[0] == '1';
         static const char *tile_env = getenv("SHL_MI355X_TILE");  // A/B override
         if (tile_env) {
             if (!strcmp(tile_env, "128")) tile = T128;
@@ -893,6 +885,10 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
             else if (!strcmp(tile_env, "256x128") && utap) tile = T256x128;
             else if (!strcmp(tile_env, "256x256") && utap) tile = T256x256;
         }
+        // producer/consumer wave specialisation (PIPE): wins on the 128x128 tile (-2..-25 % on the
+        // ResNet-50 3x3 set), loses on 256x64 where its 4-stage ring costs a block of occupancy
+        static const char *pipe_env = getenv("SHL_MI355X_PIPE");
+        pipe = pipe_env ? pipe_env[0] == '1' : (tile == T128);
         int tbm = 128, tbn = 128;
         switch (tile) {
             case T256x64: tbm = 256; tbn = 64; lds = pipe ? TileGeom<2, 1, 4, true>::LDS_B : TileGeom<2, 1, 4, false>::LDS_B; break;
@@ -901,6 +897,17 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
             default: lds = pipe ? TileGeom<2, 2, 2, true>::LDS_B : TileGeom<2, 2, 2, false>::LDS_B; break;
         }
         grid = dim3((unsigned)(((a.M + tbm - 1) / tbm) * ((a.Co + tbn - 1) / tbn)));
+        if (pipe) threads *= 2;  // as many DMA waves as MFMA waves
+        // im2col staged in LDS (conv_igemm_halo.hip) whenever the tile's input patch fits
+        // measured equal or slower than the plain tile kernels on the ResNet-50 set so far
+        // (profiles/r01_notes.md): opt-in with SHL_MI355X_HALO=1
+        static const char *halo_env = getenv("SHL_MI355X_HALO");
+        const bool want_halo = halo_env && halo_env[0] == '1';
+        const int halo_tile = tile == T128 ? 0 : tile == T256x64 ? 1 : tile == T256x128 ? 2 : -1;
+        if (want_halo && halo_tile >= 0 && halo_eligible(a, esize)) {
+            const int rc = launch_conv_igemm_halo(a, dtype, halo_tile, s);
+            if (rc != SHL_MI355X_ENOTSUP) return rc;
+        }
     }
 #define SHL_LAUNCH(...) launch_kernel<__VA_ARGS__>(grid, lds, s, a, threads)
 #define SHL_LAUNCH_EPI(KERNEL, ...)                                   \

@@ -43,16 +43,31 @@ def main():
     chain = wl.LayerChain(fe, hip, opt, layers, a.batch, dev.alloc, dev.upload, dtype=a.dtype, layout=a.layout,
                           chained=False)
     ev0, ev1 = hip.shl_mi355x_event_create(), hip.shl_mi355x_event_create()
+    stream = hip.shl_mi355x_stream_create()
     ms = C.c_float()
     tot_t = tot_ops = 0.0
     for i, e in enumerate(chain.entries):
         chain.run_layer(i)
         hip.shl_mi355x_stream_sync(None)
-        hip.shl_mi355x_event_record(ev0, None)
+        # `reps` launches captured in one hipGraph: no host gaps between them (a direct launch loop
+        # is host-bound once a kernel is shorter than the python -> csinn_* -> launch path)
+        opt.shl_mi355x_set_stream(stream)
+        hip.shl_mi355x_graph_begin(stream)
         for _ in range(a.reps):
             chain.run_layer(i)
-        hip.shl_mi355x_event_record(ev1, None)
-        hip.shl_mi355x_event_elapsed_ms(ev0, ev1, C.byref(ms))
+        g = hip.shl_mi355x_graph_end(stream)
+        hip.shl_mi355x_graph_launch(g, stream)  # warm
+        hip.shl_mi355x_stream_sync(stream)
+        best = []
+        for _ in range(3):
+            hip.shl_mi355x_event_record(ev0, stream)
+            hip.shl_mi355x_graph_launch(g, stream)
+            hip.shl_mi355x_event_record(ev1, stream)
+            hip.shl_mi355x_event_elapsed_ms(ev0, ev1, C.byref(ms))
+            best.append(ms.value)
+        hip.shl_mi355x_graph_destroy(g)
+        opt.shl_mi355x_set_stream(None)
+        ms.value = sorted(best)[1]
         t = ms.value * 1e-3 / a.reps
         L = e["layer"]
         ops, byts = wl.layer_ops(L, a.batch), wl.layer_bytes(L, a.batch, chain.esize)

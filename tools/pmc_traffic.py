@@ -21,6 +21,8 @@ FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kern
     ("conv_igemm_wave_kernel<true", "conv_igemm_wave_i8_mfma32x32x32"),
     ("conv_igemm_wave_kernel<false", "conv_igemm_wave_f16_mfma32x32x16"),
     ("conv_igemm_tile_kernel<true", "conv_igemm_tile_i8_mfma32x32x32"),
+    ("conv_igemm_halo_kernel<true", "conv_igemm_tile_i8_mfma32x32x32"),
+    ("conv_igemm_halo_kernel<false", "conv_igemm_tile_f16_mfma32x32x16"),
     ("conv_igemm_tile_kernel<false", "conv_igemm_tile_f16_mfma32x32x16"),
     ("conv_igemm_regs_kernel<true", "conv_igemm_regs_i8_mfma32x32x32"),
     ("conv_igemm_regs_kernel<false", "conv_igemm_regs_f16_mfma32x32x16"),
