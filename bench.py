@@ -316,15 +316,43 @@ def main():
                     wl.layer_name(L), e["kernel_name"], t * 1e6,
                     wl.layer_bytes(L, batch, chain.esize) / t / 1e9, wl.layer_ops(L, batch) / t / 1e12))
         if args.extra and args.workload == "mobilenetv1":
-            hbm2 = TorchHBM(torch, torch.device("cuda", local_rank))
-            rc = wl.LayerChain(fe, hip, opt, wl.RESNET50_3X3, 128, hbm2.alloc, hbm2.upload, dtype=args.dtype,
-                               layout="NHWC", seed=4321, chained=False)
-            rt = time_groups(rc, hip, opt, stream, reps=3)
-            rroof, _ = summarise_kernels(rc, wl, rt, "mfma")
-            result["extra"] = {"workload": "resnet50 3x3 set int8 NHWC batch 128 (BASELINE configs[2])",
-                               "gops": rc.total_ops() / sum(rt) / 1e9, "ms_per_pass": sum(rt) * 1e3,
-                               "roofline": rroof}
-            rc.release()
+            # the other single-GPU configurations of BASELINE.json, per-layer graph timing (no chaining)
+            extras = [
+                ("resnet50 3x3 set int8 NHWC batch 128 (BASELINE configs[2] shapes, NHWC)", wl.RESNET50_3X3, 128, "int8", "NHWC", "mfma", 3),
+                ("resnet50 3x3 set int8 NCHW batch 128 (BASELINE configs[2])", wl.RESNET50_3X3, 128, "int8", "NCHW", "mfma", 3),
+                ("mobilenetv1 fp16 NCHW batch 1 (BASELINE configs[3], c906_mobilenetv1_f16 shapes)", wl.MOBILENETV1, 1, "f16", "NCHW", "hbm", 20),
+            ]
+            result["extra"] = []
+            for name, layers_x, batch_x, dtype_x, layout_x, bound_x, reps_x in extras:
+                hbm2 = TorchHBM(torch, torch.device("cuda", local_rank))
+                rc = wl.LayerChain(fe, hip, opt, layers_x, batch_x, hbm2.alloc, hbm2.upload, dtype=dtype_x,
+                                   layout=layout_x, seed=4321, chained=False)
+                rt = time_groups(rc, hip, opt, stream, reps=reps_x)
+                rroof, _ = summarise_kernels(rc, wl, rt, bound_x)
+                unit = "GOPS" if dtype_x == "int8" else "GFLOPS"
+                result["extra"].append({"workload": name, unit.lower(): rc.total_ops() / sum(rt) / 1e9,
+                                        "images_per_sec": batch_x / sum(rt), "ms_per_pass": sum(rt) * 1e3,
+                                        "dtype": "u8" if dtype_x == "int8" else "f16", "roofline": rroof})
+                rc.release()
+                del hbm2
+        if args.extra and args.workload == "mobilenetv1":
+            # whole model through csinn_session_run with HOST input / output tensors: H2D + one
+            # hipGraph replay (28 convs + avgpool + softmax) + D2H + sync per image
+            ms = wl.ModelSession(fe, pkg.API_MI355X, args.dtype, layout)
+            mode = opt.shl_mi355x_session_is_device_resident(ms.sess)
+            x = ms.synthetic_input(0)
+            for _ in range(10):
+                ms.run(x)
+            t0 = time.perf_counter()
+            reps = 200
+            for _ in range(reps):
+                ms.run(x)
+            dt_s = (time.perf_counter() - t0) / reps
+            result["end_to_end_session"] = {
+                "workload": "mobilenetv1 %s %s whole model via csinn_session_run, host tensors (PCIe-inclusive)" % (args.dtype, layout),
+                "images_per_sec": 1.0 / dt_s, "ms_per_image": dt_s * 1e3, "layers": ms.n_layers,
+                "device_mode": {0: "host-staged", 1: "device eager", 2: "device hipGraph"}[mode]}
+            ms.close()
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = run_cpu_baseline(args)
         else:

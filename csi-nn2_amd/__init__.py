@@ -108,6 +108,17 @@ class ReluParams(C.Structure):
                 ("n_shift", C.c_int32)]
 
 
+class SoftmaxParams(C.Structure):
+    _fields_ = [("base", ParamsBase), ("axis", C.c_int32)]
+
+
+class PoolParams(C.Structure):
+    _fields_ = [("base", ParamsBase)] + [(n, C.c_int32) for n in (
+        "pool_type", "filter_height", "filter_width", "filter_depth", "stride_height", "stride_width",
+        "stride_depth", "pad_top", "pad_left", "pad_down", "pad_right", "pad_front", "pad_back",
+        "ceil_mode")] + [("count_include_pad", C.c_bool)]
+
+
 class ConvDesc(C.Structure):
     """struct shl_mi355x_conv_desc (include/shl_mi355x.h)"""
     _fields_ = [(n, C.c_int32) for n in (
@@ -120,7 +131,8 @@ class ConvDesc(C.Structure):
 ABI_STRUCTS = {"csinn_quant_info": QuantInfo, "csinn_tensor": Tensor, "csinn_session": Session,
                "csinn_callback": Callback, "csinn_params_base": ParamsBase,
                "csinn_conv2d_params": Conv2dParams, "csinn_fc_params": FcParams,
-               "csinn_relu_params": ReluParams, "csinn_model": Model}
+               "csinn_relu_params": ReluParams, "csinn_model": Model,
+               "csinn_softmax_params": SoftmaxParams, "csinn_pool_params": PoolParams}
 
 
 # ---- library loading -------------------------------------------------------------------------
@@ -181,7 +193,10 @@ def load_hip():
         "shl_mi355x_conv_plan_const_block": (vp, [vp, C.POINTER(sz)]),
         "shl_mi355x_conv_forward": (C.c_int, [vp, vp, vp, i32, vp]),
         "shl_mi355x_relu_i8": (C.c_int, [vp, vp, sz, f32, i32, f32, i32, i32, vp]),
+        "shl_mi355x_relu_f16": (C.c_int, [vp, vp, sz, i32, vp]),
         "shl_mi355x_layout_convert": (C.c_int, [vp, vp, C.c_int64, i32, i32, i32, i32, vp]),
+        "shl_mi355x_global_avgpool2d": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, f32, i32, f32, i32, vp]),
+        "shl_mi355x_softmax": (C.c_int, [vp, vp, i32, C.c_int64, i32, C.c_int64, f32, i32, f32, i32, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -218,8 +233,9 @@ _FRONTEND_SIGS = {
     "shl_mem_free": (None, [C.c_void_p]),
     "shl_debug_set_level": (None, [C.c_int]),
 }
+_SISO_OPS = ("csinn_relu", "csinn_relu6", "csinn_global_avgpool2d", "csinn_softmax")
 _CONV_OPS = ["csinn_conv2d", "csinn_conv2d_relu", "csinn_conv2d_relu6", "csinn_depthwise_conv2d",
-             "csinn_depthwise_conv2d_relu", "csinn_fullyconnected", "csinn_relu", "csinn_relu6"]
+             "csinn_depthwise_conv2d_relu", "csinn_fullyconnected"] + list(_SISO_OPS)
 
 
 def load_frontend(kind="standalone", local=False):
@@ -242,7 +258,7 @@ def load_frontend(kind="standalone", local=False):
         fn.restype, fn.argtypes = res, args
     tp = C.POINTER(Tensor)
     for op in _CONV_OPS:
-        nargs = 3 if op in ("csinn_relu", "csinn_relu6") else 5
+        nargs = 3 if op in _SISO_OPS else 5
         for suffix in ("_init", ""):
             fn = getattr(lib, op + suffix)
             fn.restype = C.c_int
@@ -267,6 +283,7 @@ def load_backend(frontend):
         opt.shl_mi355x_params_const_block.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         opt.shl_mi355x_params_kernel_name.restype = C.c_char_p
         opt.shl_mi355x_params_kernel_name.argtypes = [C.c_void_p]
+        opt.shl_mi355x_session_is_device_resident.argtypes = [C.POINTER(Session)]
         opt._typed = True
     # the dispatch tables exist after the first csinn_alloc_session (source/nn2/setup.c:77-84)
     s = frontend.csinn_alloc_session()
@@ -365,6 +382,23 @@ def fc_params(fe, keep, api, units, fuse_zp2bias=0, sess=None, name=b"fc"):
         pc.base.sess = sess
     pc.units = units
     pc.fc_extra.fuse_zp2bias = fuse_zp2bias
+    return p
+
+
+def siso_params(fe, keep, api, kind, layout=LAYOUT_NHWC, axis=1, sess=None, name=b"siso"):
+    """params block of a single-input single-output op: kind in relu | relu6 | pool | softmax"""
+    ctype = {"relu": ReluParams, "relu6": ReluParams, "pool": PoolParams, "softmax": SoftmaxParams}[kind]
+    p = fe.csinn_alloc_params(C.sizeof(ctype), sess)
+    pc = C.cast(p, C.POINTER(ctype)).contents
+    pc.base.api = api
+    pc.base.layout = layout
+    pc.base.name = keep.add(C.c_char_p(name)).value
+    if sess is not None:
+        pc.base.sess = sess
+    if kind == "softmax":
+        pc.axis = axis
+    if kind == "relu6":
+        pc.n = 6.0
     return p
 
 

@@ -43,7 +43,36 @@ __global__ __launch_bounds__(256) void relu_i8_kernel(const int8_t *in, int8_t *
     }
 }
 
+// binary16: f16 -> f32 (exact), x > 0 ? x : 0, fmin(., 6), f32 -> f16 with the reference rounding
+// (source/reference/relu.c:21-35, relu6.c:21-36 inside shl_ref_siso_callback_base)
+__global__ __launch_bounds__(256) void relu_f16_kernel(const uint16_t *in, uint16_t *out, size_t count, int relu6)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        float x = f16_bits_to_float(in[i]);
+        x = x > 0.0f ? x : 0.0f;
+        if (relu6) x = fminf(x, 6.0f);
+        out[i] = float_to_f16_bits_ref(x);
+    }
+}
+
 }  // namespace shl
+
+extern "C" int shl_mi355x_relu_f16(const uint16_t *input_dev, uint16_t *output_dev, size_t count, int32_t relu6,
+                                   void *stream)
+{
+    if (!input_dev || !output_dev) {
+        shl::set_error("relu_f16: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    if (count == 0) return SHL_MI355X_OK;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(shl::relu_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, input_dev,
+                       output_dev, count, (int)relu6);
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}
 
 extern "C" int shl_mi355x_relu_i8(const int8_t *input_dev, int8_t *output_dev, size_t count,
                                   float in_scale, int32_t in_zp, float out_scale, int32_t out_zp,

@@ -1,0 +1,143 @@
+// pool_softmax.hip -- the MobileNet tail between the last convolution and the classifier output:
+// global average pooling and softmax on quantised int8 / binary16 tensors.
+//
+// Both follow the reference's "dequantise -> fp32 op -> requantise" callbacks
+// (shl_ref_siso_callback_base, source/reference/utils.c:609-621) literally, including the ORDER of
+// the fp32 operations, so that results agree bit for bit with the C reference for any scales:
+//   global_avgpool2d  shl_ref_global_avgpool2d_f32 -> shl_ref_avgpool2d_{nhwc,nchw}_f32
+//                     (global_averagepool.c:21-44, averagepool.c:21-119): total += x in (y, x)
+//                     order in fp32, average = total / count.
+//                     One thread per (image, channel) walks its H*W values in that order; NHWC
+//                     reads are coalesced across the channel threads.  Tiny next to the convolutions
+//                     (MobileNetV1: 50 KB in, 1 KB out).
+//   softmax           shl_ref_softmax_f32 (softmax.c:21-66): max over the axis, then
+//                     acc(float) += exp(double(x - max)) in index order, then
+//                     float(exp(double(x - max)) / acc).  One block per (outer, inner) row: the
+//                     max and the exponentials are computed in parallel (order-independent), the
+//                     float accumulation is replayed sequentially by one lane from LDS.
+#include "common.h"
+
+namespace shl {
+
+__device__ __forceinline__ float load_dequant(const void *in, int64_t idx, int dtype, float si, float zi)
+{
+    if (dtype == SHL_MI355X_I8) {
+        // int8_to_float_base (source/nn2/utils.c:499-502)
+        return __fmul_rn(__fsub_rn((float)static_cast<const int8_t *>(in)[idx], zi), si);
+    }
+    return f16_bits_to_float(static_cast<const uint16_t *>(in)[idx]);
+}
+
+__device__ __forceinline__ void store_requant(void *out, int64_t idx, float v, int dtype, float so, float zo)
+{
+    if (dtype == SHL_MI355X_I8) {
+        // float_to_int8_base (source/nn2/utils.c:550-560)
+        static_cast<int8_t *>(out)[idx] = (int8_t)sat8_from_float(__fadd_rn(rintf(__fdiv_rn(v, so)), zo));
+    } else {
+        static_cast<uint16_t *>(out)[idx] = float_to_f16_bits_ref(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const void *in, void *out, int dtype, int nhwc,
+                                                             int64_t nc, int C, int HW, float si, float zi,
+                                                             float so, float zo)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, c), c fastest
+    if (i >= nc) return;
+    const int64_t n = i / C;
+    const int c = (int)(i - n * C);
+    const int64_t base = nhwc ? n * HW * C + c : (n * C + c) * (int64_t)HW;
+    const int64_t step = nhwc ? C : 1;
+    float total = 0.f;
+    for (int p = 0; p < HW; ++p) total = __fadd_rn(total, load_dequant(in, base + p * step, dtype, si, zi));
+    const float avg = __fdiv_rn(total, (float)HW);
+    store_requant(out, i, avg, dtype, so, zo);  // output is [N, 1, 1, C] / [N, C, 1, 1]: index n*C + c
+}
+
+constexpr int SOFTMAX_MAX_CNT = 8192;  // doubles parked in LDS: 64 KiB
+
+__global__ __launch_bounds__(256) void softmax_kernel(const void *in, void *out, int dtype, int cnt,
+                                                      int64_t inner, float si, float zi, float so, float zo)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *e = reinterpret_cast<double *>(smem);          // [cnt]
+    float *red = reinterpret_cast<float *>(e + cnt);       // [256]
+    const int64_t row = blockIdx.x;                         // outer * inner + k
+    const int64_t o = row / inner, k = row - o * inner;
+    const int64_t base = o * cnt * inner + k;
+    const int tid = threadIdx.x;
+    // max (fmax over floats: exact whatever the order)
+    float m = -3.402823466e+38f;
+    for (int j = tid; j < cnt; j += 256) m = fmaxf(m, load_dequant(in, base + j * inner, dtype, si, zi));
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    for (int j = tid; j < cnt; j += 256)
+        e[j] = exp((double)__fsub_rn(load_dequant(in, base + j * inner, dtype, si, zi), m));
+    __syncthreads();
+    if (tid == 0) {
+        float acc = 0.f;  // `acc_exp += exp(...)`: double add, rounded to float every step
+        for (int j = 0; j < cnt; ++j) acc = (float)((double)acc + e[j]);
+        red[0] = acc;
+    }
+    __syncthreads();
+    const double acc = (double)red[0];
+    for (int j = tid; j < cnt; j += 256) store_requant(out, base + j * inner, (float)(e[j] / acc), dtype, so, zo);
+}
+
+}  // namespace shl
+
+extern "C" int shl_mi355x_global_avgpool2d(const void *input_dev, void *output_dev, int32_t dtype, int32_t layout,
+                                           int32_t batch, int32_t channels, int32_t pixels, float in_scale,
+                                           int32_t in_zp, float out_scale, int32_t out_zp, void *stream)
+{
+    if (!input_dev || !output_dev || batch < 0 || channels <= 0 || pixels <= 0 ||
+        (dtype != SHL_MI355X_I8 && dtype != SHL_MI355X_F16) || (layout != SHL_MI355X_NHWC && layout != SHL_MI355X_NCHW)) {
+        shl::set_error("global_avgpool2d: invalid argument");
+        return SHL_MI355X_EINVAL;
+    }
+    const int64_t nc = (int64_t)batch * channels;
+    if (nc == 0) return SHL_MI355X_OK;
+    hipLaunchKernelGGL(shl::global_avgpool_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       input_dev, output_dev, (int)dtype, layout == SHL_MI355X_NHWC ? 1 : 0, nc, (int)channels,
+                       (int)pixels, in_scale, (float)in_zp, out_scale, (float)out_zp);
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}
+
+extern "C" int shl_mi355x_softmax(const void *input_dev, void *output_dev, int32_t dtype, int64_t outer, int32_t count,
+                                  int64_t inner, float in_scale, int32_t in_zp, float out_scale, int32_t out_zp,
+                                  void *stream)
+{
+    if (!input_dev || !output_dev || outer < 0 || inner <= 0 || count <= 0 ||
+        (dtype != SHL_MI355X_I8 && dtype != SHL_MI355X_F16)) {
+        shl::set_error("softmax: invalid argument");
+        return SHL_MI355X_EINVAL;
+    }
+    if (count > shl::SOFTMAX_MAX_CNT) {
+        shl::set_error("softmax: axis length %d exceeds %d", (int)count, shl::SOFTMAX_MAX_CNT);
+        return SHL_MI355X_ENOTSUP;
+    }
+    const int64_t rows = outer * inner;
+    if (rows == 0) return SHL_MI355X_OK;
+    if (rows > 0x7FFFFFFF) {
+        shl::set_error("softmax: too many rows");
+        return SHL_MI355X_ENOTSUP;
+    }
+    const size_t lds = (size_t)count * 8 + 256 * 4;
+    static bool opted_in = false;
+    if (lds > 48 * 1024 && !opted_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(shl::softmax_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        opted_in = true;
+    }
+    hipLaunchKernelGGL(shl::softmax_kernel, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, input_dev,
+                       output_dev, (int)dtype, (int)count, inner, in_scale, (float)in_zp, out_scale, (float)out_zp);
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}

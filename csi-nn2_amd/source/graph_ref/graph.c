@@ -149,6 +149,18 @@ int shl_gref_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
     return record_siso(input, output, CSINN_OP_RELU6, params);
 }
 
+int shl_gref_global_avgpool2d(struct csinn_tensor *input, struct csinn_tensor *output,
+                              struct csinn_pool_params *params)
+{
+    return record_siso(input, output, CSINN_OP_GLOBAL_AVGPOOL2D, params);
+}
+
+int shl_gref_softmax(struct csinn_tensor *input, struct csinn_tensor *output,
+                     struct csinn_softmax_params *params)
+{
+    return record_siso(input, output, CSINN_OP_SOFTMAX, params);
+}
+
 /* ------------------------------------------------------------------------ callbacks */
 int shl_gref_call_layer_func(void *fn, struct shl_node *node)
 {
@@ -201,6 +213,8 @@ static struct csinn_callback *gref_cb_map(int op, int dtype)
         {CSINN_OP_FULLYCONNECTED, shl_gref_fullyconnected},
         {CSINN_OP_RELU, shl_gref_relu},
         {CSINN_OP_RELU6, shl_gref_relu6},
+        {CSINN_OP_GLOBAL_AVGPOOL2D, shl_gref_global_avgpool2d},
+        {CSINN_OP_SOFTMAX, shl_gref_softmax},
     };
     for (unsigned i = 0; i < sizeof(table) / sizeof(table[0]); i++) {
         if (table[i].op == op) {

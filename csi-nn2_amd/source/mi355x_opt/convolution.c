@@ -286,16 +286,26 @@ int shl_mi355x_fullyconnected_exec(struct csinn_tensor *input, struct csinn_tens
 
 static int relu_common(struct csinn_tensor *input, struct csinn_tensor *output, int relu6)
 {
-    if (input->dtype != CSINN_DTYPE_INT8 || output->dtype != CSINN_DTYPE_INT8) {
-        shl_debug_error("mi355x: relu supports int8 tensors only\n");
+    const int i8 = input->dtype == CSINN_DTYPE_INT8 && output->dtype == CSINN_DTYPE_INT8;
+    const int f16 = input->dtype == CSINN_DTYPE_FLOAT16 && output->dtype == CSINN_DTYPE_FLOAT16;
+    if (!i8 && !f16) {
+        shl_debug_error("mi355x: relu supports int8 and fp16 tensors only\n");
         return CSINN_UNSUPPORT_DTYPE;
+    }
+    if (f16 && ((input->qinfo && input->qinfo->scale != 1.0f) || (output->qinfo && output->qinfo->scale != 1.0f))) {
+        shl_debug_error("mi355x: fp16 relu with qinfo scale != 1 is not supported\n");
+        return CSINN_FALSE;
     }
     const void *in_dev = shl_mi355x_stage_in(input, 0);
     void *out_dev = shl_mi355x_stage_out_begin(output, 1);
     if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
-    int st = shl_mi355x_relu_i8(in_dev, out_dev, (size_t)csinn_tensor_size(input),
-                                input->qinfo->scale, input->qinfo->zero_point, output->qinfo->scale,
-                                output->qinfo->zero_point, relu6, shl_mi355x_get_stream());
+    int st;
+    if (i8)
+        st = shl_mi355x_relu_i8(in_dev, out_dev, (size_t)csinn_tensor_size(input), input->qinfo->scale,
+                                input->qinfo->zero_point, output->qinfo->scale, output->qinfo->zero_point, relu6,
+                                shl_mi355x_get_stream());
+    else
+        st = shl_mi355x_relu_f16(in_dev, out_dev, (size_t)csinn_tensor_size(input), relu6, shl_mi355x_get_stream());
     if (st != SHL_MI355X_OK) {
         shl_debug_error("mi355x: relu launch failed (%d): %s\n", st, shl_mi355x_last_error());
         return CSINN_FALSE;

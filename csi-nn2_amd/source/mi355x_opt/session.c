@@ -1,0 +1,278 @@
+/*
+ * session.c -- device-resident execution of a whole csinn session.
+ *
+ * The reference's graph executor keeps every tensor in host memory: csinn_session_run
+ * shl_mem_alloc's each intermediate, calls the layer's exec callback on host pointers and frees the
+ * tensor when its last consumer has run (source/graph_ref/setup.c:1125-1154, 1256-1450).  Served
+ * by this backend's staging path that is one H2D + D2H + synchronisation per LAYER.
+ *
+ * Here SESSION_SETUP / SESSION_RUN are overridden for sessions whose base_api is CSINN_MI355X:
+ *   setup  runs the executor's own setup (node numbering, `init` of every layer -> device plans),
+ *          then, if every layer is one this backend executes on the GPU, gives every graph tensor a
+ *          fixed HBM buffer, builds "shadow" csinn_tensors pointing at them
+ *          (mtype = CSINN_MEM_TYPE_DMABUF) and captures the complete layer sequence into ONE
+ *          hipGraph on the session's stream;
+ *   run    uploads the graph inputs, replays the hipGraph, downloads the graph outputs and
+ *          synchronises once.
+ * Sessions containing a layer that falls through to the C reference keep the executor's host path
+ * (still correct, per-layer staging).  The graph structures are those of shl_node.h /
+ * shl_gref.h (include/shl_gref.h), so the same code walks graphs built by the genuine
+ * libshl's gref or by this repository's stand-in.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "mi355x_internal.h"
+
+struct dev_tensor {
+    struct shl_node *node;       /* tensor node of the graph */
+    void *dev;                   /* HBM buffer */
+    size_t bytes;
+    struct csinn_tensor shadow;  /* copy of the csinn_tensor with data = dev, mtype = DMABUF */
+};
+
+struct dev_session {
+    struct csinn_session *sess;
+    struct dev_tensor *t;
+    int nt;
+    void *stream;
+    void *graph_exec;
+    struct dev_session *next;
+};
+
+static struct dev_session *g_sessions;
+
+static struct dev_session *find_session(struct csinn_session *sess)
+{
+    for (struct dev_session *s = g_sessions; s; s = s->next)
+        if (s->sess == sess) return s;
+    return NULL;
+}
+
+static void free_session(struct dev_session *ds)
+{
+    if (ds->graph_exec) shl_mi355x_graph_destroy(ds->graph_exec);
+    for (int i = 0; i < ds->nt; i++)
+        if (ds->t[i].dev) shl_mi355x_free(ds->t[i].dev);
+    if (ds->stream) shl_mi355x_stream_destroy(ds->stream);
+    free(ds->t);
+    free(ds);
+}
+
+static void drop_session(struct csinn_session *sess)
+{
+    struct dev_session **pp = &g_sessions;
+    while (*pp) {
+        if ((*pp)->sess == sess) {
+            struct dev_session *dead = *pp;
+            *pp = dead->next;
+            free_session(dead);
+            return;
+        }
+        pp = &(*pp)->next;
+    }
+}
+
+/* is `exec` one of the callbacks that run on the GPU and honour DMABUF tensors? */
+static int gpu_native(int (*exec)())
+{
+    return exec == (int (*)())shl_mi355x_conv2d_exec || exec == (int (*)())shl_mi355x_fullyconnected_exec ||
+           exec == (int (*)())shl_mi355x_relu_exec || exec == (int (*)())shl_mi355x_relu6_exec ||
+           exec == (int (*)())shl_mi355x_global_avgpool2d_exec || exec == (int (*)())shl_mi355x_softmax_exec;
+}
+
+static int op_arity(int type)
+{
+    switch (type) {
+        case CSINN_OP_RELU:
+        case CSINN_OP_RELU6:
+        case CSINN_OP_GLOBAL_AVGPOOL2D:
+        case CSINN_OP_SOFTMAX:
+            return 1;
+        case CSINN_OP_CONV2D:
+        case CSINN_OP_CONV2D_RELU:
+        case CSINN_OP_CONV2D_RELU6:
+        case CSINN_OP_DEPTHWISE_CONV2D:
+        case CSINN_OP_DEPTHWISE_CONV2D_RELU:
+        case CSINN_OP_DEPTHWISE_CONV2D_RELU6:
+        case CSINN_OP_FULLYCONNECTED:
+            return 3;
+        default:
+            return 0;
+    }
+}
+
+static struct dev_tensor *lookup(struct dev_session *ds, struct shl_node *node)
+{
+    for (int i = 0; i < ds->nt; i++)
+        if (ds->t[i].node == node) return &ds->t[i];
+    return NULL;
+}
+
+static struct dev_tensor *adopt(struct dev_session *ds, struct shl_node *node)
+{
+    struct dev_tensor *d = lookup(ds, node);
+    if (d) return d;
+    d = &ds->t[ds->nt++];
+    d->node = node;
+    struct csinn_tensor *t = node->data;
+    d->bytes = (size_t)csinn_tensor_byte_size(t);
+    d->dev = shl_mi355x_malloc(d->bytes ? d->bytes : 16);
+    d->shadow = *t;
+    d->shadow.data = d->dev;
+    d->shadow.mtype = CSINN_MEM_TYPE_DMABUF;
+    return d->dev ? d : NULL;
+}
+
+/* enqueue every layer on the session stream, tensors resident in HBM */
+static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
+{
+    for (int i = 0; i < g->layer_index; i++) {
+        struct shl_node *n = g->layer[i];
+        struct csinn_params_base *params = n->data;
+        struct dev_tensor *in = lookup(ds, n->in[0]);
+        struct dev_tensor *out = lookup(ds, n->out[0]);
+        int (*f)() = params->cb->exec;
+        int rc;
+        if (op_arity(n->type) == 1)
+            rc = f(&in->shadow, &out->shadow, params);
+        else
+            rc = f(&in->shadow, &out->shadow, n->in[1]->data, n->in[2]->data, params);
+        if (rc != CSINN_TRUE) {
+            shl_debug_error("mi355x: layer %d (%s) failed while building the device graph\n", i,
+                            n->name ? n->name : "?");
+            return CSINN_FALSE;
+        }
+    }
+    return CSINN_TRUE;
+}
+
+int shl_mi355x_session_setup(struct csinn_session *sess)
+{
+    /* the reference's shl_gref_session_setup returns void (source/graph_ref/setup.c:688): its
+     * "status" is whatever the register holds, so it cannot gate anything here */
+    int (*gref_setup)(struct csinn_session *) = shl_gref_runtime_callback(CSINN_SESSION_SETUP);
+    if (gref_setup == NULL) return CSINN_FALSE;
+    int rc = gref_setup(sess);
+    drop_session(sess);
+    struct shl_ref_graph *g = shl_gref_get_graph(sess);
+    if (g == NULL || g->layer_index == 0) return rc;
+
+    /* device-resident only when every layer runs on the GPU */
+    int tensors = g->input_num;
+    for (int i = 0; i < g->layer_index; i++) {
+        struct shl_node *n = g->layer[i];
+        struct csinn_params_base *params = n->data;
+        const int arity = op_arity(n->type);
+        if (arity == 0 || n->in_num != arity || n->out_num != 1 || params->cb == NULL ||
+            !gpu_native(params->cb->exec)) {
+            shl_debug_info("mi355x: layer %d (%s, op %d) runs on the host path: session stays host-staged\n", i,
+                           n->name ? n->name : "?", n->type);
+            return rc;
+        }
+        tensors += 1;
+    }
+    struct dev_session *ds = calloc(1, sizeof(*ds));
+    ds->sess = sess;
+    ds->t = calloc((size_t)tensors + 1, sizeof(struct dev_tensor));
+    ds->stream = shl_mi355x_stream_create();
+    int ok = ds->stream != NULL;
+    for (int i = 0; ok && i < g->input_num; i++) ok = adopt(ds, g->input[i]) != NULL;
+    for (int i = 0; ok && i < g->layer_index; i++) {
+        struct shl_node *n = g->layer[i];
+        if (lookup(ds, n->in[0]) == NULL) {
+            shl_debug_error("mi355x: layer %d consumes a tensor that no earlier layer produces\n", i);
+            ok = 0;
+            break;
+        }
+        ok = adopt(ds, n->out[0]) != NULL;
+    }
+    for (int i = 0; ok && i < g->output_num; i++) ok = lookup(ds, g->output[i]) != NULL;
+    if (ok) {
+        /* capture the whole model once; a failed capture leaves the eager device path */
+        void *prev = shl_mi355x_get_stream();
+        shl_mi355x_set_stream(ds->stream);
+        if (shl_mi355x_graph_begin(ds->stream) == SHL_MI355X_OK) {
+            int built = enqueue_layers(ds, g);
+            ds->graph_exec = shl_mi355x_graph_end(ds->stream);
+            if (built != CSINN_TRUE && ds->graph_exec) {
+                shl_mi355x_graph_destroy(ds->graph_exec);
+                ds->graph_exec = NULL;
+            }
+            if (built != CSINN_TRUE) ok = 0;
+        }
+        shl_mi355x_set_stream(prev);
+    }
+    if (!ok) {
+        shl_debug_error("mi355x: device-resident session setup failed (%s); keeping the host path\n",
+                        shl_mi355x_last_error());
+        free_session(ds);
+        return rc;
+    }
+    ds->next = g_sessions;
+    g_sessions = ds;
+    return CSINN_TRUE;
+}
+
+int shl_mi355x_session_run(struct csinn_session *sess)
+{
+    struct dev_session *ds = find_session(sess);
+    if (ds == NULL) {
+        int (*gref_run)(struct csinn_session *) = shl_gref_runtime_callback(CSINN_SESSION_RUN);
+        return gref_run ? gref_run(sess) : CSINN_FALSE;
+    }
+    struct shl_ref_graph *g = shl_gref_get_graph(sess);
+    int status = CSINN_TRUE;
+    for (int i = 0; i < g->input_num; i++) {
+        struct dev_tensor *d = lookup(ds, g->input[i]);
+        struct csinn_tensor *t = g->input[i]->data;
+        int st;
+        if (t->data == NULL) {
+            shl_debug_error("mi355x: graph input %d has no data\n", i);
+            return CSINN_FALSE;
+        }
+        if (t->mtype == CSINN_MEM_TYPE_DMABUF)
+            st = shl_mi355x_copy(d->dev, t->data, d->bytes, ds->stream);
+        else
+            st = shl_mi355x_upload(d->dev, t->data, d->bytes, ds->stream);
+        if (st != SHL_MI355X_OK) status = CSINN_FALSE;
+    }
+    if (ds->graph_exec) {
+        if (shl_mi355x_graph_launch(ds->graph_exec, ds->stream) != SHL_MI355X_OK) status = CSINN_FALSE;
+    } else {
+        void *prev = shl_mi355x_get_stream();
+        shl_mi355x_set_stream(ds->stream);
+        if (enqueue_layers(ds, g) != CSINN_TRUE) status = CSINN_FALSE;
+        shl_mi355x_set_stream(prev);
+    }
+    for (int i = 0; i < g->output_num; i++) {
+        struct dev_tensor *d = lookup(ds, g->output[i]);
+        struct csinn_tensor *t = g->output[i]->data;
+        if (t->mtype == CSINN_MEM_TYPE_DMABUF && t->data != NULL) { /* caller wants it in HBM */
+            if (shl_mi355x_copy(t->data, d->dev, d->bytes, ds->stream) != SHL_MI355X_OK) status = CSINN_FALSE;
+            continue;
+        }
+        if (t->mtype != CSINN_MEM_TYPE_CPU_ACC) /* a fresh buffer per run that the caller then owns, as
+                                                   the executor does (graph_ref/setup.c:1125-1134) */
+            t->data = shl_mem_alloc((int64_t)(d->bytes ? d->bytes : 16));
+        if (t->data == NULL || shl_mi355x_download(t->data, d->dev, d->bytes, ds->stream) != SHL_MI355X_OK)
+            status = CSINN_FALSE;
+    }
+    if (shl_mi355x_stream_sync(ds->stream) != SHL_MI355X_OK) status = CSINN_FALSE;
+    if (status != CSINN_TRUE) shl_debug_error("mi355x: device session run failed: %s\n", shl_mi355x_last_error());
+    return status;
+}
+
+void shl_mi355x_session_deinit(struct csinn_session *sess)
+{
+    drop_session(sess);
+    void (*gref_deinit)(struct csinn_session *) = shl_gref_runtime_callback(CSINN_SESSION_DEINIT);
+    if (gref_deinit) gref_deinit(sess);
+}
+
+/* 1 when `sess` executes as one device-resident hipGraph, 0 when host-staged */
+int shl_mi355x_session_is_device_resident(struct csinn_session *sess)
+{
+    struct dev_session *ds = find_session(sess);
+    return ds ? (ds->graph_exec ? 2 : 1) : 0;
+}

@@ -262,9 +262,14 @@ float shl_mi355x_half_to_float(uint16_t h)
 /* ------------------------------------------------------------------------ runtime map */
 void *shl_mi355x_runtime_callback(int op)
 {
-    /* graph construction and execution are served by the graph executor; the backend only
-     * supplies compute callbacks (device-resident SESSION_RUN: see session.c when present) */
-    return shl_gref_runtime_callback(op);
+    /* graph construction is served by the graph executor; setup / run / deinit are wrapped so
+     * that all-GPU sessions execute device-resident as one hipGraph (session.c) */
+    switch (op) {
+        case CSINN_SESSION_SETUP: return shl_mi355x_session_setup;
+        case CSINN_SESSION_RUN: return shl_mi355x_session_run;
+        case CSINN_SESSION_DEINIT: return shl_mi355x_session_deinit;
+        default: return shl_gref_runtime_callback(op);
+    }
 }
 
 void shl_target_init_mi355x(void)
@@ -289,8 +294,12 @@ void shl_target_init_mi355x(void)
         reg(dt, CSINN_OP_FULLYCONNECTED, shl_mi355x_fullyconnected_init,
             shl_mi355x_fullyconnected_exec, shl_gref_fullyconnected);
     }
-    reg(CSINN_DTYPE_INT8, CSINN_OP_RELU, NULL, shl_mi355x_relu_exec, shl_gref_relu);
-    reg(CSINN_DTYPE_INT8, CSINN_OP_RELU6, NULL, shl_mi355x_relu6_exec, shl_gref_relu6);
+    for (int i = 0; i < 2; i++) {
+        reg(dts[i], CSINN_OP_RELU, NULL, shl_mi355x_relu_exec, shl_gref_relu);
+        reg(dts[i], CSINN_OP_RELU6, NULL, shl_mi355x_relu6_exec, shl_gref_relu6);
+        reg(dts[i], CSINN_OP_GLOBAL_AVGPOOL2D, NULL, shl_mi355x_global_avgpool2d_exec, shl_gref_global_avgpool2d);
+        reg(dts[i], CSINN_OP_SOFTMAX, NULL, shl_mi355x_softmax_exec, shl_gref_softmax);
+    }
     shl_register_op_callback(CSINN_MI355X, shl_cb_map_mi355x);
     shl_register_runtime_callback(CSINN_MI355X, shl_mi355x_runtime_callback);
 }

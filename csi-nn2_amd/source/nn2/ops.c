@@ -135,3 +135,27 @@ int csinn_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
 {
     return run3(&params->base, input, output, params);
 }
+
+int csinn_global_avgpool2d_init(struct csinn_tensor *input, struct csinn_tensor *output,
+                                struct csinn_pool_params *params)
+{
+    return map_and_init(&params->base, CSINN_OP_GLOBAL_AVGPOOL2D, input->dtype, input, output, NULL,
+                        NULL, params);
+}
+int csinn_global_avgpool2d(struct csinn_tensor *input, struct csinn_tensor *output,
+                           struct csinn_pool_params *params)
+{
+    return run3(&params->base, input, output, params);
+}
+
+int csinn_softmax_init(struct csinn_tensor *input, struct csinn_tensor *output,
+                       struct csinn_softmax_params *params)
+{
+    return map_and_init(&params->base, CSINN_OP_SOFTMAX, input->dtype, input, output, NULL, NULL,
+                        params);
+}
+int csinn_softmax(struct csinn_tensor *input, struct csinn_tensor *output,
+                  struct csinn_softmax_params *params)
+{
+    return run3(&params->base, input, output, params);
+}

@@ -212,3 +212,110 @@ class LayerChain:
             self.graph = None
         for e in self.entries:
             self.opt.shl_mi355x_release_params(e["params"])
+
+
+class ModelSession:
+    """MobileNetV1 end to end through the csinn SESSION API in graph mode (the call sequence of
+    example/c906_mobilenetv1_f16.c:1888-1947): 27 convolutions (+relu), global_avgpool2d, the 1x1
+    classifier convolution and softmax.  On CSINN_MI355X csinn_session_setup captures the model in
+    one hipGraph (source/mi355x_opt/session.c); run(x) = csinn_update_input + csinn_session_run +
+    csinn_get_output with HOST tensors, i.e. it includes the H2D / D2H copies and the final
+    synchronisation -- the PCIe-inclusive rate of DESIGN.md."""
+
+    def __init__(self, fe, api, dtype="int8", layout="NHWC", seed=99, layers=None):
+        from . import (QUANT_FLOAT16, QUANT_INT8_ASYM_W_SYM, RM_CPU_GRAPH, siso_params)
+        self.fe, self.dtype, self.layout = fe, dtype, layout
+        layers = layers or MOBILENETV1
+        int8 = dtype == "int8"
+        dt = DTYPE_INT8 if int8 else DTYPE_FLOAT16
+        nhwc = layout == "NHWC"
+        act_l = LAYOUT_NHWC if nhwc else LAYOUT_NCHW
+        keep = self.keep = Keep()
+        sess = self.sess = fe.csinn_alloc_session()
+        sc = sess.contents
+        sc.base_api, sc.base_run_mode, sc.base_dtype = api, RM_CPU_GRAPH, dt
+        sc.base_quant_type = QUANT_INT8_ASYM_W_SYM if int8 else QUANT_FLOAT16
+        sc.debug_level = 0
+        fe.csinn_session_init(sess)
+        fe.csinn_set_input_number(1, sess)
+        fe.csinn_set_output_number(1, sess)
+        L0 = layers[0]
+        self.in_dims = (1, L0["h"], L0["w"], L0["cin"]) if nhwc else (1, L0["cin"], L0["h"], L0["w"])
+        q = (2.0 ** -4, -5) if int8 else (1.0, 0)
+        self.in_q = q
+
+        def T(dims, q, name, data=None, const=0, lay=act_l, dtype_=dt):
+            return make_tensor(fe, keep, dims, dtype_, lay, data=data, is_const=const, name=name, sess=sess,
+                               scales=(q[0],), zps=(q[1],))
+        t_in = T(self.in_dims, q, b"data")
+        cur, ops = t_in, []
+        for i, L in enumerate(layers):
+            if i == len(layers) - 1:  # pooled map feeds the classifier
+                pooled = (1, 1, 1, L["cin"]) if nhwc else (1, L["cin"], 1, 1)
+                qp = (2.0 ** -4, -5) if int8 else (1.0, 0)
+                t_p = T(pooled, qp, b"gap_out")
+                pp = siso_params(fe, keep, api, "pool", act_l, 1, sess, b"gap")
+                ops.append((fe.csinn_global_avgpool2d_init, fe.csinn_global_avgpool2d, (cur, t_p, pp)))
+                cur, q = t_p, qp
+            ho = out_hw(L)
+            out_dims = (1, ho, ho, L["cout"]) if nhwc else (1, L["cout"], ho, ho)
+            o = synth_layer_operands(L, seed + i, dtype, layout, q[0] if int8 else None)
+            qo = (o["out_scale"], o["out_zp"])
+            t_out = T(out_dims, qo, b"out%d" % i)
+            w_l = (LAYOUT_1HWO if nhwc else LAYOUT_O1HW) if L["depthwise"] else (LAYOUT_OHWI if nhwc else LAYOUT_OIHW)
+            t_w = T(o["kernel"].shape, (o["k_scale"], 0), b"w%d" % i, o["kernel"], 1, w_l)
+            b_scale = q[0] * o["k_scale"] if int8 else 1.0
+            t_b = T((L["cout"],), (b_scale, 0), b"b%d" % i, o["bias"], 1, LAYOUT_O, DTYPE_INT32 if int8 else dt)
+            p = conv_params(fe, keep, api, act_l, (L["stride"],) * 2, (L["pad"],) * 4, (1, 1),
+                            L["cin"] if L["depthwise"] else 1, 0, sess, b"conv%d" % i)
+            relu = L["act"] == ACT_RELU
+            ops.append((fe.csinn_conv2d_relu_init if relu else fe.csinn_conv2d_init,
+                        fe.csinn_conv2d_relu if relu else fe.csinn_conv2d, (cur, t_out, t_w, t_b, p)))
+            cur, q, cur_dims = t_out, qo, out_dims
+        qs = (1.0 / 256, -128) if int8 else (1.0, 0)
+        t_sm = T(cur_dims, qs, b"prob")
+        ps = siso_params(fe, keep, api, "softmax", act_l, 3 if nhwc else 1, sess, b"softmax")
+        ops.append((fe.csinn_softmax_init, fe.csinn_softmax, (cur, t_sm, ps)))
+        self.out_dims = cur_dims
+        for init, _, args in ops:
+            if init(*args) != CSINN_TRUE:
+                raise MI355XError("%s failed" % init.__name__)
+        fe.csinn_set_tensor_entry(t_in, sess)
+        fe.csinn_set_input(0, t_in, sess)
+        for _, run, args in ops:
+            if run(*args) != CSINN_TRUE:
+                raise MI355XError("%s failed" % run.__name__)
+        fe.csinn_set_output(0, t_sm, sess)
+        fe.csinn_session_setup(sess)
+        self.n_layers = len(ops)
+        self._feed = None
+
+    def synthetic_input(self, seed=0):
+        rng = np.random.default_rng(seed)
+        if self.dtype == "int8":
+            return rng.integers(-64, 64, self.in_dims, dtype=np.int8)
+        return rng.standard_normal(self.in_dims).astype(np.float16)
+
+    def run(self, x):
+        fe, keep, sess = self.fe, self.keep, self.sess
+        int8 = self.dtype == "int8"
+        dt = DTYPE_INT8 if int8 else DTYPE_FLOAT16
+        act_l = LAYOUT_NHWC if self.layout == "NHWC" else LAYOUT_NCHW
+        if self._feed is None:
+            self._feed = make_tensor(fe, keep, x.shape, dt, act_l, sess=sess, scales=(self.in_q[0],),
+                                     zps=(self.in_q[1],))
+            self._got = make_tensor(fe, keep, (1,), dt, act_l, sess=sess)
+        self._feed.contents.data = x.ctypes.data
+        fe.csinn_update_input(0, self._feed, sess)
+        if fe.csinn_session_run(sess) != CSINN_TRUE:
+            raise MI355XError("csinn_session_run failed")
+        fe.csinn_get_output(0, self._got, sess)
+        n = int(np.prod(self.out_dims))
+        ctype = C.c_int8 if int8 else C.c_uint16
+        data = np.ctypeslib.as_array(C.cast(self._got.contents.data, C.POINTER(ctype)), (n,)).copy()
+        fe.shl_mem_free(self._got.contents.data)
+        return data if int8 else data.view(np.float16)
+
+    def close(self):
+        self.fe.csinn_session_deinit(self.sess)
+        self.fe.csinn_free_session(self.sess)

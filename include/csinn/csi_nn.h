@@ -51,6 +51,15 @@ int csinn_relu6_init(struct csinn_tensor *input, struct csinn_tensor *output,
                      struct csinn_relu_params *params);
 int csinn_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
                 struct csinn_relu_params *params);
+/* MobileNet tail (source/nn2/global_avgpool2d.c, softmax.c of the reference) */
+int csinn_global_avgpool2d_init(struct csinn_tensor *input, struct csinn_tensor *output,
+                                struct csinn_pool_params *params);
+int csinn_global_avgpool2d(struct csinn_tensor *input, struct csinn_tensor *output,
+                           struct csinn_pool_params *params);
+int csinn_softmax_init(struct csinn_tensor *input, struct csinn_tensor *output,
+                       struct csinn_softmax_params *params);
+int csinn_softmax(struct csinn_tensor *input, struct csinn_tensor *output,
+                  struct csinn_softmax_params *params);
 
 #ifdef __cplusplus
 }

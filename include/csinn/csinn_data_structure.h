@@ -351,6 +351,27 @@ struct csinn_softmax_params { /* 48 B */
     int32_t axis;
 };
 
+/* pooling (csinn_data_structure.h:643-662 of the reference); global_avgpool2d ignores the
+ * window fields (the reference overwrites them, source/reference/global_averagepool.c:24-41) */
+struct csinn_pool_params { /* 100 B, padded to 104 */
+    struct csinn_params_base base;
+    int32_t pool_type;
+    int32_t filter_height;
+    int32_t filter_width;
+    int32_t filter_depth;
+    int32_t stride_height;
+    int32_t stride_width;
+    int32_t stride_depth;
+    int32_t pad_top;
+    int32_t pad_left;
+    int32_t pad_down;
+    int32_t pad_right;
+    int32_t pad_front;
+    int32_t pad_back;
+    int32_t ceil_mode;
+    bool count_include_pad;
+};
+
 #ifdef __cplusplus
 }
 #endif

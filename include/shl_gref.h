@@ -64,6 +64,10 @@ int shl_gref_relu(struct csinn_tensor *input, struct csinn_tensor *output,
                   struct csinn_relu_params *params);
 int shl_gref_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
                    struct csinn_relu_params *params);
+int shl_gref_global_avgpool2d(struct csinn_tensor *input, struct csinn_tensor *output,
+                              struct csinn_pool_params *params);
+int shl_gref_softmax(struct csinn_tensor *input, struct csinn_tensor *output,
+                     struct csinn_softmax_params *params);
 
 /* session-level handlers of the executor; a backend forwards the ones it does not override
  * (pattern: source/c920v2_opt/setup.c:355-389) */

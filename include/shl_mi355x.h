@@ -191,6 +191,25 @@ int shl_mi355x_relu_i8(const int8_t *input_dev, int8_t *output_dev, size_t count
                        float in_scale, int32_t in_zp, float out_scale, int32_t out_zp,
                        int32_t relu6, void *stream);
 
+/* binary16 relu / relu6 (same reference functions, dtype FLOAT16, qinfo scale 1) */
+int shl_mi355x_relu_f16(const uint16_t *input_dev, uint16_t *output_dev, size_t count, int32_t relu6,
+                        void *stream);
+
+/* global average pooling over H*W (`pixels`) of an int8 / binary16 tensor:
+ * shl_ref_global_avgpool2d_quant (source/reference/global_averagepool.c:21-50 ->
+ * averagepool.c:21-119), same fp32 summation order.  Output is [N, C] (NHWC [N,1,1,C] or NCHW
+ * [N,C,1,1]).  f16: the scale arguments are ignored. */
+int shl_mi355x_global_avgpool2d(const void *input_dev, void *output_dev, int32_t dtype, int32_t layout,
+                                int32_t batch, int32_t channels, int32_t pixels, float in_scale,
+                                int32_t in_zp, float out_scale, int32_t out_zp, void *stream);
+
+/* softmax along one axis of a tensor viewed as [outer, count, inner]:
+ * shl_ref_softmax_quant (source/reference/softmax.c:21-72): float max, double exp, float running
+ * sum in index order.  count <= 8192. */
+int shl_mi355x_softmax(const void *input_dev, void *output_dev, int32_t dtype, int64_t outer, int32_t count,
+                       int64_t inner, float in_scale, int32_t in_zp, float out_scale, int32_t out_zp,
+                       void *stream);
+
 /* NCHW <-> NHWC re-layout of an activation tensor in HBM (int8: elem_bytes 1, fp16: 2):
  * shl_ref_nchw_to_nhwc_* / shl_ref_nhwc_to_nchw_* of source/reference/utils.c, which the
  * reference's own NCHW convolution uses on non-x86 builds (convolution.c:123-135).

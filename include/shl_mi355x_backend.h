@@ -55,6 +55,19 @@ int shl_mi355x_relu_exec(struct csinn_tensor *input, struct csinn_tensor *output
                          struct csinn_relu_params *params);
 int shl_mi355x_relu6_exec(struct csinn_tensor *input, struct csinn_tensor *output,
                           struct csinn_relu_params *params);
+int shl_mi355x_global_avgpool2d_exec(struct csinn_tensor *input, struct csinn_tensor *output,
+                                     struct csinn_pool_params *params);
+int shl_mi355x_softmax_exec(struct csinn_tensor *input, struct csinn_tensor *output,
+                            struct csinn_softmax_params *params);
+
+/* device-resident graph execution (source/mi355x_opt/session.c): SESSION_SETUP / SESSION_RUN /
+ * SESSION_DEINIT handlers returned by shl_mi355x_runtime_callback.  A session whose layers all run
+ * on the GPU keeps every tensor in HBM and replays one hipGraph per csinn_session_run. */
+int shl_mi355x_session_setup(struct csinn_session *sess);
+int shl_mi355x_session_run(struct csinn_session *sess);
+void shl_mi355x_session_deinit(struct csinn_session *sess);
+/* 0: host-staged (executor's own run), 1: device-resident eager, 2: device-resident hipGraph */
+int shl_mi355x_session_is_device_resident(struct csinn_session *sess);
 
 #ifdef __cplusplus
 }

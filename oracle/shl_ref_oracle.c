@@ -8,6 +8,7 @@
  */
 #include "shl_ref_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -266,6 +267,78 @@ void oracle_relu_i8(const int8_t *in, int8_t *out, int64_t count, float in_scale
         if (relu6) x = (float)fmin((double)x, 6.0);
         out[i] = oracle_float_to_int8(x, out_scale, out_zp);
     }
+}
+
+/* binary16 relu / relu6: same functions on a FLOAT16 tensor (qinfo scale 1) */
+void oracle_relu_f16(const int16_t *in, int16_t *out, int64_t count, int32_t relu6)
+{
+    for (int64_t i = 0; i < count; ++i) {
+        float x = oracle_f16_to_float(in[i]);
+        x = x > 0 ? x : 0;
+        if (relu6) x = (float)fmin((double)x, 6.0);
+        out[i] = oracle_float_to_f16(x);
+    }
+}
+
+static float oracle_load(const void *in, int64_t idx, int dtype, float scale, int32_t zp)
+{
+    return dtype == 0 ? oracle_int8_to_float(((const int8_t *)in)[idx], zp, scale)
+                      : oracle_f16_to_float(((const int16_t *)in)[idx]);
+}
+
+static void oracle_store(void *out, int64_t idx, float v, int dtype, float scale, int32_t zp)
+{
+    if (dtype == 0)
+        ((int8_t *)out)[idx] = oracle_float_to_int8(v, scale, zp);
+    else
+        ((int16_t *)out)[idx] = oracle_float_to_f16(v);
+}
+
+/* shl_ref_global_avgpool2d_quant (source/reference/global_averagepool.c:21-50): the window is the
+ * whole image, stride 1, no padding -> shl_ref_avgpool2d_{nhwc,nchw}_f32 (averagepool.c:21-119):
+ * total += x for filter_y, filter_x in order (fp32), filter_count counted in float,
+ * average = total / filter_count; siso callback base dequantises / requantises around it.
+ * dtype: 0 int8, 1 binary16.  Output [N, C]. */
+void oracle_global_avgpool2d(const void *in, void *out, int32_t dtype, int32_t nhwc, int32_t batch,
+                             int32_t channels, int32_t height, int32_t width, float in_scale,
+                             int32_t in_zp, float out_scale, int32_t out_zp)
+{
+    for (int n = 0; n < batch; ++n)
+        for (int c = 0; c < channels; ++c) {
+            float total = 0.f;
+            float filter_count = 0;
+            for (int y = 0; y < height; ++y)
+                for (int x = 0; x < width; ++x) {
+                    const int64_t idx = nhwc ? (((int64_t)n * height + y) * width + x) * channels + c
+                                             : (((int64_t)n * channels + c) * height + y) * width + x;
+                    total += oracle_load(in, idx, dtype, in_scale, in_zp);
+                    filter_count++;
+                }
+            const float average = total / filter_count;
+            oracle_store(out, (int64_t)n * channels + c, average, dtype, out_scale, out_zp);
+        }
+}
+
+/* shl_ref_softmax_quant (source/reference/softmax.c:21-72): per (outer, inner) row: float max via
+ * fmax, acc_exp (float) += exp(double) in index order, out = exp(x - max) / acc_exp (double
+ * divide, stored to float), then requantised. */
+void oracle_softmax(const void *in, void *out, int32_t dtype, int64_t outer, int32_t cnt, int64_t inner,
+                    float in_scale, int32_t in_zp, float out_scale, int32_t out_zp)
+{
+    for (int64_t o = 0; o < outer; ++o)
+        for (int64_t k = 0; k < inner; ++k) {
+            const int64_t base = o * cnt * inner + k;
+            float acc_exp = 0.0f;
+            float max = -FLT_MAX;
+            for (int j = 0; j < cnt; ++j)
+                max = (float)fmax(max, oracle_load(in, base + j * inner, dtype, in_scale, in_zp));
+            for (int j = 0; j < cnt; ++j)
+                acc_exp += exp(oracle_load(in, base + j * inner, dtype, in_scale, in_zp) - max);
+            for (int j = 0; j < cnt; ++j) {
+                const float v = exp(oracle_load(in, base + j * inner, dtype, in_scale, in_zp) - max) / acc_exp;
+                oracle_store(out, base + j * inner, v, dtype, out_scale, out_zp);
+            }
+        }
 }
 
 /* ------------------------------------------------------------------ formulation R */

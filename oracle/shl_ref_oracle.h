@@ -103,6 +103,14 @@ void oracle_relu_i8(const int8_t *in, int8_t *out, int64_t count, float in_scale
 /* wall-clock helper used by bench.py's cpu_baseline leg: runs formulation R `iters` times
  * with OpenMP over the batch*rows dimension (the reference itself uses
  * `#pragma omp parallel for num_threads(8)`, conv_avx.h:138) and returns seconds per run */
+void oracle_relu_f16(const int16_t *in, int16_t *out, int64_t count, int32_t relu6);
+/* dtype: 0 int8, 1 binary16 (scales ignored) */
+void oracle_global_avgpool2d(const void *in, void *out, int32_t dtype, int32_t nhwc, int32_t batch,
+                             int32_t channels, int32_t height, int32_t width, float in_scale,
+                             int32_t in_zp, float out_scale, int32_t out_zp);
+void oracle_softmax(const void *in, void *out, int32_t dtype, int64_t outer, int32_t cnt, int64_t inner,
+                    float in_scale, int32_t in_zp, float out_scale, int32_t out_zp);
+
 double oracle_time_conv2d_i8_ref(const struct oracle_conv *c, const int8_t *input,
                                  const int8_t *kernel, const int32_t *bias, int8_t *output,
                                  int32_t iters);

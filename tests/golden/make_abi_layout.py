@@ -31,6 +31,8 @@ STRUCTS = {
     "csinn_siso_params": ["base"],
     "csinn_relu_params": ["base", "n", "n_multiplier", "n_shift"],
     "csinn_softmax_params": ["base", "axis"],
+    "csinn_pool_params": ["base", "pool_type", "filter_height", "filter_width", "stride_height", "stride_width",
+                          "pad_top", "pad_left", "pad_down", "pad_right", "ceil_mode", "count_include_pad"],
     "shl_ref_graph": ["input", "output", "input_num", "output_num", "layer", "layer_size", "layer_index"],
     "shl_gref_target_data": ["graph", "is_hybrid_quantization_type", "cpu_option"],
     "shl_node": ["type", "in", "out", "subgraph_idx", "in_num", "out_num", "name", "data", "ref_count",

@@ -1,0 +1,167 @@
+"""MobileNet tail and device-resident sessions (8f2): relu fp16, global_avgpool2d,
+softmax, and a miniature MobileNet through the csinn session API.
+
+CPU (-m "not gpu"): the oracle restatements against golden vectors produced by the genuine
+reference (tests/golden/make_tail_golden.py).  GPU: the backend against the oracle and the goldens,
+through the C-ABI and through csinn_* in layer and graph mode.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import tail
+from cases import pkg
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tail_cases.npz"))
+CASES = tail.tail_cases()
+IDS = [c["name"] for c in CASES]
+
+
+def golden(name, dtype):
+    x, out = GOLD[name + "/x"], GOLD[name + "/out"]
+    return (x.view(np.float16), out.view(np.float16)) if dtype == "f16" else (x, out)
+
+
+def assert_same(got, want, dtype, what, lsb=0):
+    if dtype == "int8":
+        n, worst = cases.mismatch_report(got, want)
+        assert worst <= lsb and (lsb == 0 or n <= max(2, got.size // 50)), "%s: %d mismatches, max |d| %d" % (what, n, worst)
+    else:
+        g, w = got.astype(np.float32), want.astype(np.float32)
+        # binary16 results of the same fp32 arithmetic: identical bits expected; allow one fp16 ulp
+        # (softmax: the device's double exp is not glibc's)
+        tol = 1e-3 * np.maximum(np.abs(w), 1e-3)
+        assert np.all(np.abs(g - w) <= tol) or np.array_equal(got.view(np.uint16), want.view(np.uint16)), \
+            "%s: max rel err %g" % (what, float(np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-3))))
+
+
+# ------------------------------------------------------------------------------------ CPU: oracle
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_oracle_matches_the_reference_golden(case):
+    x, want = golden(case["name"], case["dtype"])
+    assert np.array_equal(x.view(np.uint8), np.ascontiguousarray(case["x"]).view(np.uint8)), "fixture input drifted"
+    got = tail.siso_oracle(case)
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), case["name"]
+
+
+@pytest.mark.parametrize("dtype,layout", [("int8", "NHWC"), ("f16", "NCHW")])
+def test_oracle_replay_of_the_mini_model_matches_the_reference_graph_run(dtype, layout):
+    net = tail.MiniNet(dtype, layout)
+    outs = []
+    for k in range(2):
+        x, want = golden("mininet_%s_%s_%d" % (dtype, layout, k), dtype)
+        assert np.array_equal(x.view(np.uint8), net.input(k).view(np.uint8))
+        got = net.oracle(x)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+        outs.append(want)
+    assert not np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8)), "the two inputs must be told apart"
+
+
+@pytest.mark.skipif(not cases.have_reference(), reason="oracle/_ref/libshl_ref_x86.so not present")
+def test_oracle_against_the_live_reference_on_random_tail_cases():
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, cases, tail
+from cases import pkg
+fe = pkg.load_frontend("reference")
+rng = np.random.default_rng(3)
+bad = 0
+for i in range(12):
+    kind = ["pool", "softmax", "relu", "relu6"][i %% 4]
+    dtype = "int8" if i %% 3 else "f16"
+    shape = tuple(int(v) for v in rng.integers(1, 9, 4))
+    x = rng.integers(-128, 128, shape, dtype=np.int8) if dtype == "int8" else (3 * rng.standard_normal(shape)).astype(np.float16)
+    q = lambda: (float(np.float32(0.02 + 0.1 * rng.random())), int(rng.integers(-20, 20))) if dtype == "int8" else (1.0, 0)
+    case = dict(name="r%%d" %% i, kind=kind, x=x, dtype=dtype, layout=["NHWC", "NCHW"][i %% 2], axis=int(rng.integers(0, 4)),
+                in_q=q(), out_q=q())
+    want = tail.siso_run(fe, pkg.API_REF, case)
+    got = tail.siso_oracle(case)
+    bad += int(not np.array_equal(got.view(np.uint8), want.view(np.uint8)))
+print("LIVE_OK" if bad == 0 else "LIVE_FAIL %%d" %% bad)
+""" % os.path.dirname(os.path.abspath(__file__))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "LIVE_OK" in res.stdout, res.stdout + res.stderr
+
+
+# ------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def gpu():
+    fe = pkg.load_frontend("standalone")
+    hip, opt = pkg.load_backend(fe)
+    if hip.shl_mi355x_device_count() < 1:
+        pytest.fail("no gfx950 device visible: " + hip.shl_mi355x_last_error().decode())
+    return fe, hip, opt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_tail_op_matches_oracle_and_golden(gpu, case):
+    fe, hip, _ = gpu
+    _, want = golden(case["name"], case["dtype"])
+    oracle = tail.siso_oracle(case)
+    lsb = 1 if case["kind"] == "softmax" else 0  # double exp on the device vs glibc: at most one quantum
+    for device in (None, cases.HipDevice(hip)):
+        got = tail.siso_run(fe, pkg.API_MI355X, case, device=device)
+        assert_same(got, oracle, case["dtype"], case["name"] + " vs oracle", lsb)
+        assert_same(got, want, case["dtype"], case["name"] + " vs reference golden", lsb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,layout", [("int8", "NHWC"), ("f16", "NCHW")])
+def test_mini_model_runs_device_resident_as_one_hipgraph(gpu, dtype, layout):
+    """csinn_session_setup captures the whole model; csinn_session_run = upload, one graph launch,
+    download.  Outputs equal the reference's own graph-mode run (golden)."""
+    fe, hip, opt = gpu
+    net = tail.MiniNet(dtype, layout)
+    sess = net.build(fe, pkg.API_MI355X)
+    assert opt.shl_mi355x_session_is_device_resident(sess) == 2
+    for k in (0, 1, 0):  # replay with changing inputs
+        x, want = golden("mininet_%s_%s_%d" % (dtype, layout, k), dtype)
+        got = net.run(fe, x)
+        assert_same(got, want, dtype, "mininet %s input %d" % (dtype, k), lsb=1)
+    plans_before = opt.shl_mi355x_live_plans(None)
+    assert plans_before >= 4
+    net.close(fe)
+
+
+DROPIN_MODEL = r"""
+import sys
+sys.path.insert(0, %(tests)r)
+import numpy as np
+import cases, tail
+from cases import pkg
+fe = pkg.load_frontend("reference")          # genuine libshl_ref_x86.so: its own gref builds the graph
+hip, opt = pkg.load_backend(fe)
+bad = 0
+for dtype, layout in (("int8", "NHWC"), ("f16", "NCHW")):
+    ref = tail.MiniNet(dtype, layout); ref.build(fe, pkg.API_REF)
+    net = tail.MiniNet(dtype, layout); sess = net.build(fe, pkg.API_MI355X)
+    mode = opt.shl_mi355x_session_is_device_resident(sess)
+    for k in range(2):
+        x = net.input(k)
+        want, got = ref.run(fe, x), net.run(fe, x)
+        if dtype == "int8":
+            n, worst = cases.mismatch_report(got, want)
+            ok = worst <= 1
+        else:
+            ok = bool(np.all(np.abs(got.astype(np.float32) - want.astype(np.float32)) <= 1e-3 * np.maximum(np.abs(want.astype(np.float32)), 1e-3)))
+        print(dtype, layout, "input", k, "device mode", mode, "ok", ok)
+        bad += int(not ok) + int(mode != 2)
+print("MODEL_OK" if bad == 0 else "MODEL_FAIL")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not cases.have_reference(), reason="oracle/_ref/libshl_ref_x86.so not present")
+def test_whole_model_drop_in_behind_the_genuine_graph_executor(gpu):
+    """The reference's csinn_session_* + gref build and own the graph; sess->base_api = 14 routes
+    SESSION_SETUP / SESSION_RUN to this backend, which runs it device-resident."""
+    code = DROPIN_MODEL % dict(tests=os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "MODEL_OK" in res.stdout, res.stdout + res.stderr
