@@ -133,6 +133,19 @@ __device__ __forceinline__ uint32_t pack4_i8(int q0, int q1, int q2, int q3)
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
+// 4x4 byte transpose: in[i] holds bytes (row i, col 0..3); out[j] holds (row 0..3, col j)
+__device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&in)[4], uint32_t (&out)[4])
+{
+    const uint32_t t0 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u);  // r0c0 r1c0 r0c1 r1c1
+    const uint32_t t1 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u);  // r2c0 r3c0 r2c1 r3c1
+    const uint32_t t2 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);  // r0c2 r1c2 r0c3 r1c3
+    const uint32_t t3 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
+    out[1] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
+    out[2] = __builtin_amdgcn_perm(t3, t2, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(t3, t2, 0x07060302u);
+}
+
 // ---- binary16 <-> fp32 with the reference's rounding ----------------------------------------
 __device__ __forceinline__ float f16_bits_to_float(uint16_t h)
 {
@@ -193,6 +206,8 @@ int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 bool igemm_supports(const shl_mi355x_conv_desc &d);
 const char *igemm_variant(int64_t M, int64_t Co);  // "tile" | "regs" | "wave"
 bool dwconv_supports(const shl_mi355x_conv_desc &d);
+bool dwconv_dot4_supports(const shl_mi355x_conv_desc &d);  // int8 3x3: weights packed [C][3 dwords]
+void dwconv_dot4_pack(const shl_mi355x_conv_desc &d, const int8_t *hwo, uint32_t *dst);
 bool stem_supports(const shl_mi355x_conv_desc &d);
 void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
 size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);

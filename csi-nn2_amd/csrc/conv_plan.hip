@@ -204,6 +204,10 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         p->kernel_name = "conv_stem_i8_dot4";
     } else if (algo == SHL_MI355X_ALGO_DW) {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "dwconv_nhwc_i8" : "dwconv_nhwc_f16";
+        if (dwconv_dot4_supports(d)) {
+            p->kstride = 12;  // marks the [C][3 dwords] packing for launch_dwconv
+            w_bytes = (size_t)d.in_c * 12;
+        }
     } else {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_direct_i8" : "conv_direct_f16";
     }
@@ -239,6 +243,9 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         else if (algo == SHL_MI355X_ALGO_STEM)
             stem_pack_weights(d, reinterpret_cast<const int8_t *>(src),
                               reinterpret_cast<int32_t *>(host.data() + p->off_w));
+        else if (algo == SHL_MI355X_ALGO_DW && p->kstride == 12)
+            dwconv_dot4_pack(d, reinterpret_cast<const int8_t *>(src),
+                             reinterpret_cast<uint32_t *>(host.data() + p->off_w));
         else
             memcpy(host.data() + p->off_w, src, raw_w);
         int32_t *acc = reinterpret_cast<int32_t *>(host.data() + p->off_acc);
@@ -256,6 +263,14 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
                 int64_t sum = 0;
                 for (int k = 0; k < 27; ++k) sum += w8[oc * 27 + k];
                 acc[oc] = (int32_t)(-(int64_t)d.in_zp * sum);
+            }
+        }
+        if (algo == SHL_MI355X_ALGO_DW && p->kstride == 12) {
+            const int8_t *w8 = reinterpret_cast<const int8_t *>(src);  // [9][C]
+            for (int c = 0; c < d.in_c; ++c) {
+                int64_t sum = 0;
+                for (int tap = 0; tap < 9; ++tap) sum += w8[(size_t)tap * d.in_c + c];
+                acc[c] = (int32_t)(-(int64_t)d.in_zp * sum);
             }
         }
         if (algo == SHL_MI355X_ALGO_IGEMM && d.dtype == SHL_MI355X_I8) {

@@ -17,19 +17,6 @@ namespace shl {
 constexpr int TP = 64;        // tile edge in elements
 constexpr int PITCH8 = 80;    // LDS row pitch (bytes) for 64 int8 + pad, 16-byte aligned
 
-// 4x4 byte transpose: in[i] holds bytes (row i, col 0..3); out[j] holds (row 0..3, col j)
-__device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&in)[4], uint32_t (&out)[4])
-{
-    const uint32_t t0 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u);  // r0c0 r1c0 r0c1 r1c1
-    const uint32_t t1 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u);  // r2c0 r3c0 r2c1 r3c1
-    const uint32_t t2 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);  // r0c2 r1c2 r0c3 r1c3
-    const uint32_t t3 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
-    out[0] = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
-    out[1] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
-    out[2] = __builtin_amdgcn_perm(t3, t2, 0x05040100u);
-    out[3] = __builtin_amdgcn_perm(t3, t2, 0x07060302u);
-}
-
 // src [N][R][S] -> dst [N][S][R], 1-byte elements, R % 4 == 0 and S % 4 == 0.
 // (R, S) = (C, HW) for NCHW->NHWC and (HW, C) for NHWC->NCHW.
 __global__ __launch_bounds__(256) void transpose_i8_kernel(const uint8_t *__restrict__ src,
