@@ -54,6 +54,7 @@ struct ConvArgs {
     float clamp_hi;       //   r = rint(f / s_out) + zp_out before the conversion to int8
     int32_t debug;        // ablation switches for tools/kbench.py (SHL_MI355X_DEBUG): 1 skip K loop, 2 skip stores
     const void *pad_page; // PAD_PAGE_BYTES of HBM filled with the padding value (zp_in / 0)
+    int32_t out_nchw;     // igemm tile kernel: write the output tensor as NCHW (input is still NHWC)
     int32_t halo_px;      // halo kernel: capacity of one LDS patch buffer in pixels (multiple of 16)
     int32_t halo_pps;     // halo kernel: patch pieces a producer wave requests per K step
 };
@@ -205,6 +206,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 bool igemm_supports(const shl_mi355x_conv_desc &d);
 const char *igemm_variant(int64_t M, int64_t Co);  // "tile" | "regs" | "wave"
+bool igemm_fuses_nchw_out(int64_t M, int64_t Co);   // the tile kernel stores NCHW itself
 bool dwconv_supports(const shl_mi355x_conv_desc &d);
 bool dwconv_dot4_supports(const shl_mi355x_conv_desc &d);  // int8 3x3: weights packed [C][3 dwords]
 void dwconv_dot4_pack(const shl_mi355x_conv_desc &d, const int8_t *hwo, uint32_t *dst);

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    const bool staged = ((a.Co * ESIZE) & 15) == 0;  // epilogue flavour (decides its barrier)
+    const bool staged = a.out_nchw || ((a.Co * ESIZE) & 15) == 0;  // epilogue flavour (decides its barrier)
     if constexpr (PIPE) {
         if (wave >= G::NWAVES) {
             // ---- producer waves: nothing but DMA issue and counted waits.  Barrier sequence must
@@ -503,6 +503,8 @@ __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile
                         const int ch = wr * 32 * MI + ih * 64 + c;   // within the block's TBN
                         const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + ch);
                         char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
+                        // NCHW output: the staging block is [channel][pixel] instead
+                        char *dst_t = ws + c * PITCH + (j * 32 + frow) * ESIZE;
                         if constexpr (kI8) {
                             const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + ch);
                             const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + ch);
@@ -510,15 +512,72 @@ __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile
                             const int q1 = requant_i8_t<EPI>(acc[i][j][4 * g + 1] + ai.y, mu.y, bi.y, a);
                             const int q2 = requant_i8_t<EPI>(acc[i][j][4 * g + 2] + ai.z, mu.z, bi.z, a);
                             const int q3 = requant_i8_t<EPI>(acc[i][j][4 * g + 3] + ai.w, mu.w, bi.w, a);
-                            *reinterpret_cast<uint32_t *>(dst) = pack4_i8(q0, q1, q2, q3);
+                            if (a.out_nchw) {
+                                dst_t[0] = (char)q0;
+                                dst_t[PITCH] = (char)q1;
+                                dst_t[2 * PITCH] = (char)q2;
+                                dst_t[3 * PITCH] = (char)q3;
+                            } else {
+                                *reinterpret_cast<uint32_t *>(dst) = pack4_i8(q0, q1, q2, q3);
+                            }
                         } else {
                             const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
                             const uint32_t h1 = finish_f16(acc[i][j][4 * g + 1], bi.y, a);
                             const uint32_t h2 = finish_f16(acc[i][j][4 * g + 2], bi.z, a);
                             const uint32_t h3 = finish_f16(acc[i][j][4 * g + 3], bi.w, a);
-                            *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                            if (a.out_nchw) {
+                                *reinterpret_cast<uint16_t *>(dst_t) = (uint16_t)h0;
+                                *reinterpret_cast<uint16_t *>(dst_t + PITCH) = (uint16_t)h1;
+                                *reinterpret_cast<uint16_t *>(dst_t + 2 * PITCH) = (uint16_t)h2;
+                                *reinterpret_cast<uint16_t *>(dst_t + 3 * PITCH) = (uint16_t)h3;
+                            } else {
+                                *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                            }
                         }
                     }
+            if (a.out_nchw) {
+                // rows of the staging block are channels: a lane owns 16 bytes = 16 / ESIZE consecutive
+                // pixels of one channel.  Pixels are flat (n, oy, ox); a channel plane holds Ho*Wo of
+                // them, so the widest store that can neither straddle an image nor be misaligned is
+                // 16 B when Ho*Wo*ESIZE is a multiple of 16, else 4 B, else one element.
+                constexpr int EPC = 16 / ESIZE;  // elements per 16-byte chunk
+                const int hw = a.Ho * a.Wo;
+                const int gran = ((hw * ESIZE) & 15) == 0 ? 16 : (((hw * ESIZE) & 3) == 0 ? 4 : ESIZE);
+#pragma unroll
+                for (int it = 0; it < 64 / RPI; ++it) {
+                    const int row = it * RPI + srow;  // channel within the 64
+                    const int oc = co0 + wr * 32 * MI + ih * 64 + row;
+                    const int p0 = pix0 + wc * 64 + schunk * EPC;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(ws + row * PITCH + schunk * 16);
+                    if (oc >= a.Co || p0 >= a.M) continue;
+                    if (gran == 16) {
+                        const int n = p0 / hw, q = p0 - n * hw;
+                        *reinterpret_cast<uint4 *>(out + (((int64_t)n * a.Co + oc) * hw + q) * ESIZE) = v;
+                    } else if (gran == 4) {
+                        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int pk = p0 + k * (4 / ESIZE);
+                            if (pk >= a.M) break;
+                            const int n = pk / hw, q = pk - n * hw;
+                            *reinterpret_cast<uint32_t *>(out + (((int64_t)n * a.Co + oc) * hw + q) * ESIZE) = w4[k];
+                        }
+                    } else {
+                        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                        for (int k = 0; k < EPC; ++k) {
+                            const int pk = p0 + k;
+                            if (pk >= a.M) break;
+                            const int n = pk / hw, q = pk - n * hw;
+                            char *o = out + (((int64_t)n * a.Co + oc) * hw + q) * ESIZE;
+                            if constexpr (kI8)
+                                *reinterpret_cast<uint8_t *>(o) = (uint8_t)(w4[k >> 2] >> (8 * (k & 3)));
+                            else
+                                *reinterpret_cast<uint16_t *>(o) = (uint16_t)(w4[k >> 1] >> (16 * (k & 1)));
+                        }
+                    }
+                }
+                continue;
+            }
             // wave-local hand-over: the same wave wrote and reads; LDS operations complete in order
             const int oc_first = co0 + wr * 32 * MI + ih * 64 + schunk * (16 / ESIZE);
 #pragma unroll
@@ -827,6 +886,13 @@ static const char *variant_override()
 {
     static const char *v = getenv("SHL_MI355X_IGEMM");
     return v ? v : "";
+}
+
+bool igemm_fuses_nchw_out(int64_t M, int64_t Co)
+{
+    static const char *halo_env = getenv("SHL_MI355X_HALO");  // the halo kernel has no NCHW epilogue
+    if (halo_env && halo_env[0] == '1') return false;
+    return !strcmp(igemm_variant(M, Co), "tile");
 }
 
 const char *igemm_variant(int64_t M, int64_t Co)

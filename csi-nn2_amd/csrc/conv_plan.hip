@@ -411,6 +411,12 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
             int rc = launch_transpose(input_dev, plan->scratch_in, a.N, a.C, a.H * a.W, es, s);
             if (rc != SHL_MI355X_OK) return rc;
             a.in = plan->scratch_in;
+            // the tile kernel's epilogue stores NCHW itself; planes whose byte size is not a multiple of
+            // 4 (7x7 int8) would fall to element stores there and are cheaper through the re-layout pass
+            if (igemm_fuses_nchw_out(a.M, a.Co) && ((a.Ho * a.Wo * es) & 3) == 0) {
+                a.out_nchw = 1;
+                return launch_conv_igemm(a, d.dtype, SHL_MI355X_NHWC, s);
+            }
             a.out = plan->scratch_out;
             rc = launch_conv_igemm(a, d.dtype, SHL_MI355X_NHWC, s);
             if (rc != SHL_MI355X_OK) return rc;
