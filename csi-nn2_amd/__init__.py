@@ -108,6 +108,10 @@ class ReluParams(C.Structure):
                 ("n_shift", C.c_int32)]
 
 
+class DisoParams(C.Structure):
+    _fields_ = [("base", ParamsBase)]
+
+
 class SoftmaxParams(C.Structure):
     _fields_ = [("base", ParamsBase), ("axis", C.c_int32)]
 
@@ -132,7 +136,8 @@ ABI_STRUCTS = {"csinn_quant_info": QuantInfo, "csinn_tensor": Tensor, "csinn_ses
                "csinn_callback": Callback, "csinn_params_base": ParamsBase,
                "csinn_conv2d_params": Conv2dParams, "csinn_fc_params": FcParams,
                "csinn_relu_params": ReluParams, "csinn_model": Model,
-               "csinn_softmax_params": SoftmaxParams, "csinn_pool_params": PoolParams}
+               "csinn_softmax_params": SoftmaxParams, "csinn_pool_params": PoolParams,
+               "csinn_diso_params": DisoParams}
 
 
 # ---- library loading -------------------------------------------------------------------------
@@ -194,6 +199,7 @@ def load_hip():
         "shl_mi355x_conv_forward": (C.c_int, [vp, vp, vp, i32, vp]),
         "shl_mi355x_relu_i8": (C.c_int, [vp, vp, sz, f32, i32, f32, i32, i32, vp]),
         "shl_mi355x_relu_f16": (C.c_int, [vp, vp, sz, i32, vp]),
+        "shl_mi355x_add": (C.c_int, [vp, vp, vp, sz, i32, f32, i32, f32, i32, f32, i32, vp]),
         "shl_mi355x_layout_convert": (C.c_int, [vp, vp, C.c_int64, i32, i32, i32, i32, vp]),
         "shl_mi355x_global_avgpool2d": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, f32, i32, f32, i32, vp]),
         "shl_mi355x_softmax": (C.c_int, [vp, vp, i32, C.c_int64, i32, C.c_int64, f32, i32, f32, i32, vp]),
@@ -263,6 +269,9 @@ def load_frontend(kind="standalone", local=False):
             fn = getattr(lib, op + suffix)
             fn.restype = C.c_int
             fn.argtypes = [tp, tp] + ([C.c_void_p] if nargs == 3 else [tp, tp, C.c_void_p])
+    for suffix in ("_init", ""):
+        fn = getattr(lib, "csinn_add" + suffix)
+        fn.restype, fn.argtypes = C.c_int, [tp, tp, tp, C.c_void_p]
     lib._typed = True
     lib.kind = kind
     return lib
@@ -387,7 +396,8 @@ def fc_params(fe, keep, api, units, fuse_zp2bias=0, sess=None, name=b"fc"):
 
 def siso_params(fe, keep, api, kind, layout=LAYOUT_NHWC, axis=1, sess=None, name=b"siso"):
     """params block of a single-input single-output op: kind in relu | relu6 | pool | softmax"""
-    ctype = {"relu": ReluParams, "relu6": ReluParams, "pool": PoolParams, "softmax": SoftmaxParams}[kind]
+    ctype = {"relu": ReluParams, "relu6": ReluParams, "pool": PoolParams, "softmax": SoftmaxParams,
+             "add": DisoParams}[kind]
     p = fe.csinn_alloc_params(C.sizeof(ctype), sess)
     pc = C.cast(p, C.POINTER(ctype)).contents
     pc.base.api = api

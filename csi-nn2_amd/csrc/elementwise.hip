@@ -56,7 +56,46 @@ __global__ __launch_bounds__(256) void relu_f16_kernel(const uint16_t *in, uint1
     }
 }
 
+// elementwise add of two same-shape tensors (residual connections):
+// shl_ref_add_quant (source/reference/add.c:21-41 inside shl_ref_diso_callback_base,
+// utils.c:623-641): dequantise both inputs, fp32 add, requantise.
+__global__ __launch_bounds__(256) void add_kernel(const void *a, const void *b, void *out, size_t count, int i8,
+                                                  float sa, float za, float sb, float zb, float so, float zo)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        if (i8) {
+            const float x = __fmul_rn(__fsub_rn((float)static_cast<const int8_t *>(a)[i], za), sa);
+            const float y = __fmul_rn(__fsub_rn((float)static_cast<const int8_t *>(b)[i], zb), sb);
+            const float r = __fadd_rn(x, y);
+            static_cast<int8_t *>(out)[i] = (int8_t)sat8_from_float(__fadd_rn(rintf(__fdiv_rn(r, so)), zo));
+        } else {
+            const float x = f16_bits_to_float(static_cast<const uint16_t *>(a)[i]);
+            const float y = f16_bits_to_float(static_cast<const uint16_t *>(b)[i]);
+            static_cast<uint16_t *>(out)[i] = float_to_f16_bits_ref(__fadd_rn(x, y));
+        }
+    }
+}
+
 }  // namespace shl
+
+extern "C" int shl_mi355x_add(const void *input0_dev, const void *input1_dev, void *output_dev, size_t count,
+                              int32_t dtype, float scale0, int32_t zp0, float scale1, int32_t zp1, float out_scale,
+                              int32_t out_zp, void *stream)
+{
+    if (!input0_dev || !input1_dev || !output_dev || (dtype != SHL_MI355X_I8 && dtype != SHL_MI355X_F16)) {
+        shl::set_error("add: invalid argument");
+        return SHL_MI355X_EINVAL;
+    }
+    if (count == 0) return SHL_MI355X_OK;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(shl::add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, input0_dev,
+                       input1_dev, output_dev, count, dtype == SHL_MI355X_I8 ? 1 : 0, scale0, (float)zp0, scale1,
+                       (float)zp1, out_scale, (float)out_zp);
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}
 
 extern "C" int shl_mi355x_relu_f16(const uint16_t *input_dev, uint16_t *output_dev, size_t count, int32_t relu6,
                                    void *stream)

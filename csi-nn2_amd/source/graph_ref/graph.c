@@ -149,6 +149,25 @@ int shl_gref_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
     return record_siso(input, output, CSINN_OP_RELU6, params);
 }
 
+/* two activation inputs (either may also be a constant tensor), one output
+ * (shl_gref_diso_op, source/graph_ref/utils.c of the reference) */
+int shl_gref_add(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
+                 struct csinn_diso_params *params)
+{
+    struct shl_node *layer = shl_node_alloc(CSINN_OP_ADD, params->base.name, 2, 1, params);
+    struct shl_node *produced = shl_node_var_alloc(output->name, output);
+    struct csinn_tensor *ins[2] = {input0, input1};
+    for (int i = 0; i < 2; i++) {
+        if (ins[i]->is_const)
+            shl_node_add_in(layer, shl_node_const_var_alloc(ins[i]->name, ins[i]), i);
+        else
+            shl_node_add_in(layer, (struct shl_node *)ins[i]->data, i);
+    }
+    shl_node_add_out(layer, produced, 0);
+    output->data = produced;
+    return shl_gref_graph_insert(layer, shl_gref_get_graph(output->sess ? output->sess : input0->sess));
+}
+
 int shl_gref_global_avgpool2d(struct csinn_tensor *input, struct csinn_tensor *output,
                               struct csinn_pool_params *params)
 {
@@ -172,6 +191,8 @@ int shl_gref_call_layer_func(void *fn, struct shl_node *node)
         case CSINN_OP_GLOBAL_AVGPOOL2D:
         case CSINN_OP_SOFTMAX:
             return f(node->in[0]->data, node->out[0]->data, params);
+        case CSINN_OP_ADD:
+            return f(node->in[0]->data, node->in[1]->data, node->out[0]->data, params);
         case CSINN_OP_CONV2D:
         case CSINN_OP_CONV2D_RELU:
         case CSINN_OP_CONV2D_RELU6:
@@ -198,7 +219,7 @@ struct csinn_callback *shl_gref_best_callback(struct shl_node *node)
     return params->cb;
 }
 
-static struct csinn_callback g_est_only[12];
+static struct csinn_callback g_est_only[16];
 
 static struct csinn_callback *gref_cb_map(int op, int dtype)
 {
@@ -215,6 +236,7 @@ static struct csinn_callback *gref_cb_map(int op, int dtype)
         {CSINN_OP_RELU6, shl_gref_relu6},
         {CSINN_OP_GLOBAL_AVGPOOL2D, shl_gref_global_avgpool2d},
         {CSINN_OP_SOFTMAX, shl_gref_softmax},
+        {CSINN_OP_ADD, shl_gref_add},
     };
     for (unsigned i = 0; i < sizeof(table) / sizeof(table[0]); i++) {
         if (table[i].op == op) {

@@ -11,7 +11,7 @@ void shl_mi355x_registry_put(void *params, shl_mi355x_conv_plan *plan);
 shl_mi355x_conv_plan *shl_mi355x_registry_get(void *params);
 
 /* Host <-> HBM staging for tensors that do not already live on the device.
- * slot: 0 = first input, 1 = output.
+ * slot: 0 = first input, 1 = output, 2 = second input.
  *   stage_in        device address holding the tensor's bytes (uploads host tensors)
  *   stage_out_begin device address the kernel should write
  *   stage_out_end   downloads + synchronises for host tensors; CSINN_TRUE on success */

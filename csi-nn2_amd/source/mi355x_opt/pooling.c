@@ -97,3 +97,40 @@ int shl_mi355x_softmax_exec(struct csinn_tensor *input, struct csinn_tensor *out
     }
     return shl_mi355x_stage_out_end(output, out_dev);
 }
+
+/* residual add, two same-shape inputs (source/reference/add.c:21-41); shapes that would need the
+ * reference's broadcasting are refused so that they fall to an error rather than a wrong answer */
+int shl_mi355x_add_exec(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
+                        struct csinn_diso_params *params)
+{
+    (void)params;
+    int dtype;
+    int rc = check_io("add", input0, output, &dtype);
+    if (rc != CSINN_TRUE) return rc;
+    if (dtype_code(input1) != dtype || input1->qinfo == NULL ||
+        (dtype == SHL_MI355X_F16 && input1->qinfo->scale != 1.0f)) {
+        shl_debug_error("mi355x: add: second input dtype / quantisation unsupported\n");
+        return CSINN_UNSUPPORT_DTYPE;
+    }
+    if (input0->dim_count != input1->dim_count || input0->dim_count != output->dim_count) {
+        shl_debug_error("mi355x: add: broadcasting is not supported\n");
+        return CSINN_FALSE;
+    }
+    for (int i = 0; i < input0->dim_count; i++)
+        if (input0->dim[i] != input1->dim[i] || input0->dim[i] != output->dim[i]) {
+            shl_debug_error("mi355x: add: broadcasting is not supported\n");
+            return CSINN_FALSE;
+        }
+    const void *a_dev = shl_mi355x_stage_in(input0, 0);
+    const void *b_dev = shl_mi355x_stage_in(input1, 2);
+    void *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    if (a_dev == NULL || b_dev == NULL || out_dev == NULL) return CSINN_FALSE;
+    int st = shl_mi355x_add(a_dev, b_dev, out_dev, (size_t)csinn_tensor_size(output), dtype, input0->qinfo->scale,
+                            input0->qinfo->zero_point, input1->qinfo->scale, input1->qinfo->zero_point,
+                            output->qinfo->scale, output->qinfo->zero_point, shl_mi355x_get_stream());
+    if (st != SHL_MI355X_OK) {
+        shl_debug_error("mi355x: add failed (%d): %s\n", st, shl_mi355x_last_error());
+        return CSINN_FALSE;
+    }
+    return shl_mi355x_stage_out_end(output, out_dev);
+}

@@ -78,7 +78,8 @@ static int gpu_native(int (*exec)())
 {
     return exec == (int (*)())shl_mi355x_conv2d_exec || exec == (int (*)())shl_mi355x_fullyconnected_exec ||
            exec == (int (*)())shl_mi355x_relu_exec || exec == (int (*)())shl_mi355x_relu6_exec ||
-           exec == (int (*)())shl_mi355x_global_avgpool2d_exec || exec == (int (*)())shl_mi355x_softmax_exec;
+           exec == (int (*)())shl_mi355x_global_avgpool2d_exec || exec == (int (*)())shl_mi355x_softmax_exec ||
+           exec == (int (*)())shl_mi355x_add_exec;
 }
 
 static int op_arity(int type)
@@ -89,6 +90,8 @@ static int op_arity(int type)
         case CSINN_OP_GLOBAL_AVGPOOL2D:
         case CSINN_OP_SOFTMAX:
             return 1;
+        case CSINN_OP_ADD:
+            return 2;
         case CSINN_OP_CONV2D:
         case CSINN_OP_CONV2D_RELU:
         case CSINN_OP_CONV2D_RELU6:
@@ -134,9 +137,12 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
         struct dev_tensor *out = lookup(ds, n->out[0]);
         int (*f)() = params->cb->exec;
         int rc;
-        if (op_arity(n->type) == 1)
+        if (op_arity(n->type) == 1) {
             rc = f(&in->shadow, &out->shadow, params);
-        else
+        } else if (op_arity(n->type) == 2) { /* add: the second operand is an activation or a constant */
+            struct dev_tensor *in1 = lookup(ds, n->in[1]);
+            rc = f(&in->shadow, in1 ? (void *)&in1->shadow : n->in[1]->data, &out->shadow, params);
+        } else
             rc = f(&in->shadow, &out->shadow, n->in[1]->data, n->in[2]->data, params);
         if (rc != CSINN_TRUE) {
             shl_debug_error("mi355x: layer %d (%s) failed while building the device graph\n", i,
@@ -170,7 +176,7 @@ int shl_mi355x_session_setup(struct csinn_session *sess)
                            n->name ? n->name : "?", n->type);
             return rc;
         }
-        tensors += 1;
+        tensors += 2;
     }
     struct dev_session *ds = calloc(1, sizeof(*ds));
     ds->sess = sess;
@@ -184,6 +190,16 @@ int shl_mi355x_session_setup(struct csinn_session *sess)
             shl_debug_error("mi355x: layer %d consumes a tensor that no earlier layer produces\n", i);
             ok = 0;
             break;
+        }
+        if (op_arity(n->type) == 2 && lookup(ds, n->in[1]) == NULL) {
+            /* a constant second operand: upload it once, keep it resident */
+            struct csinn_tensor *c = n->in[1]->data;
+            struct dev_tensor *d = c->is_const && c->data ? adopt(ds, n->in[1]) : NULL;
+            if (d == NULL || shl_mi355x_upload(d->dev, c->data, d->bytes, ds->stream) != SHL_MI355X_OK) {
+                shl_debug_error("mi355x: layer %d: second operand is neither produced earlier nor constant\n", i);
+                ok = 0;
+                break;
+            }
         }
         ok = adopt(ds, n->out[0]) != NULL;
     }

@@ -190,7 +190,7 @@ const char *shl_mi355x_params_kernel_name(void *params)
 static struct {
     void *dev;
     size_t bytes;
-} g_stage[2];
+} g_stage[3]; /* 0: first input, 1: output, 2: second input */
 
 static void *stage_buffer(int slot, size_t bytes)
 {
@@ -299,6 +299,7 @@ void shl_target_init_mi355x(void)
         reg(dts[i], CSINN_OP_RELU6, NULL, shl_mi355x_relu6_exec, shl_gref_relu6);
         reg(dts[i], CSINN_OP_GLOBAL_AVGPOOL2D, NULL, shl_mi355x_global_avgpool2d_exec, shl_gref_global_avgpool2d);
         reg(dts[i], CSINN_OP_SOFTMAX, NULL, shl_mi355x_softmax_exec, shl_gref_softmax);
+        reg(dts[i], CSINN_OP_ADD, NULL, shl_mi355x_add_exec, shl_gref_add);
     }
     shl_register_op_callback(CSINN_MI355X, shl_cb_map_mi355x);
     shl_register_runtime_callback(CSINN_MI355X, shl_mi355x_runtime_callback);

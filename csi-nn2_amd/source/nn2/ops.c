@@ -159,3 +159,25 @@ int csinn_softmax(struct csinn_tensor *input, struct csinn_tensor *output,
 {
     return run3(&params->base, input, output, params);
 }
+
+/* source/nn2/add.c:26-55: two inputs, one output */
+int csinn_add_init(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
+                   struct csinn_diso_params *params)
+{
+    int rc = shl_op_callback_map(&params->base, CSINN_OP_ADD, input0->dtype);
+    if (rc != CSINN_TRUE) return rc;
+    int (*init)() = shl_get_init_cb(&params->base);
+    if (init != NULL) {
+        rc = init(input0, input1, output, params);
+        if (rc != CSINN_TRUE) return rc;
+    }
+    return CSINN_TRUE;
+}
+int csinn_add(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
+              struct csinn_diso_params *params)
+{
+    int (*fn)() = shl_get_p0_cb(&params->base);
+    if (fn == NULL) return CSINN_CALLBACK_UNSET;
+    int rc = fn(input0, input1, output, params);
+    return rc == CSINN_TRUE ? CSINN_TRUE : rc;
+}

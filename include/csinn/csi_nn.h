@@ -51,6 +51,11 @@ int csinn_relu6_init(struct csinn_tensor *input, struct csinn_tensor *output,
                      struct csinn_relu_params *params);
 int csinn_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
                 struct csinn_relu_params *params);
+/* residual add of two same-shape tensors (source/nn2/add.c) */
+int csinn_add_init(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
+                   struct csinn_diso_params *params);
+int csinn_add(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
+              struct csinn_diso_params *params);
 /* MobileNet tail (source/nn2/global_avgpool2d.c, softmax.c of the reference) */
 int csinn_global_avgpool2d_init(struct csinn_tensor *input, struct csinn_tensor *output,
                                 struct csinn_pool_params *params);

@@ -115,6 +115,7 @@ enum csinn_op_enum {
     CSINN_OP_CONV2D = 28,
     CSINN_OP_CONV2D_RELU = 29,
     CSINN_OP_CONV2D_RELU6 = 30,
+    CSINN_OP_ADD = 3,
     CSINN_OP_CONV2D_CHANNEL = 31,
     CSINN_OP_CONV2D_CHANNEL_RELU = 32,
     CSINN_OP_CONV2D_CHANNEL_RELU6 = 33,
@@ -336,6 +337,11 @@ struct csinn_fc_params {
 
 /* ---- params of the ops that sit between MobileNet convolutions */
 struct csinn_siso_params {
+    struct csinn_params_base base;
+};
+
+/* two inputs, one output: add (csinn_data_structure.h:791-793 of the reference) */
+struct csinn_diso_params {
     struct csinn_params_base base;
 };
 

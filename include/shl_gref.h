@@ -64,6 +64,8 @@ int shl_gref_relu(struct csinn_tensor *input, struct csinn_tensor *output,
                   struct csinn_relu_params *params);
 int shl_gref_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
                    struct csinn_relu_params *params);
+int shl_gref_add(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
+                 struct csinn_diso_params *params);
 int shl_gref_global_avgpool2d(struct csinn_tensor *input, struct csinn_tensor *output,
                               struct csinn_pool_params *params);
 int shl_gref_softmax(struct csinn_tensor *input, struct csinn_tensor *output,

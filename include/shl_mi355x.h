@@ -195,6 +195,12 @@ int shl_mi355x_relu_i8(const int8_t *input_dev, int8_t *output_dev, size_t count
 int shl_mi355x_relu_f16(const uint16_t *input_dev, uint16_t *output_dev, size_t count, int32_t relu6,
                         void *stream);
 
+/* elementwise add of two same-shape tensors (residual connection): shl_ref_add_quant
+ * (source/reference/add.c:21-41): dequantise both, fp32 add, requantise.  f16: scales ignored. */
+int shl_mi355x_add(const void *input0_dev, const void *input1_dev, void *output_dev, size_t count,
+                   int32_t dtype, float scale0, int32_t zp0, float scale1, int32_t zp1, float out_scale,
+                   int32_t out_zp, void *stream);
+
 /* global average pooling over H*W (`pixels`) of an int8 / binary16 tensor:
  * shl_ref_global_avgpool2d_quant (source/reference/global_averagepool.c:21-50 ->
  * averagepool.c:21-119), same fp32 summation order.  Output is [N, C] (NHWC [N,1,1,C] or NCHW

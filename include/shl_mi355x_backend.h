@@ -55,6 +55,8 @@ int shl_mi355x_relu_exec(struct csinn_tensor *input, struct csinn_tensor *output
                          struct csinn_relu_params *params);
 int shl_mi355x_relu6_exec(struct csinn_tensor *input, struct csinn_tensor *output,
                           struct csinn_relu_params *params);
+int shl_mi355x_add_exec(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
+                        struct csinn_diso_params *params);
 int shl_mi355x_global_avgpool2d_exec(struct csinn_tensor *input, struct csinn_tensor *output,
                                      struct csinn_pool_params *params);
 int shl_mi355x_softmax_exec(struct csinn_tensor *input, struct csinn_tensor *output,

@@ -294,6 +294,18 @@ static void oracle_store(void *out, int64_t idx, float v, int dtype, float scale
         ((int16_t *)out)[idx] = oracle_float_to_f16(v);
 }
 
+/* shl_ref_add_quant (source/reference/add.c:21-41) for equal shapes: the diso callback base
+ * (utils.c:623-641) dequantises both inputs, element_add_f32 adds in fp32, the output is
+ * requantised.  dtype: 0 int8, 1 binary16. */
+void oracle_add(const void *a, const void *b, void *out, int64_t count, int32_t dtype, float sa, int32_t za,
+                float sb, int32_t zb, float so, int32_t zo)
+{
+    for (int64_t i = 0; i < count; ++i) {
+        const float r = oracle_load(a, i, dtype, sa, za) + oracle_load(b, i, dtype, sb, zb);
+        oracle_store(out, i, r, dtype, so, zo);
+    }
+}
+
 /* shl_ref_global_avgpool2d_quant (source/reference/global_averagepool.c:21-50): the window is the
  * whole image, stride 1, no padding -> shl_ref_avgpool2d_{nhwc,nchw}_f32 (averagepool.c:21-119):
  * total += x for filter_y, filter_x in order (fp32), filter_count counted in float,

@@ -108,6 +108,8 @@ void oracle_relu_f16(const int16_t *in, int16_t *out, int64_t count, int32_t rel
 void oracle_global_avgpool2d(const void *in, void *out, int32_t dtype, int32_t nhwc, int32_t batch,
                              int32_t channels, int32_t height, int32_t width, float in_scale,
                              int32_t in_zp, float out_scale, int32_t out_zp);
+void oracle_add(const void *a, const void *b, void *out, int64_t count, int32_t dtype, float sa, int32_t za,
+                float sb, int32_t zb, float so, int32_t zo);
 void oracle_softmax(const void *in, void *out, int32_t dtype, int64_t outer, int32_t cnt, int64_t inner,
                     float in_scale, int32_t in_zp, float out_scale, int32_t out_zp);
 

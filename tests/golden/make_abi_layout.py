@@ -29,6 +29,7 @@ STRUCTS = {
                             "conv_extra.conv_mode", "conv_extra.fuse_zp2bias"],
     "csinn_fc_params": ["base", "units", "fc_extra.fuse_zp2bias"],
     "csinn_siso_params": ["base"],
+    "csinn_diso_params": ["base"],
     "csinn_relu_params": ["base", "n", "n_multiplier", "n_shift"],
     "csinn_softmax_params": ["base", "axis"],
     "csinn_pool_params": ["base", "pool_type", "filter_height", "filter_width", "stride_height", "stride_width",
@@ -43,7 +44,7 @@ ENUMS = [
     "CSINN_MEM_TYPE_DMABUF", "CSINN_MEM_TYPE_CPU_ACC", "CSINN_QUANT_INT8_ASYM", "CSINN_QUANT_INT8_SYM",
     "CSINN_QUANT_FLOAT16", "CSINN_QUANT_INT8_ASYM_W_SYM", "CSINN_REF", "CSINN_GREF", "CSINN_ASP",
     "CSINN_API_SIZE", "CSINN_RM_LAYER", "CSINN_RM_CPU_GRAPH", "CSINN_RM_CPU_BASE_HYBRID",
-    "CSINN_OP_CONV2D", "CSINN_OP_CONV2D_RELU", "CSINN_OP_CONV2D_RELU6", "CSINN_OP_DEPTHWISE_CONV2D",
+    "CSINN_OP_ADD", "CSINN_OP_CONV2D", "CSINN_OP_CONV2D_RELU", "CSINN_OP_CONV2D_RELU6", "CSINN_OP_DEPTHWISE_CONV2D",
     "CSINN_OP_DEPTHWISE_CONV2D_RELU", "CSINN_OP_DEPTHWISE_CONV2D_RELU6", "CSINN_OP_GROUP_CONV2D",
     "CSINN_OP_FULLYCONNECTED", "CSINN_OP_GLOBAL_AVGPOOL2D", "CSINN_OP_RELU", "CSINN_OP_RELU6",
     "CSINN_OP_SOFTMAX", "CSINN_OP_SIZE", "CSINN_TENSOR", "CSINN_SUBGRAPH", "CSINN_OP_AND_UTILS_SIZE",

@@ -25,6 +25,8 @@ def main():
         out = tail.siso_run(fe, pkg.API_REF, case)
         blob[case["name"] + "/x"] = case["x"].view(np.uint16) if case["dtype"] == "f16" else case["x"]
         blob[case["name"] + "/out"] = out.view(np.uint16) if case["dtype"] == "f16" else out
+        if "y" in case:
+            blob[case["name"] + "/y"] = case["y"].view(np.uint16) if case["dtype"] == "f16" else case["y"]
         print("%-28s out %s" % (case["name"], out.shape))
     for dtype, layout in (("int8", "NHWC"), ("f16", "NCHW")):
         net = tail.MiniNet(dtype, layout)
@@ -36,6 +38,17 @@ def main():
             blob[key + "/x"] = x.view(np.uint16) if dtype == "f16" else x
             blob[key + "/out"] = y.view(np.uint16) if dtype == "f16" else y
             print("%-28s out %s argmax %d" % (key, y.shape, int(np.argmax(y.astype(np.float32)))))
+        net.close(fe)
+    for dtype, layout in (("int8", "NHWC"), ("f16", "NCHW")):
+        net = tail.ResidualNet(dtype, layout)
+        net.build(fe, pkg.API_REF)
+        for k in range(2):
+            x = net.input(k)
+            y = net.run(fe, x)
+            key = "resnet_block_%s_%s_%d" % (dtype, layout, k)
+            blob[key + "/x"] = x.view(np.uint16) if dtype == "f16" else x
+            blob[key + "/out"] = y.view(np.uint16) if dtype == "f16" else y
+            print("%-28s out %s" % (key, y.shape))
         net.close(fe)
     path = os.path.join(HERE, "tail_cases.npz")
     np.savez_compressed(path, **blob)

@@ -47,6 +47,13 @@ def tail_cases():
     add("relu_f16", "relu", xr, "f16")
     add("relu6_f16", "relu6", xr, "f16")
     add("relu_i8", "relu", i8((3, 50)), "int8", in_q=(0.0625, -3), out_q=(0.047, 5))
+    # residual add of two same-shape tensors with different quantisation records
+    add("add_i8_exact", "add", i8((2, 7, 7, 24)), "int8", in_q=(2.0 ** -4, -5), out_q=(2.0 ** -3, 9))
+    out[-1].update(y=i8((2, 7, 7, 24)), in1_q=_q(2.0 ** -5, 12))
+    add("add_i8_general", "add", i8((1, 33, 5, 3)), "int8", "NCHW", in_q=(0.037, 4), out_q=(0.071, -20))
+    out[-1].update(y=i8((1, 33, 5, 3)), in1_q=_q(0.052, -17))
+    add("add_f16", "add", f16((2, 9, 4, 6), 5.0), "f16")
+    out[-1].update(y=f16((2, 9, 4, 6), 5.0), in1_q=_q(1.0, 0))
     return out
 
 
@@ -64,6 +71,13 @@ def siso_oracle(case):
                                C.c_int32(zo), C.c_int32(kind == "relu6"))
         else:
             lib.oracle_relu_f16(vp(x), vp(out), C.c_int64(x.size), C.c_int32(kind == "relu6"))
+        return out
+    if kind == "add":
+        y = np.ascontiguousarray(case["y"])
+        out = np.empty_like(x)
+        s1, z1 = case["in1_q"]
+        lib.oracle_add(vp(x), vp(y), vp(out), C.c_int64(x.size), C.c_int32(dt), C.c_float(si), C.c_int32(zi),
+                       C.c_float(s1), C.c_int32(z1), C.c_float(so), C.c_int32(zo))
         return out
     if kind == "pool":
         nhwc = case["layout"] == "NHWC"
@@ -113,14 +127,26 @@ def siso_run(fe, api, case, device=None):
     kind = case["kind"]
     params = pkg.siso_params(fe, keep, api, kind, layout, case["axis"], sess)
     stem = {"relu": "csinn_relu", "relu6": "csinn_relu6", "pool": "csinn_global_avgpool2d",
-            "softmax": "csinn_softmax"}[kind]
+            "softmax": "csinn_softmax", "add": "csinn_add"}[kind]
     init, run = getattr(fe, stem + "_init"), getattr(fe, stem)
-    rc = init(t_in, t_out, params)
+    args = (t_in, t_out, params)
+    dev_in1 = None
+    if kind == "add":
+        y = np.ascontiguousarray(case["y"])
+        if device is not None:
+            dev_in1 = device.alloc(y.nbytes)
+            device.upload(dev_in1, y)
+        t_in1 = pkg.make_tensor(fe, keep, y.shape, dt, layout, data=y, scales=(case["in1_q"][0],),
+                                zps=(case["in1_q"][1],), name=b"in1", sess=sess, device_ptr=dev_in1)
+        args = (t_in, t_in1, t_out, params)
+    rc = init(*args)
     if rc != pkg.CSINN_TRUE:
         raise pkg.MI355XError("%s_init returned %d" % (stem, rc))
-    rc = run(t_in, t_out, params)
+    rc = run(*args)
     if rc != pkg.CSINN_TRUE:
         raise pkg.MI355XError("%s returned %d" % (stem, rc))
+    if dev_in1 is not None:
+        device.free(dev_in1)
     if device is not None:
         out = device.download(dev_out, out.shape, out.dtype)
         device.free(dev_in)
@@ -288,3 +314,84 @@ class MiniNet:
     def close(self, fe):
         fe.csinn_session_deinit(self._sess)
         fe.csinn_free_session(self._sess)
+
+
+class ResidualNet:
+    """data -> conv3x3 (C -> C) -> add(conv_out, data) -> relu: one ResNet-style block in graph mode;
+    the graph input feeds two layers and `add` consumes two activation tensors."""
+
+    def __init__(self, dtype="int8", layout="NHWC", seed=11, hw=12, c=32):
+        self.dtype, self.layout, self.hw, self.c = dtype, layout, hw, c
+        int8 = dtype == "int8"
+        self.q_in = _q(2.0 ** -4, -5) if int8 else _q(1.0, 0)
+        case = cases.make_case(seed, layout=layout, dtype=dtype, n=1, h=hw, w=hw, c=c, co=c)
+        if int8:
+            case["in_scale"], case["in_zp"] = self.q_in
+            case["k_scale"] = np.array([2.0 ** -7], dtype=np.float32)
+            case["b_scale"] = (np.float32(case["in_scale"]) * case["k_scale"]).astype(np.float32)
+            case["out_scale"], case["out_zp"] = 2.0 ** -3, 3
+        self.case = case
+        self.q_conv = _q(case["out_scale"], case["out_zp"])
+        self.q_add = _q(2.0 ** -2, -30) if int8 else _q(1.0, 0)
+        self.q_out = _q(2.0 ** -3, -128) if int8 else _q(1.0, 0)
+
+    def input(self, k):
+        rng = np.random.default_rng(500 + k)
+        shape = self.case["in_shape"]
+        return rng.integers(-100, 100, shape, dtype=np.int8) if self.dtype == "int8" else rng.standard_normal(shape).astype(np.float16)
+
+    def oracle(self, x):
+        case = dict(self.case)
+        case["input"] = np.ascontiguousarray(x)
+        y = cases.oracle_run(case, "ref" if self.dtype == "int8" else "f16")
+        s = siso_oracle(dict(kind="add", x=y, y=x, dtype=self.dtype, layout=self.layout, axis=1, in_q=self.q_conv,
+                             in1_q=self.q_in, out_q=self.q_add))
+        return siso_oracle(dict(kind="relu", x=s, dtype=self.dtype, layout=self.layout, axis=1, in_q=self.q_add,
+                                out_q=self.q_out))
+
+    def build(self, fe, api):
+        keep = pkg.Keep()
+        sess = fe.csinn_alloc_session()
+        sc = sess.contents
+        int8 = self.dtype == "int8"
+        dt = pkg.DTYPE_INT8 if int8 else pkg.DTYPE_FLOAT16
+        sc.base_api, sc.base_run_mode, sc.base_dtype = api, pkg.RM_CPU_GRAPH, dt
+        sc.base_quant_type = pkg.QUANT_INT8_ASYM_W_SYM if int8 else pkg.QUANT_FLOAT16
+        sc.debug_level = 0
+        fe.csinn_session_init(sess)
+        fe.csinn_set_input_number(1, sess)
+        fe.csinn_set_output_number(1, sess)
+        nhwc = self.layout == "NHWC"
+        act_l = pkg.LAYOUT_NHWC if nhwc else pkg.LAYOUT_NCHW
+        case = self.case
+
+        def T(dims, q, name, data=None, const=0, layout=act_l, dtype=dt, scales=None):
+            return pkg.make_tensor(fe, keep, dims, dtype, layout, data=data, is_const=const, name=name, sess=sess,
+                                   scales=scales if scales is not None else (q[0],), zps=(q[1] if q else 0,))
+        t_in = T(case["in_shape"], self.q_in, b"data")
+        t_c = T(case["out_shape"], self.q_conv, b"conv_out")
+        t_s = T(case["out_shape"], self.q_add, b"sum")
+        t_o = T(case["out_shape"], self.q_out, b"out")
+        t_w = T(case["w_shape"], None, b"w", case["kernel"], 1, pkg.LAYOUT_OHWI if nhwc else pkg.LAYOUT_OIHW,
+                scales=tuple(case["k_scale"]))
+        t_b = T((case["co"],), None, b"b", case["bias"], 1, pkg.LAYOUT_O, pkg.DTYPE_INT32 if int8 else dt,
+                scales=tuple(case["b_scale"]))
+        pc = pkg.conv_params(fe, keep, api, act_l, case["stride"], case["pad"], case["dilation"], 1, 0, sess, b"conv")
+        pa = pkg.siso_params(fe, keep, api, "add", act_l, 1, sess, b"add")
+        pr = pkg.siso_params(fe, keep, api, "relu", act_l, 1, sess, b"relu")
+        assert fe.csinn_conv2d_init(t_in, t_c, t_w, t_b, pc) == pkg.CSINN_TRUE
+        assert fe.csinn_add_init(t_c, t_in, t_s, pa) == pkg.CSINN_TRUE
+        assert fe.csinn_relu_init(t_s, t_o, pr) == pkg.CSINN_TRUE
+        fe.csinn_set_tensor_entry(t_in, sess)
+        fe.csinn_set_input(0, t_in, sess)
+        assert fe.csinn_conv2d(t_in, t_c, t_w, t_b, pc) == pkg.CSINN_TRUE
+        assert fe.csinn_add(t_c, t_in, t_s, pa) == pkg.CSINN_TRUE
+        assert fe.csinn_relu(t_s, t_o, pr) == pkg.CSINN_TRUE
+        fe.csinn_set_output(0, t_o, sess)
+        rc = fe.csinn_session_setup(sess)
+        assert rc == pkg.CSINN_TRUE or getattr(fe, "kind", "") == "reference"
+        self._keep, self._sess, self._out_shape, self._in_q = keep, sess, case["out_shape"], self.q_in
+        return sess
+
+    run = MiniNet.run
+    close = MiniNet.close

@@ -57,9 +57,24 @@ def test_oracle_replay_of_the_mini_model_matches_the_reference_graph_run(dtype, 
         x, want = golden("mininet_%s_%s_%d" % (dtype, layout, k), dtype)
         assert np.array_equal(x.view(np.uint8), net.input(k).view(np.uint8))
         got = net.oracle(x)
-        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+        if dtype == "int8":
+            assert np.array_equal(got, want)
+        else:  # the reference's NCHW fp32 convolution is an FMA sgemm with its own summation order
+            assert_same(got, want, dtype, "mininet oracle replay")
         outs.append(want)
     assert not np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8)), "the two inputs must be told apart"
+
+
+@pytest.mark.parametrize("dtype,layout", [("int8", "NHWC"), ("f16", "NCHW")])
+def test_oracle_replay_of_the_residual_block_matches_the_reference_graph_run(dtype, layout):
+    net = tail.ResidualNet(dtype, layout)
+    for k in range(2):
+        x, want = golden("resnet_block_%s_%s_%d" % (dtype, layout, k), dtype)
+        assert np.array_equal(x.view(np.uint8), net.input(k).view(np.uint8))
+        if dtype == "int8":
+            assert np.array_equal(net.oracle(x), want)
+        else:
+            assert_same(net.oracle(x), want, dtype, "residual block oracle replay")
 
 
 @pytest.mark.skipif(not cases.have_reference(), reason="oracle/_ref/libshl_ref_x86.so not present")
@@ -127,6 +142,20 @@ def test_mini_model_runs_device_resident_as_one_hipgraph(gpu, dtype, layout):
         assert_same(got, want, dtype, "mininet %s input %d" % (dtype, k), lsb=1)
     plans_before = opt.shl_mi355x_live_plans(None)
     assert plans_before >= 4
+    net.close(fe)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,layout", [("int8", "NHWC"), ("f16", "NCHW")])
+def test_residual_block_runs_device_resident(gpu, dtype, layout):
+    """conv -> add(conv, input) -> relu: the graph input feeds two layers, add takes two activations"""
+    fe, hip, opt = gpu
+    net = tail.ResidualNet(dtype, layout)
+    sess = net.build(fe, pkg.API_MI355X)
+    assert opt.shl_mi355x_session_is_device_resident(sess) == 2
+    for k in (0, 1, 0):
+        x, want = golden("resnet_block_%s_%s_%d" % (dtype, layout, k), dtype)
+        assert_same(net.run(fe, x), want, dtype, "residual block %s input %d" % (dtype, k))
     net.close(fe)
 
 
