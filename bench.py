@@ -353,7 +353,10 @@ def main():
                 "images_per_sec": 1.0 / dt_s, "ms_per_image": dt_s * 1e3, "layers": ms.n_layers,
                 "device_mode": {0: "host-staged", 1: "device eager", 2: "device hipGraph"}[mode]}
             ms.close()
-        if not args.no_cpu_baseline:
+        if world > 1:  # the CPU baseline is a property of the node: measured by the N=1 run only
+            result["cpu_baseline"] = {"value": None, "unit": "GOPS", "cores": 0, "kind": "reference",
+                                      "sample": "measured by the N=1 run only"}
+        elif not args.no_cpu_baseline:
             result["cpu_baseline"] = run_cpu_baseline(args)
         else:
             result["cpu_baseline"] = {"value": None, "unit": "GOPS", "cores": 0, "kind": "port", "sample": "skipped"}

@@ -50,9 +50,8 @@ static int validate(const shl_mi355x_conv_desc &d)
         return SHL_MI355X_EINVAL;
     if (d.group <= 0 || d.in_c % d.group || d.out_c % d.group) return SHL_MI355X_EINVAL;
     if (d.pad_top < 0 || d.pad_left < 0) return SHL_MI355X_EINVAL;
-    // every output position must start inside the padded image
-    if ((int64_t)(d.out_h - 1) * d.stride_h - d.pad_top >= d.in_h) return SHL_MI355X_EINVAL;
-    if ((int64_t)(d.out_w - 1) * d.stride_w - d.pad_left >= d.in_w) return SHL_MI355X_EINVAL;
+    // output positions that lie entirely in the bottom / right padding are legal (1-wide kernels
+    // with pad_right: the reference and torch produce bias there); every tap is bounds-checked
     if (d.dtype == SHL_MI355X_I8 && !(d.out_scale > 0.0f)) return SHL_MI355X_EINVAL;
     return SHL_MI355X_OK;
 }
