@@ -129,6 +129,9 @@ EST_CONV(shl_gref_conv2d_relu6, CSINN_OP_CONV2D_RELU6)
 EST_CONV(shl_gref_depthwise_conv2d, CSINN_OP_DEPTHWISE_CONV2D)
 EST_CONV(shl_gref_depthwise_conv2d_relu, CSINN_OP_DEPTHWISE_CONV2D_RELU)
 EST_CONV(shl_gref_depthwise_conv2d_relu6, CSINN_OP_DEPTHWISE_CONV2D_RELU6)
+EST_CONV(shl_gref_group_conv2d, CSINN_OP_GROUP_CONV2D)
+EST_CONV(shl_gref_group_conv2d_relu, CSINN_OP_GROUP_CONV2D_RELU)
+EST_CONV(shl_gref_group_conv2d_relu6, CSINN_OP_GROUP_CONV2D_RELU6)
 
 int shl_gref_fullyconnected(struct csinn_tensor *input, struct csinn_tensor *output,
                             struct csinn_tensor *weights, struct csinn_tensor *bias,
@@ -200,6 +203,8 @@ int shl_gref_call_layer_func(void *fn, struct shl_node *node)
         case CSINN_OP_DEPTHWISE_CONV2D_RELU:
         case CSINN_OP_DEPTHWISE_CONV2D_RELU6:
         case CSINN_OP_GROUP_CONV2D:
+        case CSINN_OP_GROUP_CONV2D_RELU:
+        case CSINN_OP_GROUP_CONV2D_RELU6:
         case CSINN_OP_FULLYCONNECTED:
             return f(node->in[0]->data, node->out[0]->data, node->in[1]->data, node->in[2]->data,
                      params);
@@ -219,7 +224,7 @@ struct csinn_callback *shl_gref_best_callback(struct shl_node *node)
     return params->cb;
 }
 
-static struct csinn_callback g_est_only[16];
+static struct csinn_callback g_est_only[24];
 
 static struct csinn_callback *gref_cb_map(int op, int dtype)
 {
@@ -231,6 +236,9 @@ static struct csinn_callback *gref_cb_map(int op, int dtype)
         {CSINN_OP_DEPTHWISE_CONV2D, shl_gref_depthwise_conv2d},
         {CSINN_OP_DEPTHWISE_CONV2D_RELU, shl_gref_depthwise_conv2d_relu},
         {CSINN_OP_DEPTHWISE_CONV2D_RELU6, shl_gref_depthwise_conv2d_relu6},
+        {CSINN_OP_GROUP_CONV2D, shl_gref_group_conv2d},
+        {CSINN_OP_GROUP_CONV2D_RELU, shl_gref_group_conv2d_relu},
+        {CSINN_OP_GROUP_CONV2D_RELU6, shl_gref_group_conv2d_relu6},
         {CSINN_OP_FULLYCONNECTED, shl_gref_fullyconnected},
         {CSINN_OP_RELU, shl_gref_relu},
         {CSINN_OP_RELU6, shl_gref_relu6},

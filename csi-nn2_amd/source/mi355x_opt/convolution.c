@@ -21,6 +21,8 @@
 
 #include "mi355x_internal.h"
 
+int shl_mi355x_group_conv2d_exec(CSINN_CONV_ARGS);
+
 /* ------------------------------------------------------------------------ descriptor */
 
 static int layout_of(struct csinn_conv2d_params *params)
@@ -153,6 +155,96 @@ static int create_plan(void *params_key, struct shl_mi355x_conv_desc *d, struct 
     return rc;
 }
 
+/* ------------------------------------------------------------------------ grouped convolution
+ * shl_ref_group_conv2d_quant (source/reference/convolution.c:476-508) dequantises the whole
+ * tensors and runs one plain convolution per group on SLICES of the buffers:
+ *   NCHW (:312-354): image j, group i reads the C/g input planes at (j*G + i) * (C/g*H*W) and
+ *        writes the Cout/g output planes at (j*G + i) * (Cout/g*Ho*Wo) -- the usual semantics;
+ *   NHWC (:271-310): group i reads the contiguous block i * (N*H*W*C/g) as an [N,H,W,C/g] tensor
+ *        and writes block i * (N*Ho*Wo*Cout/g) -- i.e. the buffers are treated as G consecutive
+ *        NHWC tensors, NOT as channel-interleaved groups.  Restated literally: identical results
+ *        are the contract.
+ * One device plan per group (key: params + 1 + i); slices start at arbitrary byte offsets, so the
+ * plans use the alignment-free direct kernel. */
+static void *group_key(void *params, int i) { return (char *)params + 1 + i; }
+
+static int group_conv_init(struct shl_mi355x_conv_desc *d, struct csinn_tensor *input,
+                           struct csinn_tensor *output, struct csinn_tensor *kernel,
+                           struct csinn_tensor *bias, struct csinn_conv2d_params *params)
+{
+    const int G = d->group;
+    if (G > 64) {
+        shl_debug_error("mi355x: grouped convolution with %d groups is not supported\n", G);
+        return CSINN_FALSE;
+    }
+    struct shl_mi355x_conv_desc sub = *d;
+    sub.group = 1;
+    sub.in_c = d->in_c / G;
+    sub.out_c = d->out_c / G;
+    sub.algo = SHL_MI355X_ALGO_DIRECT;
+    if (d->layout == SHL_MI355X_NCHW) sub.batch = 1;
+    const int es = d->dtype == SHL_MI355X_I8 ? 1 : 2;
+    const int64_t ksz = (int64_t)sub.out_c * sub.in_c * d->kernel_h * d->kernel_w; /* elements per group */
+    const int has_bias = bias != NULL && bias->dim_count != 0 && bias->data != NULL;
+    for (int i = 0; i < G; i++) {
+        struct csinn_tensor k = *kernel, b;
+        k.data = (char *)kernel->data + i * ksz * es;
+        k.dim[0] = sub.out_c;
+        if (kernel->quant_channel > 1) {
+            k.qinfo = kernel->qinfo + i * sub.out_c;
+            k.quant_channel = sub.out_c;
+        }
+        if (has_bias) {
+            b = *bias;
+            b.data = (char *)bias->data + (int64_t)i * sub.out_c * (d->dtype == SHL_MI355X_I8 ? 4 : 2);
+            b.dim[0] = sub.out_c;
+            if (bias->quant_channel > 1) {
+                b.qinfo = bias->qinfo + i * sub.out_c;
+                b.quant_channel = sub.out_c;
+            }
+        }
+        int rc = create_plan(group_key(params, i), &sub, input, output, &k, has_bias ? &b : bias,
+                             params->conv_extra.fuse_zp2bias);
+        if (rc != CSINN_TRUE) return rc;
+    }
+    params->base.cb->exec = shl_mi355x_group_conv2d_exec;
+    return CSINN_TRUE;
+}
+
+int shl_mi355x_group_conv2d_exec(CSINN_CONV_ARGS)
+{
+    (void)kernel;
+    (void)bias;
+    const int G = params->group;
+    const int nhwc = params->base.layout == CSINN_LAYOUT_NHWC;
+    const int es = input->dtype == CSINN_DTYPE_INT8 ? 1 : 2;
+    const int N = input->dim[0];
+    const int64_t in_all = csinn_tensor_size(input), out_all = csinn_tensor_size(output);
+    const int64_t isz = nhwc ? in_all / G : in_all / ((int64_t)N * G);  /* elements per slice */
+    const int64_t osz = nhwc ? out_all / G : out_all / ((int64_t)N * G);
+    void *stream = shl_mi355x_get_stream();
+    const char *in_dev = shl_mi355x_stage_in(input, 0);
+    char *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
+    const int images = nhwc ? 1 : N;
+    for (int j = 0; j < images; j++)
+        for (int i = 0; i < G; i++) {
+            shl_mi355x_conv_plan *plan = shl_mi355x_registry_get(group_key(params, i));
+            if (plan == NULL) {
+                shl_debug_error("mi355x: group_conv2d called without a successful init\n");
+                return CSINN_FALSE;
+            }
+            const int64_t slice = (int64_t)j * G + i;
+            int st = shl_mi355x_conv_forward(plan, in_dev + slice * isz * es, out_dev + slice * osz * es,
+                                             nhwc ? N : 1, stream);
+            if (st != SHL_MI355X_OK) {
+                shl_debug_error("mi355x: group_conv2d launch failed (%d): %s\n", st, shl_mi355x_last_error());
+                return CSINN_FALSE;
+            }
+        }
+    return shl_mi355x_stage_out_end(output, out_dev);
+}
+
 /* ------------------------------------------------------------------------ conv2d family */
 
 static int conv_init_common(struct csinn_tensor *input, struct csinn_tensor *output,
@@ -191,6 +283,7 @@ static int conv_init_common(struct csinn_tensor *input, struct csinn_tensor *out
     d.dilation_w = params->dilation_width > 0 ? params->dilation_width : 1;
     d.group = params->group > 0 ? params->group : 1;
 
+    if (d.group > 1 && d.group != d.in_c) return group_conv_init(&d, input, output, kernel, bias, params);
     int rc = create_plan(params, &d, input, output, kernel, bias, params->conv_extra.fuse_zp2bias);
     if (rc != CSINN_TRUE) return rc;
     /* the way every optimised backend of the reference selects its kernel */

@@ -76,7 +76,7 @@ static void drop_session(struct csinn_session *sess)
 /* is `exec` one of the callbacks that run on the GPU and honour DMABUF tensors? */
 static int gpu_native(int (*exec)())
 {
-    return exec == (int (*)())shl_mi355x_conv2d_exec || exec == (int (*)())shl_mi355x_fullyconnected_exec ||
+    return exec == (int (*)())shl_mi355x_conv2d_exec || exec == (int (*)())shl_mi355x_group_conv2d_exec || exec == (int (*)())shl_mi355x_fullyconnected_exec ||
            exec == (int (*)())shl_mi355x_relu_exec || exec == (int (*)())shl_mi355x_relu6_exec ||
            exec == (int (*)())shl_mi355x_global_avgpool2d_exec || exec == (int (*)())shl_mi355x_softmax_exec ||
            exec == (int (*)())shl_mi355x_add_exec;
@@ -98,6 +98,9 @@ static int op_arity(int type)
         case CSINN_OP_DEPTHWISE_CONV2D:
         case CSINN_OP_DEPTHWISE_CONV2D_RELU:
         case CSINN_OP_DEPTHWISE_CONV2D_RELU6:
+        case CSINN_OP_GROUP_CONV2D:
+        case CSINN_OP_GROUP_CONV2D_RELU:
+        case CSINN_OP_GROUP_CONV2D_RELU6:
         case CSINN_OP_FULLYCONNECTED:
             return 3;
         default:

@@ -11,7 +11,7 @@
 #include "mi355x_internal.h"
 
 /* ------------------------------------------------------------------------ callback table */
-#define MI355X_CB_MAX 32
+#define MI355X_CB_MAX 48
 static struct {
     int key; /* op * CSINN_DTYPE_SIZE + dtype */
     struct csinn_callback cb;
@@ -153,8 +153,19 @@ int shl_mi355x_release_params(void *params)
         s->key = TOMBSTONE;
         s->plan = NULL;
     }
+    /* grouped convolutions keep one plan per group under the keys params + 1 + i */
+    shl_mi355x_conv_plan *sub[64];
+    int nsub = 0;
+    for (int i = 0; i < 64; i++) {
+        struct slot *g = find((char *)params + 1 + i);
+        if (g == NULL) break;
+        sub[nsub++] = g->plan;
+        g->key = TOMBSTONE;
+        g->plan = NULL;
+    }
     pthread_mutex_unlock(&g_lock);
-    if (p == NULL) return CSINN_FALSE;
+    for (int i = 0; i < nsub; i++) shl_mi355x_conv_plan_destroy(sub[i]);
+    if (p == NULL) return nsub > 0 ? CSINN_TRUE : CSINN_FALSE;
     return shl_mi355x_conv_plan_destroy(p) == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
 }
 
@@ -272,6 +283,8 @@ void *shl_mi355x_runtime_callback(int op)
     }
 }
 
+#pragma weak shl_gref_group_conv2d_relu6
+
 void shl_target_init_mi355x(void)
 {
     static int done;
@@ -291,6 +304,13 @@ void shl_target_init_mi355x(void)
             shl_gref_depthwise_conv2d_relu);
         reg(dt, CSINN_OP_DEPTHWISE_CONV2D_RELU6, shl_mi355x_conv2d_relu6_init,
             shl_mi355x_conv2d_exec, shl_gref_depthwise_conv2d_relu6);
+        reg(dt, CSINN_OP_GROUP_CONV2D, shl_mi355x_conv2d_init, shl_mi355x_group_conv2d_exec, shl_gref_group_conv2d);
+        reg(dt, CSINN_OP_GROUP_CONV2D_RELU, shl_mi355x_conv2d_relu_init, shl_mi355x_group_conv2d_exec,
+            shl_gref_group_conv2d_relu);
+        /* the reference's gref has no est for this op id (no shl_gref_group_conv2d_relu6 symbol) */
+        if (shl_gref_group_conv2d_relu6)
+            reg(dt, CSINN_OP_GROUP_CONV2D_RELU6, shl_mi355x_conv2d_relu6_init, shl_mi355x_group_conv2d_exec,
+                shl_gref_group_conv2d_relu6);
         reg(dt, CSINN_OP_FULLYCONNECTED, shl_mi355x_fullyconnected_init,
             shl_mi355x_fullyconnected_exec, shl_gref_fullyconnected);
     }

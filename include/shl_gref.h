@@ -57,6 +57,9 @@ int shl_gref_conv2d_relu6(CSINN_CONV_ARGS);
 int shl_gref_depthwise_conv2d(CSINN_CONV_ARGS);
 int shl_gref_depthwise_conv2d_relu(CSINN_CONV_ARGS);
 int shl_gref_depthwise_conv2d_relu6(CSINN_CONV_ARGS);
+int shl_gref_group_conv2d(CSINN_CONV_ARGS);
+int shl_gref_group_conv2d_relu(CSINN_CONV_ARGS);
+int shl_gref_group_conv2d_relu6(CSINN_CONV_ARGS);
 int shl_gref_fullyconnected(struct csinn_tensor *input, struct csinn_tensor *output,
                             struct csinn_tensor *weights, struct csinn_tensor *bias,
                             struct csinn_fc_params *params);

@@ -45,6 +45,7 @@ const char *shl_mi355x_params_kernel_name(void *params);
 /* init / exec callbacks (exported so that a reference-side setup.c can list them) */
 int shl_mi355x_conv2d_init(CSINN_CONV_ARGS);
 int shl_mi355x_conv2d_exec(CSINN_CONV_ARGS);
+int shl_mi355x_group_conv2d_exec(CSINN_CONV_ARGS);  /* selected by init when 1 < group < Cin */
 int shl_mi355x_fullyconnected_init(struct csinn_tensor *input, struct csinn_tensor *output,
                                    struct csinn_tensor *weights, struct csinn_tensor *bias,
                                    struct csinn_fc_params *params);

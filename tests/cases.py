@@ -31,7 +31,7 @@ def out_size(i, k, s, p0, p1, d):
 
 def make_case(seed, layout=NHWC, dtype="int8", n=1, h=8, w=8, c=16, co=16, k=(3, 3), stride=(1, 1),
               pad=(1, 1, 1, 1), dilation=(1, 1), depthwise=False, multiplier=1, act=0,
-              per_channel=False, fuse_zp2bias=False, has_bias=True, exact=True, fc=False):
+              per_channel=False, fuse_zp2bias=False, has_bias=True, exact=True, fc=False, groups=1):
     """Returns a dict describing one problem with numpy operands."""
     rng = np.random.default_rng(seed)
     kh, kw = k
@@ -40,7 +40,7 @@ def make_case(seed, layout=NHWC, dtype="int8", n=1, h=8, w=8, c=16, co=16, k=(3,
         kh = kw = 1
         stride, pad, dilation = (1, 1), (0, 0, 0, 0), (1, 1)
         layout = NHWC
-    group = c if depthwise else 1
+    group = c if depthwise else groups
     if depthwise:
         co = c * multiplier
     ho = out_size(h, kh, stride[0], pad[0], pad[2], dilation[0])
@@ -247,6 +247,38 @@ def csinn_run(fe, api, case, device=None, repeat=1, keep_params=None):
     if keep_params is not None:
         keep_params.append((params, keep))
     return out
+
+
+def oracle_group_run(case, formulation="ref"):
+    """Grouped convolution exactly as shl_ref_group_conv2d_{nhwc,nchw}_f32 slice the buffers
+    (source/reference/convolution.c:271-354): NCHW image j / group i uses the contiguous slices
+    (j*G + i) of input and output; NHWC treats the buffers as G consecutive [N,H,W,C/g] tensors.
+    Each slice is a plain convolution (oracle_run)."""
+    G = case["group"]
+    nhwc = case["layout"] == NHWC
+    n, cg, og = case["n"], case["c"] // G, case["co"] // G
+    x = np.ascontiguousarray(case["input"]).reshape(-1)
+    out = np.empty(int(np.prod(case["out_shape"])), dtype=case["input"].dtype)
+    images = 1 if nhwc else n
+    sub_n = n if nhwc else 1
+    in_shape = (sub_n, case["h"], case["w"], cg) if nhwc else (sub_n, cg, case["h"], case["w"])
+    out_shape = (sub_n, case["ho"], case["wo"], og) if nhwc else (sub_n, og, case["ho"], case["wo"])
+    isz, osz = int(np.prod(in_shape)), int(np.prod(out_shape))
+    for j in range(images):
+        for i in range(G):
+            sub = dict(case)
+            sub.update(group=1, c=cg, co=og, n=sub_n, in_shape=in_shape, out_shape=out_shape, depthwise=False)
+            sl = j * G + i
+            sub["input"] = x[sl * isz:(sl + 1) * isz].reshape(in_shape)
+            sub["kernel"] = np.ascontiguousarray(case["kernel"][i * og:(i + 1) * og])
+            sub["w_shape"] = sub["kernel"].shape
+            sub["bias"] = np.ascontiguousarray(case["bias"][i * og:(i + 1) * og])
+            if len(case["k_scale"]) > 1:
+                sub["k_scale"] = case["k_scale"][i * og:(i + 1) * og]
+                sub["k_zp"] = case["k_zp"][i * og:(i + 1) * og]
+                sub["b_scale"] = case["b_scale"][i * og:(i + 1) * og]
+            out[sl * osz:(sl + 1) * osz] = oracle_run(sub, formulation).reshape(-1)
+    return out.reshape(case["out_shape"])
 
 
 def have_reference():

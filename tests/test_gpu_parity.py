@@ -293,12 +293,9 @@ def test_unsupported_requests_are_refused(gpu):
     with pytest.raises(pkg.MI355XError):
         cases.csinn_run(fe, pkg.API_MI355X, case)
     before = opt.shl_mi355x_live_plans(None)
-    grouped = cases.make_case(6, c=32, co=32)
-    grouped["group"] = 4                                 # grouped conv: refused
-    grouped["kernel"] = grouped["kernel"][..., :8].copy()
-    grouped["w_shape"] = grouped["kernel"].shape
+    many = cases.make_case(6, c=130, co=130, groups=65)  # more groups than the backend keeps plans for
     with pytest.raises(pkg.MI355XError):
-        cases.csinn_run(fe, pkg.API_MI355X, grouped)
+        cases.csinn_run(fe, pkg.API_MI355X, many)
     assert opt.shl_mi355x_live_plans(None) == before
 
 
