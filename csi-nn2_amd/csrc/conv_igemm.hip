@@ -57,6 +57,15 @@ template <int ESIZE>
 __device__ __forceinline__ PixelRow make_row(const ConvArgs &a, int p)
 {
     p = p < a.M ? p : a.M - 1;  // rows past M are computed on a clamped pixel and never stored
+    if (a.Kh * a.Kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 && a.H == a.Ho && a.W == a.Wo) {
+        // pointwise: output pixel p reads input pixel p; no (n, oy, ox) decomposition (two integer
+        // divisions) on the latency-critical prologue.  (y0, x0) = (0, 0) addresses the pixel itself.
+        PixelRow r;
+        r.base = static_cast<const char *>(a.in) + (int64_t)p * a.C * ESIZE;
+        r.y0 = 0;
+        r.x0 = 0;
+        return r;
+    }
     const int ox = p % a.Wo, t = p / a.Wo;
     const int oy = t % a.Ho, n = t / a.Ho;
     PixelRow r;
@@ -72,6 +81,11 @@ struct KCursor {
     __device__ __forceinline__ void init(const ConvArgs &a, int first)
     {
         kc = first;
+        if (a.Kh * a.Kw == 1) {  // pointwise: one tap, no divisions
+            cc = first;
+            tap_y = tap_x = 0;
+            return;
+        }
         const int tap = first / a.cchunks;
         cc = first - tap * a.cchunks;
         tap_y = tap / a.Kw;
@@ -725,7 +739,7 @@ template <bool kI8, int EPI, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
 {
     constexpr int ESIZE = kI8 ? 1 : 2;
-    __shared__ __attribute__((aligned(16))) int32_t red[KS == 4 ? 3 * 16 * 64 : 1];
+    __shared__ __attribute__((aligned(16))) int32_t red[KS == 4 ? 4 * 3 * 64 * 4 : 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: scalar K-loop control
     const int n_tiles = (a.Co + 31) / 32;
@@ -737,17 +751,19 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
 
-    // epilogue tables for this lane's 16 channels, requested first so that they arrive under
-    // the K loop (tables are padded to a multiple of 128 channels)
+    // epilogue tables, requested first so that they arrive under the K loop (tables are padded to a
+    // multiple of 128 channels).  KS == 1: this lane's 16 channels; KS == 4: wave w finishes register
+    // group w only (channels ch0 + 8w .. +3), see the reduce-scatter below
     const int ch0 = tn * 32 + 4 * fhalf;
     int4 ai[4];
     float4 mu[4], bi[4];
-    if (KS == 1 || wave == 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            ai[g] = *reinterpret_cast<const int4 *>(a.acc_init + ch0 + 8 * g);
-            mu[g] = *reinterpret_cast<const float4 *>(a.mult + ch0 + 8 * g);
-            bi[g] = *reinterpret_cast<const float4 *>(a.bias + ch0 + 8 * g);
+    for (int g = 0; g < 4; ++g) {
+        if (KS == 1 || g == 0) {
+            const int c = ch0 + 8 * (KS == 1 ? g : wave);
+            ai[g] = *reinterpret_cast<const int4 *>(a.acc_init + c);
+            mu[g] = *reinterpret_cast<const float4 *>(a.mult + c);
+            bi[g] = *reinterpret_cast<const float4 *>(a.bias + c);
         }
     }
 
@@ -782,6 +798,7 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
         wp += 32;                                                                         \
         kc.advance(a, 2);                                                                 \
     }
+    if (a.debug & 16) nsub = 0;
     SHL_LOAD_GROUP(fa0, fb0, 0)
     for (int s0 = 0; s0 < nsub; s0 += 2 * WU) {
         SHL_LOAD_GROUP(fa1, fb1, s0 + WU)
@@ -795,44 +812,17 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
     }
 #undef SHL_LOAD_GROUP
 
-    if constexpr (KS == 4) {
-        // waves 1..3 hand their partial sums to wave 0 (register r of lane l at [w-1][r][l])
-        if (wave != 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if constexpr (kI8)
-                    red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
-                else
-                    red[((wave - 1) * 16 + r) * 64 + lane] = __float_as_int(acc[r]);
-            }
-        }
-        __syncthreads();
-        if (wave != 0) return;
-#pragma unroll
-        for (int w = 0; w < 3; ++w)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if constexpr (kI8)
-                    acc[r] += red[(w * 16 + r) * 64 + lane];
-                else
-                    acc[r] += __int_as_float(red[(w * 16 + r) * 64 + lane]);
-            }
-    }
-
-    // ---- epilogue from registers
+    // ---- finish
     const int p = tm * 32 + frow;
-    if (p >= a.M) return;
     const bool vec_ok = (a.Co & 3) == 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int occ = ch0 + 8 * g;
-        if (occ >= a.Co) continue;
+    auto finish4 = [&](const int (&v_i)[4], const float (&v_f)[4], int g_tab, int occ) {
+        if (p >= a.M || occ >= a.Co) return;
         const int64_t o = (int64_t)p * a.Co + occ;
         if constexpr (kI8) {
-            const int q0 = requant_i8_t<EPI>(acc[4 * g + 0] + ai[g].x, mu[g].x, bi[g].x, a);
-            const int q1 = requant_i8_t<EPI>(acc[4 * g + 1] + ai[g].y, mu[g].y, bi[g].y, a);
-            const int q2 = requant_i8_t<EPI>(acc[4 * g + 2] + ai[g].z, mu[g].z, bi[g].z, a);
-            const int q3 = requant_i8_t<EPI>(acc[4 * g + 3] + ai[g].w, mu[g].w, bi[g].w, a);
+            const int q0 = requant_i8_t<EPI>(v_i[0] + ai[g_tab].x, mu[g_tab].x, bi[g_tab].x, a);
+            const int q1 = requant_i8_t<EPI>(v_i[1] + ai[g_tab].y, mu[g_tab].y, bi[g_tab].y, a);
+            const int q2 = requant_i8_t<EPI>(v_i[2] + ai[g_tab].z, mu[g_tab].z, bi[g_tab].z, a);
+            const int q3 = requant_i8_t<EPI>(v_i[3] + ai[g_tab].w, mu[g_tab].w, bi[g_tab].w, a);
             const uint32_t packed = pack4_i8(q0, q1, q2, q3);
             int8_t *out = static_cast<int8_t *>(a.out);
             if (vec_ok) {
@@ -841,10 +831,10 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
                 for (int e = 0; e < 4 && occ + e < a.Co; ++e) out[o + e] = (int8_t)(packed >> (8 * e));
             }
         } else {
-            const uint32_t h0 = finish_f16(acc[4 * g + 0], bi[g].x, a);
-            const uint32_t h1 = finish_f16(acc[4 * g + 1], bi[g].y, a);
-            const uint32_t h2 = finish_f16(acc[4 * g + 2], bi[g].z, a);
-            const uint32_t h3 = finish_f16(acc[4 * g + 3], bi[g].w, a);
+            const uint32_t h0 = finish_f16(v_f[0], bi[g_tab].x, a);
+            const uint32_t h1 = finish_f16(v_f[1], bi[g_tab].y, a);
+            const uint32_t h2 = finish_f16(v_f[2], bi[g_tab].z, a);
+            const uint32_t h3 = finish_f16(v_f[3], bi[g_tab].w, a);
             uint16_t *out = static_cast<uint16_t *>(a.out);
             if (vec_ok) {
                 *reinterpret_cast<uint2 *>(out + o) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
@@ -852,6 +842,70 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
                 const uint32_t h[4] = {h0, h1, h2, h3};
                 for (int e = 0; e < 4 && occ + e < a.Co; ++e) out[o + e] = (uint16_t)h[e];
             }
+        }
+    };
+
+    if constexpr (KS == 4) {
+        // Reduce-scatter through LDS: wave w keeps register group w (4 accumulators = 4 consecutive
+        // channels) and hands the other three groups to their owners, 16 bytes per lane per group
+        // (slot [owner][source][lane]); after one barrier every wave adds three 16-byte pieces and
+        // finishes 4 values -- the requantise + store tail runs on all four waves instead of one.
+        v4i *slots = reinterpret_cast<v4i *>(red);
+        v4i part[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (kI8)
+                    part[g][e] = acc[4 * g + e];
+                else
+                    part[g][e] = __float_as_int(acc[4 * g + e]);
+            }
+        if (!(a.debug & 32)) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d != wave) slots[(d * 3 + (wave < d ? wave : wave - 1)) * 64 + lane] = part[d];
+        }
+        __syncthreads();
+        if (a.debug & 64) return;
+        v4i mine = wave == 0 ? part[0] : wave == 1 ? part[1] : wave == 2 ? part[2] : part[3];
+        int v_i[4] = {0, 0, 0, 0};
+        float v_f[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (kI8)
+                v_i[e] = mine[e];
+            else
+                v_f[e] = __int_as_float(mine[e]);
+        }
+        if (!(a.debug & 32)) {
+#pragma unroll
+            for (int src = 0; src < 3; ++src) {
+                const v4i other = slots[(wave * 3 + src) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (kI8)
+                        v_i[e] += other[e];
+                    else
+                        v_f[e] += __int_as_float(other[e]);
+                }
+            }
+        }
+        finish4(v_i, v_f, 0, ch0 + 8 * wave);
+    } else {
+        if (a.debug & 64) return;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int v_i[4] = {0, 0, 0, 0};
+            float v_f[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (kI8)
+                    v_i[e] = acc[4 * g + e];
+                else
+                    v_f[e] = acc[4 * g + e];
+            }
+            finish4(v_i, v_f, g, ch0 + 8 * g);
         }
     }
 }

@@ -3,8 +3,8 @@
 //
 // K = 27 is far too shallow for the MFMA tile path (Cin*1 B is not a 16-byte chunk) and the
 // generic one-output-per-thread kernel spends 27 dependent-ish byte loads on every one of its
-// 32*Ho*Wo threads (10.4 us at batch 1).  Here one thread owns one output PIXEL and all its output
-// channels:
+// 32*Ho*Wo threads (10.4 us at batch 1).  Here COP/16 adjacent threads share one output PIXEL
+// (16 output channels each):
 //   * the 27 input bytes of the receptive field are fetched once, all loads in flight together
 //     (out-of-image taps become the input zero point), and packed into 7 dwords;
 //   * the weights are pre-packed at plan time as [kg][co] dwords (4 consecutive k per dword, zero
@@ -12,7 +12,7 @@
 //     (broadcast) ds_read_b128;
 //   * the reduction runs on v_dot4_i32_i8 (4 MACs per instruction, exact int32);
 //   * the zero point is folded like in the MFMA path: acc_init[co] = -zp_in * sum_k w[co,k];
-//   * a thread stores its 32 (or 64) channels as contiguous 16-byte pieces.
+//   * a thread stores its 16 channels as one 16-byte piece.
 // Replaces shl_ref_conv2d_nhwc_f32 (source/reference/convolution.c:28-89) for this shape.
 #include "common.h"
 
@@ -34,9 +34,14 @@ __global__ __launch_bounds__(64) void conv_stem_i8_kernel(ConvArgs a)
         t_mult[i] = a.mult[i];
         t_bias[i] = a.bias[i];
     }
-    const int p = blockIdx.x * 64 + tid;
-    const bool live = p < a.M;
-    const int pc = live ? p : a.M - 1;
+    // a pixel's channels are split over COP/16 adjacent threads (16 channels = one 16-byte store
+    // each): at batch 1 the layer is latency-bound and the per-thread dot4 chain is the long pole
+    constexpr int NSPLIT = COP / 16;
+    const int gid = blockIdx.x * 64 + tid;
+    const int p = gid / NSPLIT;
+    const int cb = (gid % NSPLIT) * 16;
+    const bool live = p < a.M && cb < a.Co;
+    const int pc = p < a.M ? p : a.M - 1;
     const int ox = pc % a.Wo, t = pc / a.Wo;
     const int oy = t % a.Ho, n = t / a.Ho;
     const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
@@ -63,40 +68,36 @@ __global__ __launch_bounds__(64) void conv_stem_i8_kernel(ConvArgs a)
     __syncthreads();
 
     int8_t *out = static_cast<int8_t *>(a.out) + (int64_t)p * a.Co;
+    int acc[16];
 #pragma unroll
-    for (int cb = 0; cb < COP; cb += 16) {  // 16 channels at a time: one 16-byte store
-        if (cb >= a.Co) break;
-        int acc[16];
+    for (int e = 0; e < 16; ++e) acc[e] = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0;
-#pragma unroll
-        for (int g = 0; g < STEM_KG; ++g) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int4 w = *reinterpret_cast<const int4 *>(&w_lds[g * COP + cb + 4 * v]);
-                acc[4 * v + 0] = __builtin_amdgcn_sdot4((int)q4[g], w.x, acc[4 * v + 0], false);
-                acc[4 * v + 1] = __builtin_amdgcn_sdot4((int)q4[g], w.y, acc[4 * v + 1], false);
-                acc[4 * v + 2] = __builtin_amdgcn_sdot4((int)q4[g], w.z, acc[4 * v + 2], false);
-                acc[4 * v + 3] = __builtin_amdgcn_sdot4((int)q4[g], w.w, acc[4 * v + 3], false);
-            }
-        }
-        uint32_t packed[4];
+    for (int g = 0; g < STEM_KG; ++g) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            int qq[4];
+            const int4 w = *reinterpret_cast<const int4 *>(&w_lds[g * COP + cb + 4 * v]);
+            acc[4 * v + 0] = __builtin_amdgcn_sdot4((int)q4[g], w.x, acc[4 * v + 0], false);
+            acc[4 * v + 1] = __builtin_amdgcn_sdot4((int)q4[g], w.y, acc[4 * v + 1], false);
+            acc[4 * v + 2] = __builtin_amdgcn_sdot4((int)q4[g], w.z, acc[4 * v + 2], false);
+            acc[4 * v + 3] = __builtin_amdgcn_sdot4((int)q4[g], w.w, acc[4 * v + 3], false);
+        }
+    }
+    uint32_t packed[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = cb + 4 * v + e;
-                qq[e] = requant_i8_t<EPI>(acc[4 * v + e] + t_acc[c], t_mult[c], t_bias[c], a);
-            }
-            packed[v] = pack4_i8(qq[0], qq[1], qq[2], qq[3]);
+    for (int v = 0; v < 4; ++v) {
+        int qq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = cb + 4 * v + e;
+            qq[e] = requant_i8_t<EPI>(acc[4 * v + e] + t_acc[c], t_mult[c], t_bias[c], a);
         }
-        if (!live) continue;
-        if (cb + 16 <= a.Co && (a.Co & 15) == 0) {
-            *reinterpret_cast<uint4 *>(out + cb) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-        } else {
-            for (int e = 0; e < 16 && cb + e < a.Co; ++e) out[cb + e] = (int8_t)(packed[e >> 2] >> (8 * (e & 3)));
-        }
+        packed[v] = pack4_i8(qq[0], qq[1], qq[2], qq[3]);
+    }
+    if (!live) return;
+    if (cb + 16 <= a.Co && (a.Co & 15) == 0) {
+        *reinterpret_cast<uint4 *>(out + cb) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    } else {
+        for (int e = 0; e < 16 && cb + e < a.Co; ++e) out[cb + e] = (int8_t)(packed[e >> 2] >> (8 * (e & 3)));
     }
 }
 
@@ -127,7 +128,8 @@ size_t stem_weight_bytes(const shl_mi355x_conv_desc &d) { return (size_t)STEM_KG
 int launch_conv_stem(const ConvArgs &a, hipStream_t s)
 {
     if (a.M == 0) return SHL_MI355X_OK;
-    const dim3 grid((unsigned)((a.M + 63) / 64));
+    const int nsplit = a.Co <= 32 ? 2 : 4;  // COP / 16 threads per pixel
+    const dim3 grid((unsigned)(((int64_t)a.M * nsplit + 63) / 64));
     const int epi = epi_code(a);
 #define SHL_STEM(COP)                                                                                              \
     switch (epi) {                                                                                                 \
