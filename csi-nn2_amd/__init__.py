@@ -197,6 +197,8 @@ def load_hip():
         "shl_mi355x_conv_plan_bytes": (sz, [vp]),
         "shl_mi355x_conv_plan_const_block": (vp, [vp, C.POINTER(sz)]),
         "shl_mi355x_conv_forward": (C.c_int, [vp, vp, vp, i32, vp]),
+        "shl_mi355x_dwpw_fusable": (C.c_int, [vp, vp, i32]),
+        "shl_mi355x_dwpw_forward": (C.c_int, [vp, vp, vp, vp, i32, vp]),
         "shl_mi355x_relu_i8": (C.c_int, [vp, vp, sz, f32, i32, f32, i32, i32, vp]),
         "shl_mi355x_relu_f16": (C.c_int, [vp, vp, sz, i32, vp]),
         "shl_mi355x_add": (C.c_int, [vp, vp, vp, sz, i32, f32, i32, f32, i32, f32, i32, vp]),
@@ -293,6 +295,9 @@ def load_backend(frontend):
         opt.shl_mi355x_params_kernel_name.restype = C.c_char_p
         opt.shl_mi355x_params_kernel_name.argtypes = [C.c_void_p]
         opt.shl_mi355x_session_is_device_resident.argtypes = [C.POINTER(Session)]
+        opt.shl_mi355x_session_fused_pairs.argtypes = [C.POINTER(Session)]
+        opt.shl_mi355x_session_stream.argtypes = [C.POINTER(Session)]
+        opt.shl_mi355x_session_stream.restype = C.c_void_p
         opt._typed = True
     # the dispatch tables exist after the first csinn_alloc_session (source/nn2/setup.c:77-84)
     s = frontend.csinn_alloc_session()

@@ -214,6 +214,9 @@ bool stem_supports(const shl_mi355x_conv_desc &d);
 void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
 size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);
 int launch_conv_stem(const ConvArgs &a, hipStream_t s);
+// depthwise 3x3 + pointwise 1x1 in one launch (dwpw_fused.hip)
+bool dwpw_fusable(const ConvArgs &dw, const ConvArgs &pw, int dw_dot4_packed, int pw_is_igemm);
+int launch_dwpw_fused(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);
 // [N][R][S] -> [N][S][R] for 1- or 2-byte elements (layout.hip)
 int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s);
 

@@ -346,15 +346,14 @@ void *shl_mi355x_conv_plan_const_block(shl_mi355x_conv_plan *plan, size_t *bytes
     return plan->block;
 }
 
-int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev,
-                            void *output_dev, int32_t batch, void *stream)
+}  // extern "C"
+
+// kernel argument block of one forward pass of `plan`
+static int fill_args(const shl_mi355x_conv_plan *plan, const void *input_dev, void *output_dev, int32_t batch,
+                     shl::ConvArgs &a)
 {
-    if (!plan || !input_dev || !output_dev) {
-        set_error("conv_forward: NULL argument");
-        return SHL_MI355X_EINVAL;
-    }
+    using namespace shl;
     const shl_mi355x_conv_desc &d = plan->desc;
-    ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = input_dev;
     a.out = output_dev;
@@ -396,6 +395,22 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
         static const char *dbg = getenv("SHL_MI355X_DEBUG");
         a.debug = dbg ? atoi(dbg) : 0;
     }
+    return SHL_MI355X_OK;
+}
+
+extern "C" {
+
+int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev,
+                            void *output_dev, int32_t batch, void *stream)
+{
+    if (!plan || !input_dev || !output_dev) {
+        set_error("conv_forward: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    const shl_mi355x_conv_desc &d = plan->desc;
+    ConvArgs a;
+    int frc = fill_args(plan, input_dev, output_dev, batch, a);
+    if (frc != SHL_MI355X_OK) return frc;
     if (a.M == 0) return SHL_MI355X_OK;
     hipStream_t s = (hipStream_t)stream;
     switch (plan->algo) {
@@ -429,6 +444,40 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
             return launch_conv_direct(a, d.dtype, d.layout,
                                       is_depthwise(d) && d.layout == SHL_MI355X_NHWC, s);
     }
+}
+
+/* depthwise 3x3 + pointwise 1x1 fused into one launch (dwpw_fused.hip); 1 when the pair qualifies */
+int shl_mi355x_dwpw_fusable(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw, int32_t batch)
+{
+    if (!dw || !pw) return 0;
+    static const char *off = getenv("SHL_MI355X_NO_FUSION");
+    if (off && off[0] == '1') return 0;
+    if (dw->desc.dtype != SHL_MI355X_I8 || pw->desc.dtype != SHL_MI355X_I8) return 0;
+    if (dw->desc.layout != SHL_MI355X_NHWC || pw->desc.layout != SHL_MI355X_NHWC) return 0;
+    ConvArgs a, b;
+    static char dummy[16];
+    if (fill_args(dw, dummy, dummy, batch, a) != SHL_MI355X_OK || fill_args(pw, dummy, dummy, batch, b) != SHL_MI355X_OK)
+        return 0;
+    return dwpw_fusable(a, b, dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12, pw->algo == SHL_MI355X_ALGO_IGEMM) ? 1 : 0;
+}
+
+int shl_mi355x_dwpw_forward(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw, const void *input_dev,
+                            void *output_dev, int32_t batch, void *stream)
+{
+    if (!dw || !pw || !input_dev || !output_dev) {
+        set_error("dwpw_forward: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    if (!shl_mi355x_dwpw_fusable(dw, pw, batch)) {
+        set_error("dwpw_forward: the pair does not qualify for the fused kernel");
+        return SHL_MI355X_ENOTSUP;
+    }
+    ConvArgs a, b;
+    int rc = fill_args(dw, input_dev, output_dev, batch, a);
+    if (rc == SHL_MI355X_OK) rc = fill_args(pw, input_dev, output_dev, batch, b);
+    if (rc != SHL_MI355X_OK) return rc;
+    if (a.M == 0) return SHL_MI355X_OK;
+    return launch_dwpw_fused(a, b, (hipStream_t)stream);
 }
 
 }  // extern "C"

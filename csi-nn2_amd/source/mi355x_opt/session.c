@@ -29,6 +29,9 @@ struct dev_tensor {
     void *dev;                   /* HBM buffer */
     size_t bytes;
     struct csinn_tensor shadow;  /* copy of the csinn_tensor with data = dev, mtype = DMABUF */
+    int borrowed;                /* dev is the caller's own HBM buffer, bound at run time (rebind) */
+    void *probe_ptr;             /* last pointer classified by is_device_ptr, and the verdict */
+    int probe_dev;
 };
 
 struct dev_session {
@@ -37,6 +40,8 @@ struct dev_session {
     int nt;
     void *stream;
     void *graph_exec;
+    unsigned char *fused; /* per layer: 1 = runs fused with the next layer (depthwise + pointwise) */
+    int nfused;
     struct dev_session *next;
 };
 
@@ -53,9 +58,10 @@ static void free_session(struct dev_session *ds)
 {
     if (ds->graph_exec) shl_mi355x_graph_destroy(ds->graph_exec);
     for (int i = 0; i < ds->nt; i++)
-        if (ds->t[i].dev) shl_mi355x_free(ds->t[i].dev);
+        if (ds->t[i].dev && !ds->t[i].borrowed) shl_mi355x_free(ds->t[i].dev);
     if (ds->stream) shl_mi355x_stream_destroy(ds->stream);
     free(ds->t);
+    free(ds->fused);
     free(ds);
 }
 
@@ -130,6 +136,43 @@ static struct dev_tensor *adopt(struct dev_session *ds, struct shl_node *node)
     return d->dev ? d : NULL;
 }
 
+static int is_dw_op(int type)
+{
+    return type == CSINN_OP_DEPTHWISE_CONV2D || type == CSINN_OP_DEPTHWISE_CONV2D_RELU ||
+           type == CSINN_OP_DEPTHWISE_CONV2D_RELU6;
+}
+
+static int is_conv_op(int type)
+{
+    return type == CSINN_OP_CONV2D || type == CSINN_OP_CONV2D_RELU || type == CSINN_OP_CONV2D_RELU6;
+}
+
+/* Graph-level fusion: a depthwise convolution whose ONLY consumer is the next layer, a 1x1
+ * convolution, runs with it as one launch (csrc/dwpw_fused.hip) when the pair of device plans
+ * qualifies; the intermediate tensor then never exists in HBM. */
+static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
+{
+    ds->fused = calloc((size_t)g->layer_index + 1, 1);
+    for (int i = 0; i + 1 < g->layer_index; i++) {
+        struct shl_node *a = g->layer[i], *b = g->layer[i + 1];
+        if (!is_dw_op(a->type) || !is_conv_op(b->type) || b->in[0] != a->out[0]) continue;
+        int consumers = 0;
+        for (int k = 0; k < g->layer_index; k++)
+            for (int j = 0; j < g->layer[k]->in_num; j++)
+                if (g->layer[k]->in[j] == a->out[0]) consumers++;
+        for (int k = 0; k < g->output_num; k++)
+            if (g->output[k] == a->out[0]) consumers++;
+        if (consumers != 1) continue;
+        shl_mi355x_conv_plan *pa = shl_mi355x_registry_get(a->data), *pb = shl_mi355x_registry_get(b->data);
+        struct csinn_tensor *in = a->in[0]->data;
+        if (pa && pb && shl_mi355x_dwpw_fusable(pa, pb, in->dim[0])) {
+            ds->fused[i] = 1;
+            ds->nfused++;
+            i++; /* the pointwise layer is taken */
+        }
+    }
+}
+
 /* enqueue every layer on the session stream, tensors resident in HBM */
 static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
 {
@@ -140,13 +183,21 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
         struct dev_tensor *out = lookup(ds, n->out[0]);
         int (*f)() = params->cb->exec;
         int rc;
-        if (op_arity(n->type) == 1) {
+        if (ds->fused && ds->fused[i]) {
+            struct shl_node *nx = g->layer[i + 1];
+            struct dev_tensor *out2 = lookup(ds, nx->out[0]);
+            int st = shl_mi355x_dwpw_forward(shl_mi355x_registry_get(n->data), shl_mi355x_registry_get(nx->data),
+                                             in->dev, out2->dev, in->shadow.dim[0], shl_mi355x_get_stream());
+            rc = st == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
+            i++;
+        } else if (op_arity(n->type) == 1) {
             rc = f(&in->shadow, &out->shadow, params);
         } else if (op_arity(n->type) == 2) { /* add: the second operand is an activation or a constant */
             struct dev_tensor *in1 = lookup(ds, n->in[1]);
             rc = f(&in->shadow, in1 ? (void *)&in1->shadow : n->in[1]->data, &out->shadow, params);
-        } else
+        } else {
             rc = f(&in->shadow, &out->shadow, n->in[1]->data, n->in[2]->data, params);
+        }
         if (rc != CSINN_TRUE) {
             shl_debug_error("mi355x: layer %d (%s) failed while building the device graph\n", i,
                             n->name ? n->name : "?");
@@ -154,6 +205,50 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
         }
     }
     return CSINN_TRUE;
+}
+
+static int capture(struct dev_session *ds, struct shl_ref_graph *g)
+{
+    if (ds->graph_exec) {
+        shl_mi355x_graph_destroy(ds->graph_exec);
+        ds->graph_exec = NULL;
+    }
+    void *prev = shl_mi355x_get_stream();
+    shl_mi355x_set_stream(ds->stream);
+    int built = CSINN_FALSE;
+    if (shl_mi355x_graph_begin(ds->stream) == SHL_MI355X_OK) {
+        built = enqueue_layers(ds, g);
+        ds->graph_exec = shl_mi355x_graph_end(ds->stream);
+        if (built != CSINN_TRUE && ds->graph_exec) {
+            shl_mi355x_graph_destroy(ds->graph_exec);
+            ds->graph_exec = NULL;
+        }
+    }
+    shl_mi355x_set_stream(prev);
+    return built;
+}
+
+/* does the caller's buffer live in HBM?  (graph tensors carry node pointers in `data` while the
+ * graph is built -- graph_ref/setup.c:75-268 -- so device residency of inputs / outputs can only be
+ * seen on the pointers handed over by csinn_update_input / csinn_update_output) */
+static int caller_buffer_is_device(struct dev_tensor *d, struct csinn_tensor *t)
+{
+    if (t->data == NULL) return 0;
+    if (t->mtype == CSINN_MEM_TYPE_DMABUF) return 1;
+    if (d->probe_ptr != t->data) {
+        d->probe_ptr = t->data;
+        d->probe_dev = shl_mi355x_is_device_ptr(t->data);
+    }
+    return d->probe_dev;
+}
+
+/* run in place on the caller's HBM buffer from now on; the captured graph must be rebuilt */
+static void rebind(struct dev_tensor *d, void *dev)
+{
+    if (d->dev && !d->borrowed) shl_mi355x_free(d->dev);
+    d->dev = dev;
+    d->borrowed = 1;
+    d->shadow.data = dev;
 }
 
 int shl_mi355x_session_setup(struct csinn_session *sess)
@@ -207,21 +302,8 @@ int shl_mi355x_session_setup(struct csinn_session *sess)
         ok = adopt(ds, n->out[0]) != NULL;
     }
     for (int i = 0; ok && i < g->output_num; i++) ok = lookup(ds, g->output[i]) != NULL;
-    if (ok) {
-        /* capture the whole model once; a failed capture leaves the eager device path */
-        void *prev = shl_mi355x_get_stream();
-        shl_mi355x_set_stream(ds->stream);
-        if (shl_mi355x_graph_begin(ds->stream) == SHL_MI355X_OK) {
-            int built = enqueue_layers(ds, g);
-            ds->graph_exec = shl_mi355x_graph_end(ds->stream);
-            if (built != CSINN_TRUE && ds->graph_exec) {
-                shl_mi355x_graph_destroy(ds->graph_exec);
-                ds->graph_exec = NULL;
-            }
-            if (built != CSINN_TRUE) ok = 0;
-        }
-        shl_mi355x_set_stream(prev);
-    }
+    if (ok) plan_fusion(ds, g);
+    if (ok) ok = capture(ds, g) == CSINN_TRUE; /* the whole model as one hipGraph */
     if (!ok) {
         shl_debug_error("mi355x: device-resident session setup failed (%s); keeping the host path\n",
                         shl_mi355x_last_error());
@@ -241,20 +323,35 @@ int shl_mi355x_session_run(struct csinn_session *sess)
         return gref_run ? gref_run(sess) : CSINN_FALSE;
     }
     struct shl_ref_graph *g = shl_gref_get_graph(sess);
-    int status = CSINN_TRUE;
+    int status = CSINN_TRUE, host_outputs = 0, stale = 0;
+    /* inputs / outputs the caller keeps in HBM are used in place (first sight of a new pointer
+     * re-captures the graph once); host buffers are copied */
     for (int i = 0; i < g->input_num; i++) {
         struct dev_tensor *d = lookup(ds, g->input[i]);
         struct csinn_tensor *t = g->input[i]->data;
-        int st;
         if (t->data == NULL) {
             shl_debug_error("mi355x: graph input %d has no data\n", i);
             return CSINN_FALSE;
         }
-        if (t->mtype == CSINN_MEM_TYPE_DMABUF)
-            st = shl_mi355x_copy(d->dev, t->data, d->bytes, ds->stream);
-        else
-            st = shl_mi355x_upload(d->dev, t->data, d->bytes, ds->stream);
-        if (st != SHL_MI355X_OK) status = CSINN_FALSE;
+        if (caller_buffer_is_device(d, t) && t->data != d->dev) {
+            rebind(d, t->data);
+            stale = 1;
+        }
+    }
+    for (int i = 0; i < g->output_num; i++) {
+        struct dev_tensor *d = lookup(ds, g->output[i]);
+        struct csinn_tensor *t = g->output[i]->data;
+        if (t->mtype == CSINN_MEM_TYPE_CPU_ACC && caller_buffer_is_device(d, t) && t->data != d->dev) {
+            rebind(d, t->data);
+            stale = 1;
+        }
+    }
+    if (stale && capture(ds, g) != CSINN_TRUE) return CSINN_FALSE;
+    for (int i = 0; i < g->input_num; i++) {
+        struct dev_tensor *d = lookup(ds, g->input[i]);
+        struct csinn_tensor *t = g->input[i]->data;
+        if (t->data != d->dev && shl_mi355x_upload(d->dev, t->data, d->bytes, ds->stream) != SHL_MI355X_OK)
+            status = CSINN_FALSE;
     }
     if (ds->graph_exec) {
         if (shl_mi355x_graph_launch(ds->graph_exec, ds->stream) != SHL_MI355X_OK) status = CSINN_FALSE;
@@ -267,17 +364,16 @@ int shl_mi355x_session_run(struct csinn_session *sess)
     for (int i = 0; i < g->output_num; i++) {
         struct dev_tensor *d = lookup(ds, g->output[i]);
         struct csinn_tensor *t = g->output[i]->data;
-        if (t->mtype == CSINN_MEM_TYPE_DMABUF && t->data != NULL) { /* caller wants it in HBM */
-            if (shl_mi355x_copy(t->data, d->dev, d->bytes, ds->stream) != SHL_MI355X_OK) status = CSINN_FALSE;
-            continue;
-        }
+        if (t->mtype == CSINN_MEM_TYPE_CPU_ACC && t->data == d->dev) continue; /* written in place, in HBM */
         if (t->mtype != CSINN_MEM_TYPE_CPU_ACC) /* a fresh buffer per run that the caller then owns, as
                                                    the executor does (graph_ref/setup.c:1125-1134) */
             t->data = shl_mem_alloc((int64_t)(d->bytes ? d->bytes : 16));
+        host_outputs++;
         if (t->data == NULL || shl_mi355x_download(t->data, d->dev, d->bytes, ds->stream) != SHL_MI355X_OK)
             status = CSINN_FALSE;
     }
-    if (shl_mi355x_stream_sync(ds->stream) != SHL_MI355X_OK) status = CSINN_FALSE;
+    /* outputs that stay in HBM stay asynchronous (shl_mi355x_session_stream + stream_sync to wait) */
+    if (host_outputs > 0 && shl_mi355x_stream_sync(ds->stream) != SHL_MI355X_OK) status = CSINN_FALSE;
     if (status != CSINN_TRUE) shl_debug_error("mi355x: device session run failed: %s\n", shl_mi355x_last_error());
     return status;
 }
@@ -287,6 +383,20 @@ void shl_mi355x_session_deinit(struct csinn_session *sess)
     drop_session(sess);
     void (*gref_deinit)(struct csinn_session *) = shl_gref_runtime_callback(CSINN_SESSION_DEINIT);
     if (gref_deinit) gref_deinit(sess);
+}
+
+/* the stream a device-resident session runs on (NULL for host-staged sessions) */
+void *shl_mi355x_session_stream(struct csinn_session *sess)
+{
+    struct dev_session *ds = find_session(sess);
+    return ds ? ds->stream : NULL;
+}
+
+/* number of depthwise + pointwise pairs that run as one launch in `sess` */
+int shl_mi355x_session_fused_pairs(struct csinn_session *sess)
+{
+    struct dev_session *ds = find_session(sess);
+    return ds ? ds->nfused : 0;
 }
 
 /* 1 when `sess` executes as one device-resident hipGraph, 0 when host-staged */

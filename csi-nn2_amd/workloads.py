@@ -222,7 +222,9 @@ class ModelSession:
     csinn_get_output with HOST tensors, i.e. it includes the H2D / D2H copies and the final
     synchronisation -- the PCIe-inclusive rate of DESIGN.md."""
 
-    def __init__(self, fe, api, dtype="int8", layout="NHWC", seed=99, layers=None):
+    def __init__(self, fe, api, dtype="int8", layout="NHWC", seed=99, layers=None, dev_in=None, dev_out=None):
+        """dev_in / dev_out: HBM pointers for the graph input / output (DMABUF tensors): the session then
+        runs in place on them and csinn_session_run only enqueues (run_async)."""
         from . import (QUANT_FLOAT16, QUANT_INT8_ASYM_W_SYM, RM_CPU_GRAPH, siso_params)
         self.fe, self.dtype, self.layout = fe, dtype, layout
         layers = layers or MOBILENETV1
@@ -244,9 +246,9 @@ class ModelSession:
         q = (2.0 ** -4, -5) if int8 else (1.0, 0)
         self.in_q = q
 
-        def T(dims, q, name, data=None, const=0, lay=act_l, dtype_=dt):
+        def T(dims, q, name, data=None, const=0, lay=act_l, dtype_=dt, device_ptr=None):
             return make_tensor(fe, keep, dims, dtype_, lay, data=data, is_const=const, name=name, sess=sess,
-                               scales=(q[0],), zps=(q[1],))
+                               scales=(q[0],), zps=(q[1],), device_ptr=device_ptr)
         t_in = T(self.in_dims, q, b"data")
         cur, ops = t_in, []
         for i, L in enumerate(layers):
@@ -289,6 +291,14 @@ class ModelSession:
         fe.csinn_session_setup(sess)
         self.n_layers = len(ops)
         self._feed = None
+        if dev_in is not None:  # hand the HBM buffers over the way a caller would: update_input / _output
+            self._dfeed = make_tensor(fe, keep, self.in_dims, dt, act_l, sess=sess, scales=(self.in_q[0],),
+                                      zps=(self.in_q[1],), device_ptr=dev_in)
+            fe.csinn_update_input(0, self._dfeed, sess)
+        if dev_out is not None:
+            self._dout = make_tensor(fe, keep, cur_dims, dt, act_l, sess=sess, scales=(qs[0],), zps=(qs[1],),
+                                     device_ptr=dev_out)
+            fe.csinn_update_output(0, self._dout, sess)
 
     def synthetic_input(self, seed=0):
         rng = np.random.default_rng(seed)
@@ -315,6 +325,11 @@ class ModelSession:
         data = np.ctypeslib.as_array(C.cast(self._got.contents.data, C.POINTER(ctype)), (n,)).copy()
         fe.shl_mem_free(self._got.contents.data)
         return data if int8 else data.view(np.float16)
+
+    def run_async(self):
+        """device-resident io: enqueue one inference on the session's stream, no synchronisation"""
+        if self.fe.csinn_session_run(self.sess) != CSINN_TRUE:
+            raise MI355XError("csinn_session_run failed")
 
     def close(self):
         self.fe.csinn_session_deinit(self.sess)

@@ -184,6 +184,17 @@ void *shl_mi355x_conv_plan_const_block(shl_mi355x_conv_plan *plan, size_t *bytes
 int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev,
                             void *output_dev, int32_t batch, void *stream);
 
+/*
+ * Depthwise 3x3 + pointwise 1x1 of a separable block as ONE launch (int8 NHWC, latency-bound
+ * sizes): the int8 result of shl_ref_depthwise_conv2d_quant is formed in registers and consumed as
+ * the MFMA operand of shl_ref_conv2d_quant -- same bits as running the two plans back to back, the
+ * intermediate tensor is never written.  `input_dev` is the depthwise layer's input, `output_dev`
+ * the pointwise layer's output.  shl_mi355x_dwpw_fusable() tells whether a pair of plans qualifies.
+ */
+int shl_mi355x_dwpw_fusable(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw, int32_t batch);
+int shl_mi355x_dwpw_forward(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw,
+                            const void *input_dev, void *output_dev, int32_t batch, void *stream);
+
 /* ---- elementwise neighbours of the path ---------------------------------- */
 /* relu / relu6 on a quantised int8 tensor: shl_ref_relu_quant / shl_ref_relu6_quant
  * (source/reference/relu.c:21-43, relu6.c:21-43) */

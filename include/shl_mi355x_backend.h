@@ -71,6 +71,11 @@ int shl_mi355x_session_run(struct csinn_session *sess);
 void shl_mi355x_session_deinit(struct csinn_session *sess);
 /* 0: host-staged (executor's own run), 1: device-resident eager, 2: device-resident hipGraph */
 int shl_mi355x_session_is_device_resident(struct csinn_session *sess);
+/* stream of a device-resident session: when every graph output is a DMABUF tensor csinn_session_run
+ * only enqueues (no synchronisation); wait with shl_mi355x_stream_sync on this stream */
+void *shl_mi355x_session_stream(struct csinn_session *sess);
+/* depthwise + pointwise pairs of `sess` that run as one fused launch (graph-level fusion) */
+int shl_mi355x_session_fused_pairs(struct csinn_session *sess);
 
 #ifdef __cplusplus
 }
