@@ -740,6 +740,7 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
 {
     constexpr int ESIZE = kI8 ? 1 : 2;
     __shared__ __attribute__((aligned(16))) int32_t red[KS == 4 ? 4 * 3 * 64 * 4 : 4];
+    if (a.debug & 128) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: scalar K-loop control
     const int n_tiles = (a.Co + 31) / 32;
