@@ -28,6 +28,8 @@ FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kern
     ("conv_igemm_regs_kernel<false", "conv_igemm_regs_f16_mfma32x32x16"),
     ("conv_stem_i8_kernel", "conv_stem_i8_dot4"),
     ("dwconv_nhwc_kernel<true", "dwconv_nhwc_i8"),
+    ("dwconv3x3_i8_dot4_kernel", "dwconv_nhwc_i8"),
+    ("dwpw_fused_kernel", "dwpw_fused_i8"),
     ("dwconv_nhwc_kernel<false", "dwconv_nhwc_f16"),
     ("conv_direct_kernel<true", "conv_direct_i8"),
     ("conv_direct_kernel<false", "conv_direct_f16"),
