@@ -214,6 +214,11 @@ bool stem_supports(const shl_mi355x_conv_desc &d);
 void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
 size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);
 int launch_conv_stem(const ConvArgs &a, hipStream_t s);
+// NCHW-native kernels for latency-bound sizes (nchw_small.hip)
+bool conv1x1_nchw_eligible(const ConvArgs &a);
+int launch_conv1x1_nchw(const ConvArgs &a, int dtype, hipStream_t s);
+bool dwconv_nchw_supports(const shl_mi355x_conv_desc &d);
+int launch_dwconv_nchw(const ConvArgs &a, int dtype, hipStream_t s);
 // depthwise 3x3 + pointwise 1x1 in one launch (dwpw_fused.hip)
 bool dwpw_fusable(const ConvArgs &dw, const ConvArgs &pw, int dw_dot4_packed, int pw_is_igemm);
 int launch_dwpw_fused(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);

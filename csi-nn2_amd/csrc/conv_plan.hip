@@ -99,7 +99,7 @@ static bool is_pow2_scale(float s)
 
 static int choose_algo(const shl_mi355x_conv_desc &d)
 {
-    if (is_depthwise(d)) return dwconv_supports(d) ? SHL_MI355X_ALGO_DW : SHL_MI355X_ALGO_DIRECT;
+    if (is_depthwise(d)) return (dwconv_supports(d) || dwconv_nchw_supports(d)) ? SHL_MI355X_ALGO_DW : SHL_MI355X_ALGO_DIRECT;
     if (d.group != 1) return -1;  // grouped convolution: SURVEY 8f3
     if (stem_supports(d)) return SHL_MI355X_ALGO_STEM;
     return igemm_supports(d) ? SHL_MI355X_ALGO_IGEMM : SHL_MI355X_ALGO_DIRECT;
@@ -162,7 +162,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         set_error("conv_plan_create: IGEMM needs group==1, NHWC and C*esize %% 16 == 0");
         return SHL_MI355X_ENOTSUP;
     }
-    if (algo == SHL_MI355X_ALGO_DW && !dwconv_supports(d)) {
+    if (algo == SHL_MI355X_ALGO_DW && !dwconv_supports(d) && !dwconv_nchw_supports(d)) {
         set_error("conv_plan_create: DW kernel needs NHWC, multiplier 1 and C %% 4 == 0");
         return SHL_MI355X_ENOTSUP;
     }
@@ -203,6 +203,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         p->kernel_name = "conv_stem_i8_dot4";
     } else if (algo == SHL_MI355X_ALGO_DW) {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "dwconv_nhwc_i8" : "dwconv_nhwc_f16";
+        if (d.layout == SHL_MI355X_NCHW) p->kernel_name = d.dtype == SHL_MI355X_I8 ? "dwconv3x3_nchw_i8" : "dwconv3x3_nchw_f16";
         if (dwconv_dot4_supports(d)) {
             p->kstride = 12;  // marks the [C][3 dwords] packing for launch_dwconv
             w_bytes = (size_t)d.in_c * 12;
@@ -416,6 +417,12 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
     switch (plan->algo) {
         case SHL_MI355X_ALGO_IGEMM: {
             if (d.layout == SHL_MI355X_NHWC) return launch_conv_igemm(a, d.dtype, d.layout, s);
+            // a 1x1 spatial extent on both sides (classifier on the pooled map): [N,C,1,1] and
+            // [N,1,1,C] are the same bytes, the NHWC kernels apply as they are
+            if (a.H * a.W == 1 && a.Ho * a.Wo == 1) return launch_conv_igemm(a, d.dtype, SHL_MI355X_NHWC, s);
+            // latency-bound pointwise layers read and write NCHW directly (nchw_small.hip)
+            if (!strcmp(igemm_variant(a.M, a.Co), "wave") && conv1x1_nchw_eligible(a))
+                return launch_conv1x1_nchw(a, d.dtype, s);
             // NCHW: [C][HW] -> [HW][C] scratch, NHWC kernel, [HoWo][Co] -> [Co][HoWo]
             if (a.N > d.batch || !plan->scratch_in) {
                 set_error("conv_forward: NCHW plan was created for batch %d, got %d", d.batch, a.N);
@@ -437,6 +444,7 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
             return launch_transpose(plan->scratch_out, output_dev, a.N, a.Ho * a.Wo, a.Co, es, s);
         }
         case SHL_MI355X_ALGO_DW:
+            if (d.layout == SHL_MI355X_NCHW) return launch_dwconv_nchw(a, d.dtype, s);
             return launch_dwconv(a, d.dtype, d.layout, s);
         case SHL_MI355X_ALGO_STEM:
             return launch_conv_stem(a, s);
