@@ -1023,7 +1023,10 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         // measured equal or slower than the plain tile kernels on the ResNet-50 set so far
         // (profiles/r01_notes.md): opt-in with SHL_MI355X_HALO=1
         static const char *halo_env = getenv("SHL_MI355X_HALO");
-        const bool want_halo = halo_env && halo_env[0] == '1';
+        bool want_halo = halo_env && halo_env[0] == '1';
+        // ... except its "resident" mode: Cout <= 64 with a K short enough for the whole weight tensor
+        // to sit in the ring (ResNet-50 64->64 @56: 45 -> see notes), on unless SHL_MI355X_HALO=0
+        if (!halo_env && tile == T256x64 && a.Kh * a.Kw * (a.C * esize / BKB) <= 10 && !a.out_nchw) want_halo = true;
         const int halo_tile = tile == T128 ? 0 : tile == T256x64 ? 1 : tile == T256x128 ? 2 : -1;
         if (want_halo && halo_tile >= 0 && halo_eligible(a, esize)) {
             const int rc = launch_conv_igemm_halo(a, dtype, halo_tile, s);

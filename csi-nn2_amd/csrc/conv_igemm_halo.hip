@@ -70,6 +70,15 @@ __host__ __device__ inline void halo_span(const ConvArgs &a, int pix0, int tbm, 
     if (npx < 1) npx = 1;
 }
 
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F &&>(f));
+    }
+}
+
 template <int MI, int WR, int WC, int NSTV>
 struct HaloGeom {
     static constexpr int NST = NSTV;  // weight ring depth; look-ahead NST-1 K steps
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
     const int nsteps = ncg * taps;
 
     const bool producer = wave >= G::NWAVES;
+    const bool resident = nsteps <= NST;  // the whole K extent of the weights fits the ring
     const bool dma_on = !(a.debug & 4);
     if (producer) {
         // =========================== producer waves: DMA issue and counted waits only ==========
@@ -163,6 +173,16 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
         constexpr int HL = LA - 2;  // batches that may still be in flight when step+1 must be complete
         if (dma_on)
             for (int piece = pw; piece < npieces; piece += G::NWAVES) issue_patch(piece, 0);
+        if (resident) {
+            // every weight slab fits the ring: request them all, wait once, and let the consumers
+            // free-run (no per-step hand-over); a second block on the CU overlaps its own loads
+            if (dma_on)
+                for (int st = 0; st < nsteps; ++st) issue_weights(st);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!(a.debug & 2)) __builtin_amdgcn_s_barrier();  // mirrors the consumers' epilogue barrier
+            return;
+        }
         int issued = 0;
         if (dma_on)
             for (int st = 0; st < LA && st < nsteps; ++st, ++issued) issue_weights(st);
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
         constexpr int next = (stage + 1) % NST;
         advance_cursor();  // -> step+1 (past the end on the last step: addresses stay inside the patch
                            //    buffers or the pad slot, the fetched data is never consumed)
-        __builtin_amdgcn_s_barrier();  // weights stage step+1 and the patch of step+1 are complete
+        if (!resident) __builtin_amdgcn_s_barrier();  // weights stage step+1 and the patch of step+1 are complete
         if (a.debug & 8) return;
 #pragma unroll
         for (int i = 0; i < MI; ++i) lds_read128_async<stage * G::WGT_B>(fa1[i], offA[i][1]);
@@ -346,16 +366,11 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
             for (int j = 0; j < 2; ++j) acc[i][j] = mfma<kI8>(fa1[i], fb1[j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int step = 0; step < nsteps; step += NST) {
-        body(std::integral_constant<int, 0>{}, step);
-        if (step + 1 < nsteps) body(std::integral_constant<int, 1>{}, step + 1);
-        if (step + 2 < nsteps) body(std::integral_constant<int, 2>{}, step + 2);
-        if (step + 3 < nsteps) body(std::integral_constant<int, 3>{}, step + 3);
-        if constexpr (NST > 4) {
-            if (step + 4 < nsteps) body(std::integral_constant<int, 4 % NST>{}, step + 4);
-            if (step + 5 < nsteps) body(std::integral_constant<int, 5 % NST>{}, step + 5);
-        }
-    }
+    for (int step = 0; step < nsteps; step += NST)
+        static_for<NST>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (step + i < nsteps) body(std::integral_constant<int, i>{}, step + i);
+        });
     lds_wait<0, MI>(fa0, fb0);  // the prefetch issued by the last step
     if (a.debug & 2) return;
 
@@ -478,7 +493,10 @@ int launch_conv_igemm_halo(const ConvArgs &a_in, int dtype, int tile, hipStream_
     const bool i8 = dtype == SHL_MI355X_I8;
     const int esize = i8 ? 1 : 2;
     static const char *ring_env = getenv("SHL_MI355X_RING");  // A/B: weight ring depth 4 | 6
-    const int nst = ring_env && ring_env[0] == '4' ? 4 : 6;
+    int nst = ring_env && ring_env[0] == '4' ? 4 : 6;
+    // 256 x 64 tile with a short K (ResNet-50's first stage: 9 steps): a 10-deep ring holds every
+    // weight slab -> the kernel's "resident" mode (one hand-over, no per-step barriers)
+    if (tile == 1 && (a_in.Kh * a_in.Kw) * (a_in.C * esize / BKB) <= 10) nst = 10;
     int tbm, tbn, nwaves = 4, wgt_stage;
     switch (tile) {
         case 1: tbm = 256; tbn = 64; break;
@@ -493,12 +511,14 @@ int launch_conv_igemm_halo(const ConvArgs &a_in, int dtype, int tile, hipStream_
     const int max_px = halo_max_pixels(a, tbm);
     const int pieces = (max_px + 15) / 16;
     // group g+1's patch is requested during the first taps-LA+1 = taps-nst+2 steps of group g
-    const int slots = taps - nst + 2;
-    if (slots < 1) return SHL_MI355X_ENOTSUP;
-    a.halo_pps = (pieces + nwaves * slots - 1) / (nwaves * slots);
-    if (a.halo_pps > 4) return SHL_MI355X_ENOTSUP;
-    a.halo_px = pieces * 16;
     const int ncg = a.C * esize / BKB;
+    const int slots = taps - nst + 2;
+    if (ncg > 1) {
+        if (slots < 1) return SHL_MI355X_ENOTSUP;
+        a.halo_pps = (pieces + nwaves * slots - 1) / (nwaves * slots);
+        if (a.halo_pps > 4) return SHL_MI355X_ENOTSUP;
+    }
+    a.halo_px = pieces * 16;
     size_t patch_area = (size_t)(ncg > 1 ? 2 : 1) * a.halo_px * BKB;  // one group: no double buffer
     if (patch_area < (size_t)stage_b) patch_area = stage_b;
     const size_t lds = patch_off + patch_area;
@@ -522,7 +542,9 @@ int launch_conv_igemm_halo(const ConvArgs &a_in, int dtype, int tile, hipStream_
     }
 #define SHL_HALO_RING(MI, WRV, WCV) \
     if (nst == 4) { SHL_HALO_EPI(MI, WRV, WCV, 4) } else { SHL_HALO_EPI(MI, WRV, WCV, 6) }
-    if (tile == 1) {
+    if (tile == 1 && nst == 10) {
+        SHL_HALO_EPI(2, 1, 4, 10)
+    } else if (tile == 1) {
         SHL_HALO_RING(2, 1, 4)
     } else if (tile == 2) {
         SHL_HALO_RING(4, 1, 4)
