@@ -215,6 +215,11 @@ def main():
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook: run every rank on ONE device over gloo (a 1-GPU box can then exercise the N > 1 code
+    # path: weight broadcast, replica agreement, barriers, max-over-ranks); never set by the driver
+    single_dev = os.environ.get("SHL_BENCH_SINGLE_DEVICE") == "1"
+    if single_dev:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
@@ -223,7 +228,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if single_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("csi-nn2_amd")
     wl = importlib.import_module("csi-nn2_amd.workloads")

@@ -251,6 +251,16 @@ static void rebind(struct dev_tensor *d, void *dev)
     d->shadow.data = dev;
 }
 
+/* back to a buffer of our own (the caller switched from an HBM buffer to host memory: the borrowed
+ * one may be gone, nothing may be copied into it) */
+static int unbind(struct dev_tensor *d)
+{
+    d->dev = shl_mi355x_malloc(d->bytes ? d->bytes : 16);
+    d->borrowed = 0;
+    d->shadow.data = d->dev;
+    return d->dev != NULL;
+}
+
 int shl_mi355x_session_setup(struct csinn_session *sess)
 {
     /* the reference's shl_gref_session_setup returns void (source/graph_ref/setup.c:688): its
@@ -333,16 +343,24 @@ int shl_mi355x_session_run(struct csinn_session *sess)
             shl_debug_error("mi355x: graph input %d has no data\n", i);
             return CSINN_FALSE;
         }
-        if (caller_buffer_is_device(d, t) && t->data != d->dev) {
+        const int on_dev = caller_buffer_is_device(d, t);
+        if (on_dev && t->data != d->dev) {
             rebind(d, t->data);
+            stale = 1;
+        } else if (!on_dev && d->borrowed) {
+            if (!unbind(d)) return CSINN_FALSE;
             stale = 1;
         }
     }
     for (int i = 0; i < g->output_num; i++) {
         struct dev_tensor *d = lookup(ds, g->output[i]);
         struct csinn_tensor *t = g->output[i]->data;
-        if (t->mtype == CSINN_MEM_TYPE_CPU_ACC && caller_buffer_is_device(d, t) && t->data != d->dev) {
+        const int on_dev = t->mtype == CSINN_MEM_TYPE_CPU_ACC && caller_buffer_is_device(d, t);
+        if (on_dev && t->data != d->dev) {
             rebind(d, t->data);
+            stale = 1;
+        } else if (!on_dev && d->borrowed) {
+            if (!unbind(d)) return CSINN_FALSE;
             stale = 1;
         }
     }

@@ -159,6 +159,42 @@ def test_residual_block_runs_device_resident(gpu, dtype, layout):
     net.close(fe)
 
 
+@pytest.mark.gpu
+def test_session_runs_in_place_on_caller_hbm_buffers_and_back_to_host(gpu):
+    """update_input / update_output with device pointers: no copies, asynchronous; switching back to
+    host tensors re-binds private buffers"""
+    import ctypes as C
+    fe, hip, opt = gpu
+    net = tail.MiniNet("int8", "NHWC")
+    sess = net.build(fe, pkg.API_MI355X)
+    dev = cases.HipDevice(hip)
+    x0, want0 = golden("mininet_int8_NHWC_0", "int8")
+    x1, want1 = golden("mininet_int8_NHWC_1", "int8")
+    assert_same(net.run(fe, x0), want0, "int8", "host run", lsb=1)
+    d_in, d_out = dev.alloc(x1.nbytes), dev.alloc(want1.nbytes)
+    dev.upload(d_in, x1)
+    keep = pkg.Keep()
+    t_in = pkg.make_tensor(fe, keep, x1.shape, pkg.DTYPE_INT8, pkg.LAYOUT_NHWC, sess=sess, device_ptr=d_in)
+    t_out = pkg.make_tensor(fe, keep, want1.shape, pkg.DTYPE_INT8, pkg.LAYOUT_NHWC, sess=sess, device_ptr=d_out)
+    fe.csinn_update_input(0, t_in, sess)
+    fe.csinn_update_output(0, t_out, sess)
+    for _ in range(3):
+        assert fe.csinn_session_run(sess) == pkg.CSINN_TRUE       # enqueues only
+    pkg.check(hip.shl_mi355x_stream_sync(opt.shl_mi355x_session_stream(sess)), hip, "sync")
+    assert_same(dev.download(d_out, want1.shape, np.int8), want1, "int8", "in-place device run", lsb=1)
+    # back to host tensors: output via a caller-owned host buffer (CPU_ACC), input from host
+    host_out = np.zeros(want0.shape, np.int8)
+    t_hout = pkg.make_tensor(fe, keep, want0.shape, pkg.DTYPE_INT8, pkg.LAYOUT_NHWC, data=host_out, sess=sess)
+    fe.csinn_update_output(0, t_hout, sess)
+    t_hin = pkg.make_tensor(fe, keep, x0.shape, pkg.DTYPE_INT8, pkg.LAYOUT_NHWC, data=x0, sess=sess)
+    fe.csinn_update_input(0, t_hin, sess)
+    assert fe.csinn_session_run(sess) == pkg.CSINN_TRUE
+    assert_same(host_out, want0, "int8", "host run after device runs", lsb=1)
+    dev.free(d_in)
+    dev.free(d_out)
+    net.close(fe)
+
+
 DROPIN_MODEL = r"""
 import sys
 sys.path.insert(0, %(tests)r)
