@@ -118,20 +118,59 @@ __device__ __forceinline__ int requant_i8_t(int32_t S, float mult, float bias_f,
     }
 }
 
-// run-time dispatch of the same code (kernels that are not specialised on EPI)
-__device__ __forceinline__ int requant_i8_fast(int32_t S, float mult, float bias_f, const ConvArgs &a)
-{
-    if (a.act != SHL_MI355X_ACT_NONE && !a.act_clamp)
-        return a.div_exact ? requant_i8_t<5>(S, mult, bias_f, a) : requant_i8_t<2>(S, mult, bias_f, a);
-    return a.div_exact ? requant_i8_t<3>(S, mult, bias_f, a) : requant_i8_t<0>(S, mult, bias_f, a);
-}
-
 // four saturated int8 values -> one dword (v_perm_b32 x3)
 __device__ __forceinline__ uint32_t pack4_i8(int q0, int q1, int q2, int q3)
 {
     const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);
     const uint32_t hi = __builtin_amdgcn_perm((uint32_t)q3, (uint32_t)q2, 0x0c0c0400u);
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+// Four outputs at once -> one packed dword.  For the clamp epilogues (EPI % 3 != 2) the multiply /
+// add / multiply chain runs on packed fp32 (v_pk_mul_f32, v_pk_add_f32: two IEEE single operations
+// per instruction, same roundings as the scalar code -- nothing is contracted), which is a third
+// fewer VALU instructions in the tile kernels' epilogues.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int EPI>
+__device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3, const float4 &m, const float4 &b,
+                                                  const ConvArgs &a)
+{
+    if constexpr (EPI % 3 == 2) {
+        return pack4_i8(requant_i8_t<EPI>(s0, m.x, b.x, a), requant_i8_t<EPI>(s1, m.y, b.y, a),
+                        requant_i8_t<EPI>(s2, m.z, b.z, a), requant_i8_t<EPI>(s3, m.w, b.w, a));
+    } else {
+        v2f lo = {(float)s0, (float)s1}, hi = {(float)s2, (float)s3};
+        const v2f mlo = {m.x, m.y}, mhi = {m.z, m.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
+        lo = lo * mlo;
+        hi = hi * mhi;
+        lo = lo + blo;
+        hi = hi + bhi;
+        if constexpr (EPI >= 3) {
+            const v2f inv = {a.inv_out_scale, a.inv_out_scale};
+            lo = lo * inv;
+            hi = hi * inv;
+        } else {
+            lo = v2f{__fdiv_rn(lo.x, a.out_scale), __fdiv_rn(lo.y, a.out_scale)};
+            hi = v2f{__fdiv_rn(hi.x, a.out_scale), __fdiv_rn(hi.y, a.out_scale)};
+        }
+        const v2f zp = {a.out_zp_f, a.out_zp_f};
+        lo = v2f{rintf(lo.x), rintf(lo.y)} + zp;
+        hi = v2f{rintf(hi.x), rintf(hi.y)} + zp;
+        const int q0 = (int)__builtin_amdgcn_fmed3f(lo.x, a.clamp_lo, a.clamp_hi);
+        const int q1 = (int)__builtin_amdgcn_fmed3f(lo.y, a.clamp_lo, a.clamp_hi);
+        const int q2 = (int)__builtin_amdgcn_fmed3f(hi.x, a.clamp_lo, a.clamp_hi);
+        const int q3 = (int)__builtin_amdgcn_fmed3f(hi.y, a.clamp_lo, a.clamp_hi);
+        return pack4_i8(q0, q1, q2, q3);
+    }
+}
+
+// run-time dispatch of the same code (kernels that are not specialised on EPI)
+__device__ __forceinline__ int requant_i8_fast(int32_t S, float mult, float bias_f, const ConvArgs &a)
+{
+    if (a.act != SHL_MI355X_ACT_NONE && !a.act_clamp)
+        return a.div_exact ? requant_i8_t<5>(S, mult, bias_f, a) : requant_i8_t<2>(S, mult, bias_f, a);
+    return a.div_exact ? requant_i8_t<3>(S, mult, bias_f, a) : requant_i8_t<0>(S, mult, bias_f, a);
 }
 
 // 4x4 byte transpose: in[i] holds bytes (row i, col 0..3); out[j] holds (row 0..3, col j)

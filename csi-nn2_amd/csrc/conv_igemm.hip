@@ -522,17 +522,16 @@ __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile
                         if constexpr (kI8) {
                             const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + ch);
                             const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + ch);
-                            const int q0 = requant_i8_t<EPI>(acc[i][j][4 * g + 0] + ai.x, mu.x, bi.x, a);
-                            const int q1 = requant_i8_t<EPI>(acc[i][j][4 * g + 1] + ai.y, mu.y, bi.y, a);
-                            const int q2 = requant_i8_t<EPI>(acc[i][j][4 * g + 2] + ai.z, mu.z, bi.z, a);
-                            const int q3 = requant_i8_t<EPI>(acc[i][j][4 * g + 3] + ai.w, mu.w, bi.w, a);
+                            const uint32_t pk = requant4_i8_t<EPI>(acc[i][j][4 * g + 0] + ai.x, acc[i][j][4 * g + 1] + ai.y,
+                                                                   acc[i][j][4 * g + 2] + ai.z, acc[i][j][4 * g + 3] + ai.w, mu, bi, a);
+                            const int q0 = (int8_t)pk, q1 = (int8_t)(pk >> 8), q2 = (int8_t)(pk >> 16), q3 = (int8_t)(pk >> 24);
                             if (a.out_nchw) {
                                 dst_t[0] = (char)q0;
                                 dst_t[PITCH] = (char)q1;
                                 dst_t[2 * PITCH] = (char)q2;
                                 dst_t[3 * PITCH] = (char)q3;
                             } else {
-                                *reinterpret_cast<uint32_t *>(dst) = pack4_i8(q0, q1, q2, q3);
+                                *reinterpret_cast<uint32_t *>(dst) = pk;
                             }
                         } else {
                             const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
@@ -820,11 +819,8 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
         if (p >= a.M || occ >= a.Co) return;
         const int64_t o = (int64_t)p * a.Co + occ;
         if constexpr (kI8) {
-            const int q0 = requant_i8_t<EPI>(v_i[0] + ai[g_tab].x, mu[g_tab].x, bi[g_tab].x, a);
-            const int q1 = requant_i8_t<EPI>(v_i[1] + ai[g_tab].y, mu[g_tab].y, bi[g_tab].y, a);
-            const int q2 = requant_i8_t<EPI>(v_i[2] + ai[g_tab].z, mu[g_tab].z, bi[g_tab].z, a);
-            const int q3 = requant_i8_t<EPI>(v_i[3] + ai[g_tab].w, mu[g_tab].w, bi[g_tab].w, a);
-            const uint32_t packed = pack4_i8(q0, q1, q2, q3);
+            const uint32_t packed = requant4_i8_t<EPI>(v_i[0] + ai[g_tab].x, v_i[1] + ai[g_tab].y, v_i[2] + ai[g_tab].z,
+                                                       v_i[3] + ai[g_tab].w, mu[g_tab], bi[g_tab], a);
             int8_t *out = static_cast<int8_t *>(a.out);
             if (vec_ok) {
                 *reinterpret_cast<uint32_t *>(out + o) = packed;

@@ -404,11 +404,9 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
                     if constexpr (kI8) {
                         const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + ch);
                         const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + ch);
-                        const int q0 = requant_i8_t<EPI>(acc[i][j][4 * g + 0] + ai.x, mu.x, bi.x, a);
-                        const int q1 = requant_i8_t<EPI>(acc[i][j][4 * g + 1] + ai.y, mu.y, bi.y, a);
-                        const int q2 = requant_i8_t<EPI>(acc[i][j][4 * g + 2] + ai.z, mu.z, bi.z, a);
-                        const int q3 = requant_i8_t<EPI>(acc[i][j][4 * g + 3] + ai.w, mu.w, bi.w, a);
-                        *reinterpret_cast<uint32_t *>(dst) = pack4_i8(q0, q1, q2, q3);
+                        *reinterpret_cast<uint32_t *>(dst) = requant4_i8_t<EPI>(
+                            acc[i][j][4 * g + 0] + ai.x, acc[i][j][4 * g + 1] + ai.y, acc[i][j][4 * g + 2] + ai.z,
+                            acc[i][j][4 * g + 3] + ai.w, mu, bi, a);
                     } else {
                         const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
                         const uint32_t h1 = finish_f16(acc[i][j][4 * g + 1], bi.y, a);

@@ -172,12 +172,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_dot4_kernel(ConvArgs a)
         acc[ch] = __builtin_amdgcn_sdot4((int)t1[ch], (int)wk[3 * ch + 1], acc[ch], false);
         acc[ch] = __builtin_amdgcn_sdot4((int)t2, (int)wk[3 * ch + 2], acc[ch], false);
     }
-    const int q0 = requant_i8_t<EPI>(acc[0], mu.x, bi.x, a);
-    const int q1 = requant_i8_t<EPI>(acc[1], mu.y, bi.y, a);
-    const int q2 = requant_i8_t<EPI>(acc[2], mu.z, bi.z, a);
-    const int q3 = requant_i8_t<EPI>(acc[3], mu.w, bi.w, a);
     const int64_t o = ((int64_t)row * a.Wo + ox) * a.C + c;
-    *reinterpret_cast<uint32_t *>(static_cast<int8_t *>(a.out) + o) = pack4_i8(q0, q1, q2, q3);
+    *reinterpret_cast<uint32_t *>(static_cast<int8_t *>(a.out) + o) =
+        requant4_i8_t<EPI>(acc[0], acc[1], acc[2], acc[3], mu, bi, a);
 }
 
 bool dwconv_dot4_supports(const shl_mi355x_conv_desc &d)
