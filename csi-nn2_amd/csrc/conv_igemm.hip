@@ -190,9 +190,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const Acc &acc, in
 //                 barrier + LDS latency + MFMA in series (600-700 cycles measured with one wave
 //                 per SIMD, profiles/r01_notes.md).
 
-template <int MI, int WR, int WC, bool PIPE>
-struct TileGeom {
-    static constexpr int NST = PIPE ? 4 : 3;  // ring depth
+template <int MI, int WR, int WC, int PIPE>  // PIPE: 0 = every wave loads and computes, ring of 3;
+struct TileGeom {                            //       N > 0 = producer / consumer waves, ring of N
+    static constexpr int NST = PIPE ? PIPE : 3;  // ring depth
     static constexpr int NWAVES = WR * WC;     // MFMA waves (PIPE adds as many DMA waves)
     static constexpr int THREADS = 64 * NWAVES * (PIPE ? 2 : 1);
     static constexpr int TBN = 32 * MI * WR;       // channels per block
@@ -209,7 +209,7 @@ struct TileGeom {
     static_assert(TBM % (16 * NWAVES) == 0 && TBN % (16 * NWAVES) == 0, "DMA rows must divide evenly");
 };
 
-template <bool kI8, int EPI, int MI, int WR, int WC, bool kUniformTap, bool PIPE>
+template <bool kI8, int EPI, int MI, int WR, int WC, bool kUniformTap, int PIPE>
 __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile_kernel(ConvArgs a)
 {
     using G = TileGeom<MI, WR, WC, PIPE>;
@@ -401,10 +401,14 @@ __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     auto read_frags = [&](auto stage_c, auto kk_c, v4i (&fa)[MI], v4i (&fb)[2]) {
         constexpr int st = decltype(stage_c)::value, kk = decltype(kk_c)::value;
+        // the ds_read offset field is 16 bits: stages past 64 KiB go through a second base (+64 KiB)
+        constexpr int full = st * G::STAGE_B;
+        constexpr int imm = full & 0xFFFF;
+        const uint32_t base = lds0 + (full & ~0xFFFF);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) lds_read128_async<st * G::STAGE_B>(fa[i], lds0 + offA[i][kk]);
+        for (int i = 0; i < MI; ++i) lds_read128_async<imm>(fa[i], base + offA[i][kk]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) lds_read128_async<st * G::STAGE_B>(fb[j], lds0 + offB[j][kk]);
+        for (int j = 0; j < 2; ++j) lds_read128_async<imm>(fb[j], base + offB[j][kk]);
     };
     auto mfma_group = [&](const v4i (&fa)[MI], const v4i (&fb)[2]) {
 #pragma unroll
@@ -436,18 +440,18 @@ __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile
         if (wave >= G::NWAVES) {
             // ---- producer waves: nothing but DMA issue and counted waits.  Barrier sequence must
             // mirror the consumers': one before the loop, one per step, one in the staged epilogue.
-            if (nsteps > 2) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PER_STAGE) : "memory");
-            } else if (nsteps == 2) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // stage 0 has landed once only the younger stages of the prologue remain in flight
+            {
+                const int issued = nsteps < LA ? nsteps : LA;
+                wait_vmcnt_dyn((issued - 1) * G::PER_STAGE);
             }
             __builtin_amdgcn_s_barrier();
             for (int step = 0; step < nsteps; ++step) {
-                // certify stage step+1: of the stages issued so far only step+2 may still be in flight
-                if (step + 2 < nsteps) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_STAGE) : "memory");
+                // certify stage step+1: stages step+2 .. step+LA-1 (LA-2 of them) may still be in flight.
+                // The deeper the ring, the more DMA latency is hidden: with two stages in flight a K
+                // step cannot be shorter than half the DMA latency (profiles/r01_notes.md)
+                if (step + LA - 1 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 2) * G::PER_STAGE) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -471,12 +475,11 @@ __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage 0 is complete
         read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fa0, fb0);
-        for (int step = 0; step < nsteps; step += NST) {
-            pipe_body(std::integral_constant<int, 0>{}, step);
-            if (step + 1 < nsteps) pipe_body(std::integral_constant<int, 1>{}, step + 1);
-            if (step + 2 < nsteps) pipe_body(std::integral_constant<int, 2>{}, step + 2);
-            if (step + 3 < nsteps) pipe_body(std::integral_constant<int, 3 % NST>{}, step + 3);
-        }
+        for (int step = 0; step < nsteps; step += NST)
+            static_for<NST>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if (step + i < nsteps) pipe_body(std::integral_constant<int, i>{}, step + i);
+            });
         lds_wait<0, MI>(fa0, fb0);  // the prefetch of the step after the last one
     } else {
         for (int step = 0; step < nsteps; step += NST) {
@@ -968,7 +971,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     size_t lds = 0;
     int threads = 256;
     int kind;  // 0 wave, 1 regs, 2 tile
-    bool pipe = false;
+    int pipe = 0;  // 0: plain ring-3 kernel, N: producer/consumer waves with an N-deep ring
     // tile flavours (see the kernel header); uniform-tap addressing when a K step stays in a tap
     const bool utap = (a.C * esize) % 64 == 0 && a.Kh * a.Kw <= 32;
     enum { T128, T256x64, T256x128, T256x256 } tile = T128;
@@ -1004,14 +1007,18 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         }
         // producer/consumer wave specialisation (PIPE): wins on the 128x128 tile (-2..-25 % on the
         // ResNet-50 3x3 set), loses on 256x64 where its 4-stage ring costs a block of occupancy
-        static const char *pipe_env = getenv("SHL_MI355X_PIPE");
-        pipe = pipe_env ? pipe_env[0] == '1' : (tile == T128);
+        static const char *pipe_env = getenv("SHL_MI355X_PIPE");  // 0 | 1 (= 4) | 4 | 8
+        pipe = tile == T128 ? 4 : 0;
+        // at most one block per CU anyway: spend the LDS on an 8-deep ring (512->512 @14 s2: 31 -> 27 us;
+        // with more tiles the second block per CU is worth more than the deeper ring)
+        if (tile == T128 && utap && (int64_t)((a.M + 127) / 128) * ((a.Co + 127) / 128) <= 256) pipe = 8;
+        if (pipe_env) pipe = pipe_env[0] == '8' ? 8 : (pipe_env[0] == '0' ? 0 : 4);
         int tbm = 128, tbn = 128;
         switch (tile) {
-            case T256x64: tbm = 256; tbn = 64; lds = pipe ? TileGeom<2, 1, 4, true>::LDS_B : TileGeom<2, 1, 4, false>::LDS_B; break;
-            case T256x128: tbm = 256; tbn = 128; lds = TileGeom<4, 1, 4, false>::LDS_B; pipe = false; break;
-            case T256x256: tbm = 256; tbn = 256; lds = TileGeom<4, 2, 4, false>::LDS_B; threads = 512; pipe = false; break;
-            default: lds = pipe ? TileGeom<2, 2, 2, true>::LDS_B : TileGeom<2, 2, 2, false>::LDS_B; break;
+            case T256x64: tbm = 256; tbn = 64; if (pipe) pipe = 4; lds = pipe ? TileGeom<2, 1, 4, 4>::LDS_B : TileGeom<2, 1, 4, 0>::LDS_B; break;
+            case T256x128: tbm = 256; tbn = 128; lds = TileGeom<4, 1, 4, 0>::LDS_B; pipe = 0; break;
+            case T256x256: tbm = 256; tbn = 256; lds = TileGeom<4, 2, 4, 0>::LDS_B; threads = 512; pipe = 0; break;
+            default: lds = pipe == 8 ? TileGeom<2, 2, 2, 8>::LDS_B : pipe ? TileGeom<2, 2, 2, 4>::LDS_B : TileGeom<2, 2, 2, 0>::LDS_B; break;
         }
         grid = dim3((unsigned)(((a.M + tbm - 1) / tbm) * ((a.Co + tbn - 1) / tbn)));
         if (pipe) threads *= 2;  // as many DMA waves as MFMA waves
@@ -1044,7 +1051,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     if (i8) { SHL_LAUNCH_EPI(conv_igemm_tile_kernel, SHL_COMMA MI SHL_COMMA WRV SHL_COMMA WCV SHL_COMMA UT SHL_COMMA PP) } \
     else { SHL_LAUNCH(conv_igemm_tile_kernel<false, 0, MI, WRV, WCV, UT, PP>); }
 #define SHL_TILE(MI, WRV, WCV, UT) \
-    if (pipe) { SHL_TILE_P(MI, WRV, WCV, UT, true) } else { SHL_TILE_P(MI, WRV, WCV, UT, false) }
+    if (pipe) { SHL_TILE_P(MI, WRV, WCV, UT, 4) } else { SHL_TILE_P(MI, WRV, WCV, UT, 0) }
     if (kind == 0) {
         if (splitk) {
             if (i8) { SHL_LAUNCH_EPI(conv_igemm_wave_kernel, SHL_COMMA 4) } else { SHL_LAUNCH(conv_igemm_wave_kernel<false, 0, 4>); }
@@ -1054,11 +1061,13 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     } else if (kind == 1) {
         if (i8) { SHL_LAUNCH_EPI(conv_igemm_regs_kernel) } else { SHL_LAUNCH(conv_igemm_regs_kernel<false, 0>); }
     } else if (tile == T256x256) {
-        SHL_TILE_P(4, 2, 4, true, false)
+        SHL_TILE_P(4, 2, 4, true, 0)
     } else if (tile == T256x128) {
-        SHL_TILE_P(4, 1, 4, true, false)
+        SHL_TILE_P(4, 1, 4, true, 0)
     } else if (tile == T256x64) {
         if (utap) { SHL_TILE(2, 1, 4, true) } else { SHL_TILE(2, 1, 4, false) }
+    } else if (pipe == 8 && utap) {
+        SHL_TILE_P(2, 2, 2, true, 8)
     } else {
         if (utap) { SHL_TILE(2, 2, 2, true) } else { SHL_TILE(2, 2, 2, false) }
     }

@@ -70,15 +70,6 @@ __host__ __device__ inline void halo_span(const ConvArgs &a, int pix0, int tbm, 
     if (npx < 1) npx = 1;
 }
 
-template <int N, typename F, int I = 0>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, F, I + 1>(static_cast<F &&>(f));
-    }
-}
-
 template <int MI, int WR, int WC, int NSTV>
 struct HaloGeom {
     static constexpr int NST = NSTV;  // weight ring depth; look-ahead NST-1 K steps

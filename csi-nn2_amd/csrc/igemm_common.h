@@ -80,6 +80,16 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n)
 #undef SHL_W
 }
 
+// compile-time unrolled loop: f(std::integral_constant<int, 0>) ... f(<N-1>)
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F &&>(f));
+    }
+}
+
 // XCD-aware block order: hardware hands workgroup b to XCD b % 8.  Returns the logical tile index
 // such that each XCD works on one contiguous run of logical tiles (neighbouring tiles share
 // activations / weights in that XCD's L2).  Bijection on [0, nb).
