@@ -344,6 +344,35 @@ def main():
                 rc.release()
                 del hbm2
         if args.extra and args.workload == "mobilenetv1":
+            # serving view: independent batch-1 requests in flight on several streams of ONE GPU (the
+            # headline `value` is strictly one request at a time; a single chain leaves most CUs idle)
+            nstreams = 4
+            chains, streams = [], []
+            for k in range(nstreams):
+                hk = TorchHBM(torch, torch.device("cuda", local_rank))
+                ck = wl.LayerChain(fe, hip, opt, layers, batch, hk.alloc, hk.upload, dtype=args.dtype, layout=layout,
+                                   seed=1234, chained=chained)
+                sk = hip.shl_mi355x_stream_create()
+                ck.capture(sk)
+                chains.append((ck, hk))
+                streams.append(sk)
+            for ck, _ in chains:
+                ck.replay()
+            for sk in streams:
+                hip.shl_mi355x_stream_sync(sk)
+            reps = 100
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for ck, _ in chains:
+                    ck.replay()
+            for sk in streams:
+                hip.shl_mi355x_stream_sync(sk)
+            dt_c = time.perf_counter() - t0
+            result["concurrent_streams"] = {"streams": nstreams, "images_per_sec": nstreams * reps * batch / dt_c,
+                                            "note": "independent batch-1 chains on separate HIP streams of one GPU"}
+            for ck, _ in chains:
+                ck.release()
+            del chains
             # whole model through csinn_session_run with HOST input / output tensors: H2D + one
             # hipGraph replay (28 convs + avgpool + softmax) + D2H + sync per image
             ms = wl.ModelSession(fe, pkg.API_MI355X, args.dtype, layout)
