@@ -17,11 +17,12 @@
 //   with 4 consecutive output channels of one pixel: one 4-byte (int8) or 8-byte (f16) NHWC store.
 //
 // Three kernels share that formulation:
-//   conv_igemm_tile_kernel   128(pixel) x 128(cout) block tile, 4 waves x (64x64), K step 64 B.
+//   conv_igemm_tile_kernel   128(pixel) x 128(cout) block tile, 4 MFMA waves x (64x64), K step 64 B.
 //                            Operands stream HBM/L2 -> LDS with global_load_lds_dwordx4 (no
-//                            VGPR round trip) through a 3-stage ring: two K steps are in flight
-//                            while one is consumed, waits are counted (s_waitcnt vmcnt(4)) and
-//                            the only synchronisation is one raw s_barrier per step.  LDS rows are
+//                            VGPR round trip) through a 3/4/8-stage ring, by the MFMA waves
+//                            themselves or by dedicated producer waves; waits are counted
+//                            (s_waitcnt vmcnt(n)) and the only synchronisation is one raw
+//                            s_barrier per step.  LDS rows are
 //                            unpadded 64 B (the DMA destination is lane-linear); bank conflicts
 //                            of the ds_read_b128 fragment reads are removed by XOR-ing the chunk
 //                            slot with (row >> 2) & 3 on the SOURCE side of the DMA and on the read.
@@ -165,7 +166,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const Acc &acc, in
 }
 
 // =================================================================================================
-// conv_igemm_tile_kernel: global_load_lds 3-stage ring, block tile = (64*WC pixels) x (32*MI*WR
+// conv_igemm_tile_kernel: global_load_lds ring, block tile = (64*WC pixels) x (32*MI*WR
 // channels), WR*WC waves, each wave MI x 2 MFMA tiles (32*MI channels x 64 pixels).
 //   <MI=2, WR=2, WC=2>  128 x 128, 4 waves   general purpose
 //   <MI=2, WR=1, WC=4>  256 x  64, 4 waves   Cout <= 64 (a wider channel tile would multiply zeros)
@@ -182,13 +183,19 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const Acc &acc, in
 //           tests two bits of per-pixel ky / kx validity masks built in the prologue.
 // =================================================================================================
 // Two loop structures share the kernel:
-//   PIPE = false  3-stage ring.  Step t: wait DMA(t), barrier, issue DMA(t+2), read fragments, MFMA.
-//   PIPE = true   4-stage ring, software pipelined.  The barrier of step t certifies stage t+1, so
-//                 the fragments of (t+1, kk0) are fetched from LDS while the MFMAs of (t, kk1) run
-//                 and every MFMA group starts with its operands already in registers: a wave's
-//                 K step is then paced by the matrix pipe (256 cycles) instead of by
-//                 barrier + LDS latency + MFMA in series (600-700 cycles measured with one wave
-//                 per SIMD, profiles/r01_notes.md).
+//   PIPE = 0   3-stage ring, every wave loads and computes.  Step t: wait DMA(t), barrier, issue
+//              DMA(t+2), read fragments, MFMA.
+//   PIPE = N   (4 or 8) wave specialisation over an N-stage ring: WR*WC consumer waves (LDS fragment
+//              reads + MFMA, no VMEM) and as many producer waves (global_load_lds issue + counted
+//              vmcnt waits), one of each per SIMD, one s_barrier per K step.  An LDS-DMA instruction
+//              holds its wave ~70 cycles at issue: inside one instruction stream that time is taken
+//              from the MFMAs (interleaving them measured slower), in a separate wave it is not.
+//              The barrier of step t certifies stage t+1, so consumers fetch the fragments of
+//              (t+1, kk0) while the MFMAs of (t, kk1) run: MI+2 ds_read_b128 stay in flight across
+//              every counted lgkmcnt wait (inline-asm reads, see igemm_common.h -- hipcc's own
+//              waitcnt insertion drains to 0 and undoes the pipelining).  N = 8 when a layer has at
+//              most one block per CU anyway (deeper look-ahead for free), N = 4 otherwise (two
+//              blocks per CU).  Numbers: profiles/r01_notes.md.
 
 template <int MI, int WR, int WC, int PIPE>  // PIPE: 0 = every wave loads and computes, ring of 3;
 struct TileGeom {                            //       N > 0 = producer / consumer waves, ring of N
