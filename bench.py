@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--layout", default="", choices=["", "NHWC", "NCHW"])
     ap.add_argument("--extra", action="store_true", help="also time the ResNet-50 3x3 set at batch 128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="every layer its own launch (no pointwise+depthwise fusion)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--detail", action="store_true", help="print the per-layer table to stderr")
@@ -141,16 +142,17 @@ class TorchHBM:
 
 
 def time_groups(chain, hip, opt, stream, reps=20):
-    """Average launch duration per layer, measured with HIP events recorded on the launch stream
-    around `reps` back-to-back launches of that layer (captured in a graph: no host gaps)."""
+    """Average duration of every launch of one pass (a layer, or a fused pointwise + depthwise pair),
+    measured with HIP events recorded on the launch stream around `reps` back-to-back launches of it
+    (captured in a graph: no host gaps)."""
     out = []
     ev0, ev1 = hip.shl_mi355x_event_create(), hip.shl_mi355x_event_create()
     ms = C.c_float()
-    for i in range(len(chain.entries)):
+    for u in range(len(chain.units)):
         opt.shl_mi355x_set_stream(stream)
         hip.shl_mi355x_graph_begin(stream)
         for _ in range(reps):
-            chain.run_layer(i)
+            chain.run_unit(u)
         g = hip.shl_mi355x_graph_end(stream)
         hip.shl_mi355x_graph_launch(g, stream)  # warm
         hip.shl_mi355x_stream_sync(stream)
@@ -170,11 +172,11 @@ def time_groups(chain, hip, opt, stream, reps=20):
 
 def summarise_kernels(chain, wl, per_layer_s, bound_hint):
     groups = {}
-    for e, t in zip(chain.entries, per_layer_s):
-        g = groups.setdefault(e["kernel_name"], dict(time=0.0, bytes=0, ops=0, launches=0))
+    for u, t in enumerate(per_layer_s):
+        g = groups.setdefault(chain.unit_kernel_name(u), dict(time=0.0, bytes=0, ops=0, launches=0))
         g["time"] += t
-        g["bytes"] += wl.layer_bytes(e["layer"], chain.batch, chain.esize)
-        g["ops"] += wl.layer_ops(e["layer"], chain.batch)
+        g["bytes"] += chain.unit_bytes(u)
+        g["ops"] += chain.unit_ops(u)
         g["launches"] += 1
     name, g = max(groups.items(), key=lambda kv: kv[1]["time"])
     if bound_hint == "hbm":
@@ -250,10 +252,13 @@ def main():
     else:
         layers, batch, chained, bound = wl.RESNET50_3X3, args.batch or 128, False, "mfma"
         layout = args.layout or "NHWC"
+    # the graph-level rewrite csinn_session_setup applies on this backend (session.c plan_fusion):
+    # pointwise + the depthwise layer that consumes it = one launch
+    fuse = chained and args.dtype == "int8" and layout == "NHWC" and not args.no_fuse
     # rank 0 owns the real weights; other ranks build their plans from a different seed and must
     # receive rank 0's packed blocks over RCCL before they can agree with it
     chain = wl.LayerChain(fe, hip, opt, layers, batch, hbm.alloc, hbm.upload, dtype=args.dtype, layout=layout,
-                          seed=1234 if rank == 0 else 999 + rank, chained=chained)
+                          seed=1234 if rank == 0 else 999 + rank, chained=chained, fuse=fuse)
     if world > 1:
         par.broadcast_plan_blocks(chain, torch, dist, hip, src=0)
         par.assert_replicas_agree(chain, torch, dist, hip)
@@ -289,8 +294,9 @@ def main():
         "vs_baseline": None, "dtype": "u8" if args.dtype == "int8" else "f16", "data": "synthetic",
         "conv_gops": ops_per_step * args.steps / elapsed / 1e9,
         "images_per_sec": images / elapsed,
-        "config": {"workload": "%s %s %s, %d conv layers, batch %d per GPU, hipGraph replay via csinn_* C API"
-                               % (args.workload, args.dtype, layout, len(layers), batch),
+        "config": {"workload": "%s %s %s, %d conv layers in %d launches%s, batch %d per GPU, hipGraph replay via csinn_* C API"
+                               % (args.workload, args.dtype, layout, len(layers), len(chain.units),
+                                  " (pointwise+depthwise pairs fused as csinn_session_setup does)" if fuse else "", batch),
                    "per_gpu_batch": batch, "parallelism": "replicas x%d (batch shard, RCCL weight bcast)" % world,
                    "ops_per_image": chain.total_ops() // batch, "algorithmic_bytes_per_image": chain.total_bytes() // batch,
                    "device": arch.value.decode(), "compute_units": cus.value},
@@ -318,11 +324,10 @@ def main():
                              for k, v in groups.items()}
         result["sum_layer_us"] = sum(per_layer) * 1e6
         if args.detail:
-            for e, t in zip(chain.entries, per_layer):
-                L = e["layer"]
-                sys.stderr.write("%-28s %-28s %8.2f us %8.1f GB/s %8.2f TOP/s\n" % (
-                    wl.layer_name(L), e["kernel_name"], t * 1e6,
-                    wl.layer_bytes(L, batch, chain.esize) / t / 1e9, wl.layer_ops(L, batch) / t / 1e12))
+            for u, t in enumerate(per_layer):
+                sys.stderr.write("%-52s %-32s %8.2f us %8.1f GB/s %8.2f TOP/s\n" % (
+                    chain.unit_name(u), chain.unit_kernel_name(u), t * 1e6,
+                    chain.unit_bytes(u) / t / 1e9, chain.unit_ops(u) / t / 1e12))
         if args.extra and args.workload == "mobilenetv1":
             # the other single-GPU configurations of BASELINE.json, per-layer graph timing (no chaining)
             extras = [
@@ -351,7 +356,7 @@ def main():
             for k in range(nstreams):
                 hk = TorchHBM(torch, torch.device("cuda", local_rank))
                 ck = wl.LayerChain(fe, hip, opt, layers, batch, hk.alloc, hk.upload, dtype=args.dtype, layout=layout,
-                                   seed=1234, chained=chained)
+                                   seed=1234, chained=chained, fuse=fuse)
                 sk = hip.shl_mi355x_stream_create()
                 ck.capture(sk)
                 chains.append((ck, hk))
@@ -390,6 +395,28 @@ def main():
                 "images_per_sec": 1.0 / dt_s, "ms_per_image": dt_s * 1e3, "layers": ms.n_layers,
                 "device_mode": {0: "host-staged", 1: "device eager", 2: "device hipGraph"}[mode]}
             ms.close()
+            # the same session with its input and output tensors in HBM (csinn_update_input / _output with
+            # device buffers): csinn_session_run only enqueues the captured graph; one sync at the end
+            hio = TorchHBM(torch, torch.device("cuda", local_rank))
+            d_in = hio.alloc(224 * 224 * 3 * (1 if args.dtype == "int8" else 2))
+            d_out = hio.alloc(1000 * (1 if args.dtype == "int8" else 2))
+            hio.upload(d_in, x)
+            msd = wl.ModelSession(fe, pkg.API_MI355X, args.dtype, layout, dev_in=d_in, dev_out=d_out)
+            sst = opt.shl_mi355x_session_stream(msd.sess)
+            for _ in range(10):
+                msd.run_async()
+            hip.shl_mi355x_stream_sync(sst)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                msd.run_async()
+            hip.shl_mi355x_stream_sync(sst)
+            dt_d = (time.perf_counter() - t0) / reps
+            result["session_device_io"] = {
+                "workload": "mobilenetv1 %s %s whole model via csinn_session_run, input/output tensors in HBM" % (args.dtype, layout),
+                "images_per_sec": 1.0 / dt_d, "ms_per_image": dt_d * 1e3, "layers": msd.n_layers,
+                "fused_pairs": opt.shl_mi355x_session_fused_pairs(msd.sess)}
+            msd.close()
+            del hio
         if world > 1:  # the CPU baseline is a property of the node: measured by the N=1 run only
             result["cpu_baseline"] = {"value": None, "unit": "GOPS", "cores": 0, "kind": "reference",
                                       "sample": "measured by the N=1 run only"}

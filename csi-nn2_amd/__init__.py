@@ -199,6 +199,8 @@ def load_hip():
         "shl_mi355x_conv_forward": (C.c_int, [vp, vp, vp, i32, vp]),
         "shl_mi355x_dwpw_fusable": (C.c_int, [vp, vp, i32]),
         "shl_mi355x_dwpw_forward": (C.c_int, [vp, vp, vp, vp, i32, vp]),
+        "shl_mi355x_pwdw_fusable": (C.c_int, [vp, vp, i32]),
+        "shl_mi355x_pwdw_forward": (C.c_int, [vp, vp, vp, vp, i32, vp]),
         "shl_mi355x_relu_i8": (C.c_int, [vp, vp, sz, f32, i32, f32, i32, i32, vp]),
         "shl_mi355x_relu_f16": (C.c_int, [vp, vp, sz, i32, vp]),
         "shl_mi355x_add": (C.c_int, [vp, vp, vp, sz, i32, f32, i32, f32, i32, f32, i32, vp]),

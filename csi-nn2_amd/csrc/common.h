@@ -261,6 +261,9 @@ int launch_dwconv_nchw(const ConvArgs &a, int dtype, hipStream_t s);
 // depthwise 3x3 + pointwise 1x1 in one launch (dwpw_fused.hip)
 bool dwpw_fusable(const ConvArgs &dw, const ConvArgs &pw, int dw_dot4_packed, int pw_is_igemm);
 int launch_dwpw_fused(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);
+// pointwise 1x1 + the depthwise 3x3 that consumes it in one launch (pwdw_fused.hip)
+bool pwdw_fusable(const ConvArgs &pw, const ConvArgs &dw, int pw_is_igemm, int dw_dot4_packed);
+int launch_pwdw_fused(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
 // [N][R][S] -> [N][S][R] for 1- or 2-byte elements (layout.hip)
 int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s);
 

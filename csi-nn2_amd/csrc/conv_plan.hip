@@ -488,4 +488,39 @@ int shl_mi355x_dwpw_forward(const shl_mi355x_conv_plan *dw, const shl_mi355x_con
     return launch_dwpw_fused(a, b, (hipStream_t)stream);
 }
 
+/* pointwise 1x1 + the depthwise 3x3 consuming it, fused into one launch (pwdw_fused.hip) */
+int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch)
+{
+    if (!dw || !pw) return 0;
+    static const char *off = getenv("SHL_MI355X_NO_FUSION");
+    static const char *sel = getenv("SHL_MI355X_PWDW");  // "0": keep pointwise and depthwise launches apart
+    if ((off && off[0] == '1') || (sel && sel[0] == '0')) return 0;
+    if (dw->desc.dtype != SHL_MI355X_I8 || pw->desc.dtype != SHL_MI355X_I8) return 0;
+    if (dw->desc.layout != SHL_MI355X_NHWC || pw->desc.layout != SHL_MI355X_NHWC) return 0;
+    ConvArgs a, b;
+    static char dummy[16];
+    if (fill_args(pw, dummy, dummy, batch, a) != SHL_MI355X_OK || fill_args(dw, dummy, dummy, batch, b) != SHL_MI355X_OK)
+        return 0;
+    return pwdw_fusable(a, b, pw->algo == SHL_MI355X_ALGO_IGEMM, dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12) ? 1 : 0;
+}
+
+int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, const void *input_dev,
+                            void *output_dev, int32_t batch, void *stream)
+{
+    if (!dw || !pw || !input_dev || !output_dev) {
+        set_error("pwdw_forward: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    if (!shl_mi355x_pwdw_fusable(pw, dw, batch)) {
+        set_error("pwdw_forward: the pair does not qualify for the fused kernel");
+        return SHL_MI355X_ENOTSUP;
+    }
+    ConvArgs a, b;
+    int rc = fill_args(pw, input_dev, output_dev, batch, a);
+    if (rc == SHL_MI355X_OK) rc = fill_args(dw, input_dev, output_dev, batch, b);
+    if (rc != SHL_MI355X_OK) return rc;
+    if (b.M == 0) return SHL_MI355X_OK;
+    return launch_pwdw_fused(a, b, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,319 @@
+// pwdw_fused.hip -- pointwise 1x1 convolution + the depthwise 3x3 convolution that consumes it, in
+// ONE launch (int8 NHWC).  MobileNet's body is dw, pw, dw, pw, ...: pairing each pointwise layer with
+// the NEXT depthwise layer halves the number of dependent launches of the chain (a hipGraph kernel
+// node costs 1.6-2.1 us before it does anything, profiles/r01_notes.md) and the pointwise output
+// -- the largest tensors of the network -- never travels to HBM and back.
+//
+// Why this direction and not depthwise -> pointwise (dwpw_fused.hip, opt-in): a depthwise layer is
+// independent per channel, so a workgroup that owns a 32-channel SLICE of the pointwise output can
+// run the depthwise layer on exactly those channels with nothing recomputed except a one-pixel halo;
+// the other order recomputes the whole depthwise tile in every one of the Cout/32 workgroups that
+// share it.
+//
+//   workgroup = (32-channel slice) x (bh x bw rectangle of depthwise OUTPUT pixels), 4 waves
+//   1. pointwise: the rectangle's input patch, ((bh-1) s + 3) x ((bw-1) s + 3) pixels of the
+//      pointwise layer, is cut into 32-pixel MFMA tiles.  A wave owns (tile, K part) pairs: K is
+//      split KS ways (deep K: one memory round trip instead of KS), tiles are dealt to the 4/KS wave
+//      groups.  Every fragment is requested up front -- weights [32 ch][K] rows and pixel rows are
+//      both contiguous 16-byte pieces per lane -- then v_mfma_i32_32x32x32_i8.
+//   2. partial sums meet in LDS; wave w finishes register group w (channels 8w + 4 half .. +3) of
+//      every tile: + acc_init, pointwise requantisation (+ relu), one dword into the LDS patch
+//      [pixel][32 B] (dword index XOR-swizzled with the pixel so stores and loads are conflict-free).
+//   3. depthwise: thread = (output pixel, 4 channels): nine dwords from the LDS patch (the padding
+//      value for taps outside the image), byte transposes + v_dot4_i32_i8 against the depthwise
+//      plan's packed weights, depthwise requantisation (+ relu), one dword to HBM.
+// Bit-identical to the two stand-alone launches: the int8 intermediate is produced by the same
+// requantisation code and consumed by the same integer arithmetic.
+// Restates shl_ref_conv2d_quant followed by shl_ref_depthwise_conv2d_quant
+// (source/reference/convolution.c:370-400, 416-460) incl. the relu variants (convolution_relu.c).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "igemm_common.h"
+
+namespace shl {
+
+struct PwDwArgs {
+    ConvArgs pw;  // in = the pair's input tensor; out unused
+    ConvArgs dw;  // in unused; out = the pair's output tensor
+    int32_t bh, bw;            // depthwise output rectangle of a workgroup
+    int32_t tiles_x, tiles_y;  // rectangles per image
+    int32_t rw;                // patch width  (bw - 1) * sw + 3
+    int32_t npx;               // patch pixels rh * rw
+    int32_t mt;                // 32-pixel MFMA tiles per patch
+    int32_t ks;                // K split: 1, 2 or 4
+    int32_t nsw;               // K sub-steps (32 B) per wave
+    int32_t nsub;              // K sub-steps in all = C / 32
+    uint32_t rw_magic;         // ceil(2^20 / rw): j / rw == (j * rw_magic) >> 20 for j < 4096
+    uint32_t bw_magic;         // same for bw
+};
+
+// wave-uniform choice between the four epilogue code paths (common.h: EPI)
+__device__ __forceinline__ uint32_t requant4_i8_rt(int s0, int s1, int s2, int s3, const float4 &m, const float4 &b,
+                                                   const ConvArgs &a)
+{
+    const bool literal = a.act != SHL_MI355X_ACT_NONE && !a.act_clamp;
+    if (literal)
+        return a.div_exact ? requant4_i8_t<5>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<2>(s0, s1, s2, s3, m, b, a);
+    return a.div_exact ? requant4_i8_t<3>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<0>(s0, s1, s2, s3, m, b, a);
+}
+
+// MTW: MFMA tiles per wave (upper bound), NSW: K sub-steps per wave (upper bound)
+template <int MTW, int NSW>
+__global__ __launch_bounds__(256) void pwdw_fused_kernel(PwDwArgs f)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvArgs &q = f.pw;
+    const ConvArgs &d = f.dw;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar control around MFMA
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int slice = blockIdx.x;
+    const int tx = blockIdx.y;
+    int ty = blockIdx.z, n = 0;
+    if (d.N > 1) {
+        n = ty / f.tiles_y;
+        ty -= n * f.tiles_y;
+    }
+    const int oy0 = ty * f.bh, ox0 = tx * f.bw;
+    const int ry0 = oy0 * d.sh - d.pt, rx0 = ox0 * d.sw - d.pl;  // patch origin in the image (may be -pad)
+
+    // ---- constants of the finishing roles, requested first (they arrive under the K loop)
+    // pointwise: wave w finishes channels 8w + 4 half .. +3 of the slice, for every tile
+    const int pc = slice * 32 + 8 * wave + 4 * fhalf;
+    const int4 p_ai = *reinterpret_cast<const int4 *>(q.acc_init + pc);
+    const float4 p_mu = *reinterpret_cast<const float4 *>(q.mult + pc);
+    const float4 p_bi = *reinterpret_cast<const float4 *>(q.bias + pc);
+    // depthwise: thread handles channel group tid & 7 of the slice for every output it computes
+    const int cg = tid & 7;
+    const int dc = slice * 32 + cg * 4;
+    const uint4 *dwp = reinterpret_cast<const uint4 *>(static_cast<const char *>(d.w) + (int64_t)dc * 12);
+    const uint4 w0 = dwp[0], w1 = dwp[1], w2 = dwp[2];
+    const int4 d_ai = *reinterpret_cast<const int4 *>(d.acc_init + dc);
+    const float4 d_mu = *reinterpret_cast<const float4 *>(d.mult + dc);
+    const float4 d_bi = *reinterpret_cast<const float4 *>(d.bias + dc);
+
+    // ---- pointwise: this wave's (tile, K part) pairs
+    const int ks = f.ks;
+    const int kpart = wave & (ks - 1);
+    const int mw = ks == 4 ? 0 : (ks == 2 ? wave >> 1 : wave);  // wave group over tiles
+    const int mwn = 4 / ks;                                      // number of wave groups
+    const int sub0 = kpart * f.nsw;
+    int nsw = f.nsub - sub0;
+    nsw = nsw < f.nsw ? nsw : f.nsw;  // may be <= 0 for a ragged last part
+
+    const char *img = static_cast<const char *>(q.in) + (int64_t)n * q.H * q.W * q.C;
+    const char *wp = static_cast<const char *>(q.w) + (int64_t)(slice * 32 + frow) * q.kstride + fhalf * 16 + sub0 * 32;
+    v4i fa[NSW];
+#pragma unroll
+    for (int s = 0; s < NSW; ++s)
+        if (s < nsw) fa[s] = *reinterpret_cast<const v4i *>(wp + s * 32);
+    v4i fb[MTW][NSW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int tile = mw + i * mwn;
+        if (tile < f.mt) {
+            int j = tile * 32 + frow;
+            j = j < f.npx ? j : f.npx - 1;
+            const int r = (int)(((uint32_t)j * f.rw_magic) >> 20);
+            const int c = j - r * f.rw;
+            int y = ry0 + r, x = rx0 + c;  // pixels outside the image: any valid address (never used)
+            y = y < 0 ? 0 : (y >= q.H ? q.H - 1 : y);
+            x = x < 0 ? 0 : (x >= q.W ? q.W - 1 : x);
+            const char *px = img + (y * q.W + x) * q.C + fhalf * 16 + sub0 * 32;
+#pragma unroll
+            for (int s = 0; s < NSW; ++s)
+                if (s < nsw) fb[i][s] = *reinterpret_cast<const v4i *>(px + s * 32);
+        }
+    }
+    v16i acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+#pragma unroll
+    for (int s = 0; s < NSW; ++s) {
+        if (s < nsw) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+                if (mw + i * mwn < f.mt) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s], fb[i][s], acc[i], 0, 0, 0);
+        }
+    }
+
+    // ---- partial sums -> LDS: part[((tile * ks + kpart) * 4 + group) * 64 + lane] = 4 channels
+    v4i *part = reinterpret_cast<v4i *>(smem);
+    uint32_t *patch = reinterpret_cast<uint32_t *>(smem + (size_t)f.mt * ks * 4096);  // [pixel][8 dwords]
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int tile = mw + i * mwn;
+        if (tile < f.mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4i v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e];
+                part[((tile * ks + kpart) * 4 + g) * 64 + lane] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- finish the pointwise layer: group `wave` of every tile -> int8 patch in LDS
+    for (int tile = 0; tile < f.mt; ++tile) {
+        v4i v = part[((tile * ks) * 4 + wave) * 64 + lane];
+        for (int k = 1; k < ks; ++k) v += part[((tile * ks + k) * 4 + wave) * 64 + lane];
+        const int j = tile * 32 + frow;
+        const uint32_t packed = requant4_i8_rt(v[0] + p_ai.x, v[1] + p_ai.y, v[2] + p_ai.z, v[3] + p_ai.w, p_mu, p_bi, q);
+        if (j < f.npx) patch[j * 8 + ((2 * wave + fhalf) ^ ((j >> 2) & 7))] = packed;
+    }
+    __syncthreads();
+
+    // ---- depthwise 3x3 on the slice's 32 channels, from the LDS patch
+    const uint32_t zp4 = (uint32_t)(d.in_zp & 0xff) * 0x01010101u;
+    const uint32_t wk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    const int nout = f.bh * f.bw;
+    int8_t *out = static_cast<int8_t *>(d.out);
+    for (int po = tid >> 3; po < nout; po += 32) {
+        const int oyl = (int)(((uint32_t)po * f.bw_magic) >> 20);
+        const int oxl = po - oyl * f.bw;
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
+        if (oy >= d.Ho || ox >= d.Wo) continue;
+        uint32_t iv[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int r = oyl * d.sh + ky, c = oxl * d.sw + kx;
+                const int j = r * f.rw + c;
+                const bool ok = (unsigned)(ry0 + r) < (unsigned)d.H && (unsigned)(rx0 + c) < (unsigned)d.W;
+                const uint32_t v = patch[j * 8 + (cg ^ ((j >> 2) & 7))];
+                iv[ky * 3 + kx] = ok ? v : zp4;
+            }
+        const uint32_t r0[4] = {iv[0], iv[1], iv[2], iv[3]}, r1[4] = {iv[4], iv[5], iv[6], iv[7]};
+        uint32_t t0[4], t1[4];
+        transpose4x4_bytes(r0, t0);
+        transpose4x4_bytes(r1, t1);
+        int a4[4] = {d_ai.x, d_ai.y, d_ai.z, d_ai.w};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const uint32_t t2 = __builtin_amdgcn_ubfe(iv[8], 8 * ch, 8);
+            a4[ch] = __builtin_amdgcn_sdot4((int)t0[ch], (int)wk[3 * ch + 0], a4[ch], false);
+            a4[ch] = __builtin_amdgcn_sdot4((int)t1[ch], (int)wk[3 * ch + 1], a4[ch], false);
+            a4[ch] = __builtin_amdgcn_sdot4((int)t2, (int)wk[3 * ch + 2], a4[ch], false);
+        }
+        const int64_t o = (((int64_t)n * d.Ho + oy) * d.Wo + ox) * d.C + dc;
+        *reinterpret_cast<uint32_t *>(out + o) = requant4_i8_rt(a4[0], a4[1], a4[2], a4[3], d_mu, d_bi, d);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static int ks_for(int nsub) { return nsub >= 8 ? 4 : (nsub >= 4 ? 2 : 1); }
+constexpr int PWDW_MTW = 4;  // tiles per wave the kernels are instantiated for
+
+static bool shapes_pair(const ConvArgs &q, const ConvArgs &d)
+{
+    if (q.Kh != 1 || q.Kw != 1 || q.sh != 1 || q.sw != 1 || q.pt != 0 || q.pl != 0) return false;
+    if (q.H != q.Ho || q.W != q.Wo || (q.C & 31) != 0 || (q.Co & 31) != 0 || q.kstride < q.C) return false;
+    if (d.Kh != 3 || d.Kw != 3 || d.dh != 1 || d.dw != 1 || d.C != d.Co || d.C != q.Co) return false;
+    if (d.H != q.Ho || d.W != q.Wo || d.N != q.N) return false;
+    if (d.sh < 1 || d.sh > 2 || d.sw < 1 || d.sw > 2 || d.pt > 2 || d.pl > 2 || d.pt < 0 || d.pl < 0) return false;
+    if (q.C > 1024) return false;  // 8 sub-steps per wave at most
+    if ((int64_t)q.H * q.W * q.C >= ((int64_t)1 << 31)) return false;  // 32-bit offsets inside an image
+    return true;
+}
+
+// choose the workgroup rectangle; returns false when nothing fits
+static bool choose_rect(const ConvArgs &q, const ConvArgs &d, PwDwArgs &f)
+{
+    const int nsub = q.C >> 5;
+    const int ks = ks_for(nsub);
+    const int mt_max = (4 / ks) * PWDW_MTW;
+    const int nsw = (nsub + ks - 1) / ks;
+    const int64_t slices = q.Co >> 5;
+    int force_h = 0, force_w = 0;
+    const char *env = getenv("SHL_MI355X_PWDW_TILE");  // "<bh>x<bw>": tuning override (tools/pair_bench.py)
+    if (env) sscanf(env, "%dx%d", &force_h, &force_w);
+    double best = 1e30;
+    int best_h = 0, best_w = 0;
+    for (int bh = 1; bh <= d.Ho && bh <= 32; ++bh) {
+        for (int div = 1; div <= 16; ++div) {
+            const int bw = (d.Wo + div - 1) / div;
+            if (div > 1 && bw == (d.Wo + div - 2) / (div - 1)) continue;  // same width as the previous div
+            if (force_h && (bh != force_h || bw != force_w)) continue;
+            const int rh = (bh - 1) * d.sh + 3, rw = (bw - 1) * d.sw + 3;
+            const int npx = rh * rw;
+            const int mt = (npx + 31) / 32;
+            if (mt > mt_max || rw > 256 || bw > 256 || npx >= 4096 || bh * bw >= 4096) continue;
+            const int64_t blocks = slices * ((d.Ho + bh - 1) / bh) * ((d.Wo + bw - 1) / bw) * d.N;
+            // Measured on MobileNetV1 at batch 1 (tools/pair_bench.py --sweep, profiles/r01_notes.md): what
+            // a rectangle costs is the bytes its CU has to pull through its L1 -- (mt pixel tiles + 1
+            // weight tile) x K per workgroup, times the workgroups that land on one CU -- plus a little
+            // per depthwise pass; among equals, more workgroups (up to one per CU) finish sooner.
+            const double rounds = (double)((blocks + 255) / 256);
+            const double score = rounds * ((mt + 1) * nsub + 2.0 * ((bh * bw + 31) / 32) + 4.0) -
+                                 (blocks <= 256 ? blocks / 1024.0 : 0.0);
+            if (score < best) {
+                best = score;
+                best_h = bh;
+                best_w = bw;
+            }
+        }
+    }
+    if (!best_h) return false;
+    f.bh = best_h;
+    f.bw = best_w;
+    f.tiles_y = (d.Ho + f.bh - 1) / f.bh;
+    f.tiles_x = (d.Wo + f.bw - 1) / f.bw;
+    f.rw = (f.bw - 1) * d.sw + 3;
+    f.npx = ((f.bh - 1) * d.sh + 3) * f.rw;
+    f.mt = (f.npx + 31) / 32;
+    f.ks = ks;
+    f.nsw = nsw;
+    f.nsub = nsub;
+    f.rw_magic = ((1u << 20) + f.rw - 1) / f.rw;
+    f.bw_magic = ((1u << 20) + f.bw - 1) / f.bw;
+    return true;
+}
+
+bool pwdw_fusable(const ConvArgs &q, const ConvArgs &d, int pw_is_igemm, int dw_dot4_packed)
+{
+    if (!pw_is_igemm || !dw_dot4_packed || !shapes_pair(q, d)) return false;
+    PwDwArgs f;
+    if (!choose_rect(q, d, f)) return false;
+    if ((int64_t)f.tiles_y * d.N > 65535 || f.tiles_x > 65535) return false;
+    return true;
+}
+
+int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
+{
+    PwDwArgs f;
+    f.pw = q;
+    f.dw = d;
+    if (!shapes_pair(q, d) || !choose_rect(q, d, f)) {
+        set_error("pwdw_fused: the pair does not qualify");
+        return SHL_MI355X_ENOTSUP;
+    }
+    const dim3 grid((unsigned)(q.Co >> 5), (unsigned)f.tiles_x, (unsigned)(f.tiles_y * d.N));
+    const size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
+#define SHL_PWDW(NSWV)                                                                                         \
+    do {                                                                                                       \
+        static bool opted_in = false;                                                                          \
+        if (lds > 64 * 1024 && !opted_in) {                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pwdw_fused_kernel<PWDW_MTW, NSWV>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+            opted_in = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((pwdw_fused_kernel<PWDW_MTW, NSWV>), grid, dim3(256), lds, s, f);                   \
+    } while (0)
+    if (f.nsw <= 2)
+        SHL_PWDW(2);
+    else if (f.nsw <= 4)
+        SHL_PWDW(4);
+    else
+        SHL_PWDW(8);
+#undef SHL_PWDW
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}
+
+}  // namespace shl

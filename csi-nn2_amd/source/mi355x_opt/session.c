@@ -147,15 +147,18 @@ static int is_conv_op(int type)
     return type == CSINN_OP_CONV2D || type == CSINN_OP_CONV2D_RELU || type == CSINN_OP_CONV2D_RELU6;
 }
 
-/* Graph-level fusion: a depthwise convolution whose ONLY consumer is the next layer, a 1x1
- * convolution, runs with it as one launch (csrc/dwpw_fused.hip) when the pair of device plans
- * qualifies; the intermediate tensor then never exists in HBM. */
+/* Graph-level fusion of a layer with its ONLY consumer when the pair of device plans qualifies; the
+ * intermediate tensor then never exists in HBM:
+ *   1x1 convolution -> depthwise 3x3   one launch of csrc/pwdw_fused.hip   (fused[i] = 2)
+ *   depthwise 3x3 -> 1x1 convolution   one launch of csrc/dwpw_fused.hip   (fused[i] = 1, opt-in) */
 static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
 {
     ds->fused = calloc((size_t)g->layer_index + 1, 1);
     for (int i = 0; i + 1 < g->layer_index; i++) {
         struct shl_node *a = g->layer[i], *b = g->layer[i + 1];
-        if (!is_dw_op(a->type) || !is_conv_op(b->type) || b->in[0] != a->out[0]) continue;
+        if (b->in[0] != a->out[0]) continue;
+        const int pw_dw = is_conv_op(a->type) && is_dw_op(b->type);
+        if (!pw_dw && !(is_dw_op(a->type) && is_conv_op(b->type))) continue;
         int consumers = 0;
         for (int k = 0; k < g->layer_index; k++)
             for (int j = 0; j < g->layer[k]->in_num; j++)
@@ -165,7 +168,11 @@ static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
         if (consumers != 1) continue;
         shl_mi355x_conv_plan *pa = shl_mi355x_registry_get(a->data), *pb = shl_mi355x_registry_get(b->data);
         struct csinn_tensor *in = a->in[0]->data;
-        if (pa && pb && shl_mi355x_dwpw_fusable(pa, pb, in->dim[0])) {
+        if (pa && pb && pw_dw && shl_mi355x_pwdw_fusable(pa, pb, in->dim[0])) {
+            ds->fused[i] = 2;
+            ds->nfused++;
+            i++; /* the depthwise layer is taken */
+        } else if (pa && pb && !pw_dw && shl_mi355x_dwpw_fusable(pa, pb, in->dim[0])) {
             ds->fused[i] = 1;
             ds->nfused++;
             i++; /* the pointwise layer is taken */
@@ -186,8 +193,10 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
         if (ds->fused && ds->fused[i]) {
             struct shl_node *nx = g->layer[i + 1];
             struct dev_tensor *out2 = lookup(ds, nx->out[0]);
-            int st = shl_mi355x_dwpw_forward(shl_mi355x_registry_get(n->data), shl_mi355x_registry_get(nx->data),
-                                             in->dev, out2->dev, in->shadow.dim[0], shl_mi355x_get_stream());
+            int (*fwd)(const shl_mi355x_conv_plan *, const shl_mi355x_conv_plan *, const void *, void *, int32_t,
+                       void *) = ds->fused[i] == 2 ? shl_mi355x_pwdw_forward : shl_mi355x_dwpw_forward;
+            int st = fwd(shl_mi355x_registry_get(n->data), shl_mi355x_registry_get(nx->data), in->dev, out2->dev,
+                         in->shadow.dim[0], shl_mi355x_get_stream());
             rc = st == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
             i++;
         } else if (op_arity(n->type) == 1) {

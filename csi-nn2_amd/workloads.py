@@ -101,7 +101,10 @@ class LayerChain:
     """
 
     def __init__(self, fe, hip, opt, layers, batch, alloc, upload, dtype="int8", layout="NHWC", seed=1234,
-                 chained=True):
+                 chained=True, fuse=False):
+        """fuse=True applies the session-level rewrite of source/mi355x_opt/session.c (plan_fusion) to the
+        chain: a pointwise layer whose output feeds the next depthwise layer runs with it as ONE launch
+        (shl_mi355x_pwdw_forward on the two layers' own plans); `units` lists the resulting launches."""
         self.fe, self.hip, self.opt = fe, hip, opt
         self.layers, self.batch, self.dtype, self.layout = layers, batch, dtype, layout
         self.keep = Keep()
@@ -162,6 +165,22 @@ class LayerChain:
             prev_out = (d_out, ops["out_scale"], ops["out_zp"])
             prev_desc = out_dims
         self.graph = None
+        self.units = []  # launches of one pass: [layer index] or [pointwise index, depthwise index]
+        opt.shl_mi355x_registry_get.restype = C.c_void_p
+        opt.shl_mi355x_registry_get.argtypes = [C.c_void_p]
+        i = 0
+        while i < len(self.entries):
+            a = self.entries[i]
+            b = self.entries[i + 1] if i + 1 < len(self.entries) else None
+            if (fuse and b is not None and not a["layer"]["depthwise"] and b["layer"]["depthwise"]
+                    and b["d_in"] == a["d_out"]
+                    and hip.shl_mi355x_pwdw_fusable(opt.shl_mi355x_registry_get(a["params"]),
+                                                    opt.shl_mi355x_registry_get(b["params"]), batch) == 1):
+                self.units.append([i, i + 1])
+                i += 2
+            else:
+                self.units.append([i])
+                i += 1
 
     # ---- execution ----------------------------------------------------------------------------
     def run_layer(self, i):
@@ -170,9 +189,37 @@ class LayerChain:
         if rc != CSINN_TRUE:
             raise MI355XError("layer %d returned %d" % (i, rc))
 
+    def run_unit(self, u, stream=None):
+        idx = self.units[u]
+        if len(idx) == 1:
+            return self.run_layer(idx[0])
+        a, b = self.entries[idx[0]], self.entries[idx[1]]
+        get = self.opt.shl_mi355x_registry_get
+        check(self.hip.shl_mi355x_pwdw_forward(get(a["params"]), get(b["params"]), a["d_in"], b["d_out"], self.batch,
+                                               self.opt.shl_mi355x_get_stream()), self.hip, "pwdw_forward")
+
+    def unit_kernel_name(self, u):
+        idx = self.units[u]
+        return self.entries[idx[0]]["kernel_name"] if len(idx) == 1 else "pwdw_fused_i8"
+
+    def unit_name(self, u):
+        return " + ".join(layer_name(self.entries[i]["layer"]) for i in self.units[u])
+
+    def unit_ops(self, u):
+        return sum(layer_ops(self.entries[i]["layer"], self.batch) for i in self.units[u])
+
+    def unit_bytes(self, u):
+        """algorithmic HBM bytes of the launch: a fused pair neither writes nor re-reads the
+        intermediate tensor"""
+        idx = self.units[u]
+        total = sum(layer_bytes(self.entries[i]["layer"], self.batch, self.esize) for i in idx)
+        if len(idx) == 2:
+            total -= 2 * int(np.prod(self.entries[idx[0]]["out_dims"])) * self.esize
+        return total
+
     def run_eager(self):
-        for i in range(len(self.entries)):
-            self.run_layer(i)
+        for u in range(len(self.units)):
+            self.run_unit(u)
 
     def capture(self, stream):
         """Record one pass of the chain on `stream` into a hipGraph (C-ABI graph entry points)."""
@@ -195,7 +242,7 @@ class LayerChain:
         return sum(layer_ops(e["layer"], self.batch) for e in self.entries)
 
     def total_bytes(self):
-        return sum(layer_bytes(e["layer"], self.batch, self.esize) for e in self.entries)
+        return sum(self.unit_bytes(u) for u in range(len(self.units)))
 
     def const_blocks(self):
         """[(device pointer, bytes)] of every layer's packed weights + tables (RCCL broadcast)."""

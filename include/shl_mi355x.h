@@ -195,6 +195,17 @@ int shl_mi355x_dwpw_fusable(const shl_mi355x_conv_plan *dw, const shl_mi355x_con
 int shl_mi355x_dwpw_forward(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw,
                             const void *input_dev, void *output_dev, int32_t batch, void *stream);
 
+/*
+ * Pointwise 1x1 + the depthwise 3x3 that consumes its output, as ONE launch (int8 NHWC): a workgroup
+ * owns a 32-channel slice of shl_ref_conv2d_quant's output over a small pixel patch, keeps the int8
+ * result in LDS and runs shl_ref_depthwise_conv2d_quant on those channels from there -- same bits as
+ * the two plans back to back; the pointwise output (the largest tensors of a MobileNet) is never
+ * written.  `input_dev` is the pointwise layer's input, `output_dev` the depthwise layer's output.
+ */
+int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch);
+int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw,
+                            const void *input_dev, void *output_dev, int32_t batch, void *stream);
+
 /* ---- elementwise neighbours of the path ---------------------------------- */
 /* relu / relu6 on a quantised int8 tensor: shl_ref_relu_quant / shl_ref_relu6_quant
  * (source/reference/relu.c:21-43, relu6.c:21-43) */

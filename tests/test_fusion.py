@@ -1,6 +1,7 @@
-"""Depthwise + pointwise fusion (csrc/dwpw_fused.hip): the fused launch must produce exactly the
-bytes of the two stand-alone kernels (and of the oracle chain), for every K split, stride, ragged
-tile and activation combination; sessions must pick it up as a graph-level rewrite."""
+"""Graph-level fusion of separable blocks -- pointwise + the depthwise layer consuming it
+(csrc/pwdw_fused.hip, default) and depthwise + pointwise (csrc/dwpw_fused.hip, opt-in): a fused launch
+must produce exactly the bytes of the two stand-alone kernels (and of the oracle chain), for every K
+split, stride, ragged tile and activation combination; sessions must pick it up as a graph rewrite."""
 import ctypes as C
 import os
 import subprocess
@@ -85,6 +86,83 @@ def test_fused_pair_equals_the_two_kernels_and_the_oracle(gpu, i):
         opt.shl_mi355x_release_params(p)
 
 
+# pointwise -> depthwise pairs: (pointwise Cin -> Cout @hw) then depthwise 3x3 on Cout channels
+PWDW_PAIRS = [
+    dict(c=32, co=64, hw=16, stride=2),                    # one K sub-step, 4 wave groups over tiles
+    dict(c=64, co=128, hw=12),                             # two sub-steps, no K split
+    dict(c=128, co=128, hw=9, stride=2, relu=(0, 1)),      # 2-way K split, odd size (ragged rectangles)
+    dict(c=256, co=64, hw=7, relu=(1, 0)),                 # 4-way K split
+    dict(c=512, co=512, hw=14),                            # MobileNetV1's 14x14 body
+    dict(c=512, co=96, hw=14, stride=2, n=2),              # stride 2, batch 2
+    dict(c=1024, co=32, hw=7),                             # 8 sub-steps per wave
+    dict(c=96, co=32, hw=8),                               # 3 sub-steps (ragged K parts)
+    dict(c=160, co=64, hw=10, exact=False),                # 5 sub-steps, general scales
+    dict(c=64, co=64, hw=8, pad=(0, 0, 1, 1), stride=2),   # TF-style "same" padding for stride 2
+    dict(c=32, co=32, hw=33, n=3),                         # wide image: several rectangles per row
+    dict(c=64, co=32, hw=5, pad=(2, 2, 2, 2)),             # padding 2: outputs whose window is mostly padding
+]
+
+
+def make_pwdw(i, c, co, hw, stride=1, relu=(1, 1), n=1, exact=True, pad=(1, 1, 1, 1)):
+    pw = cases.make_case(700 + i, n=n, h=hw, w=hw, c=c, co=co, k=(1, 1), pad=(0, 0, 0, 0), act=relu[0], exact=exact)
+    dw = cases.make_case(750 + i, n=n, h=hw, w=hw, c=co, depthwise=True, stride=(stride, stride), act=relu[1],
+                         exact=exact, pad=pad)
+    dw["in_scale"], dw["in_zp"] = pw["out_scale"], pw["out_zp"]
+    dw["b_scale"] = (np.float32(dw["in_scale"]) * dw["k_scale"]).astype(np.float32)
+    return pw, dw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(PWDW_PAIRS)),
+                         ids=["c%d_co%d_hw%d" % (p["c"], p["co"], p["hw"]) for p in PWDW_PAIRS])
+def test_pointwise_depthwise_pair_equals_the_two_kernels_and_the_oracle(gpu, i):
+    fe, hip, opt = gpu
+    pw, dw = make_pwdw(i, **PWDW_PAIRS[i])
+    dev = cases.HipDevice(hip)
+    keep = []
+    mid = cases.csinn_run(fe, pkg.API_MI355X, pw, device=dev, keep_params=keep)      # stand-alone pointwise
+    dw["input"] = mid
+    want = cases.csinn_run(fe, pkg.API_MI355X, dw, device=dev, keep_params=keep)     # stand-alone depthwise
+    o_mid = cases.oracle_run(pw, "exact")
+    n, worst = cases.mismatch_report(mid, o_mid)
+    assert n == 0, "pointwise vs oracle: %d mismatches (max %d)" % (n, worst)
+    o_dw = dict(dw)
+    o_dw["input"] = o_mid
+    n, worst = cases.mismatch_report(want, cases.oracle_run(o_dw, "exact"))
+    assert n == 0, "depthwise vs oracle: %d mismatches (max %d)" % (n, worst)
+    plan_pw, plan_dw = (opt.shl_mi355x_registry_get(p) for p, _ in keep)
+    assert hip.shl_mi355x_pwdw_fusable(plan_pw, plan_dw, pw["n"]) == 1
+    d_in = dev.alloc(pw["input"].nbytes)
+    dev.upload(d_in, pw["input"])
+    d_out = dev.alloc(want.nbytes)
+    hip.shl_mi355x_memset(d_out, 0x55, want.nbytes, None)
+    pkg.check(hip.shl_mi355x_pwdw_forward(plan_pw, plan_dw, d_in, d_out, pw["n"], None), hip, "pwdw_forward")
+    got = dev.download(d_out, want.shape, np.int8)
+    n, worst = cases.mismatch_report(got, want)
+    assert n == 0, "fused vs stand-alone: %d mismatches (max |d| %d)" % (n, worst)
+    dev.free(d_in)
+    dev.free(d_out)
+    for p, _ in keep:
+        opt.shl_mi355x_release_params(p)
+
+
+@pytest.mark.gpu
+def test_pointwise_depthwise_pairs_that_do_not_qualify_are_refused(gpu):
+    fe, hip, opt = gpu
+    dev = cases.HipDevice(hip)
+    keep = []
+    pw = cases.make_case(3, h=8, w=8, c=32, co=48, k=(1, 1), pad=(0, 0, 0, 0))    # Cout not a multiple of 32
+    dw = cases.make_case(4, h=8, w=8, c=48, depthwise=True)
+    cases.csinn_run(fe, pkg.API_MI355X, pw, device=dev, keep_params=keep)
+    cases.csinn_run(fe, pkg.API_MI355X, dw, device=dev, keep_params=keep)
+    a, b = (opt.shl_mi355x_registry_get(p) for p, _ in keep)
+    assert hip.shl_mi355x_pwdw_fusable(a, b, 1) == 0
+    assert hip.shl_mi355x_pwdw_fusable(b, a, 1) == 0                              # wrong order
+    assert hip.shl_mi355x_pwdw_forward(a, b, 16, 16, 1, None) == -3               # ENOTSUP, nothing launched
+    for p, _ in keep:
+        opt.shl_mi355x_release_params(p)
+
+
 @pytest.mark.gpu
 def test_pairs_that_do_not_qualify_are_refused(gpu):
     fe, hip, opt = gpu
@@ -135,12 +213,16 @@ print("OUT", out.astype(np.int32).tolist())
 def test_whole_mobilenet_is_identical_with_and_without_fusion(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for env in ("0", "1"):
-        e = dict(os.environ, SHL_MI355X_NO_FUSION=env, SHL_MI355X_FUSE_ALL="1")
+    variants = {"none": dict(SHL_MI355X_NO_FUSION="1"),                 # every layer its own launch
+                "dwpw": dict(SHL_MI355X_FUSE_ALL="1"),                  # depthwise -> pointwise pairs (opt-in)
+                "pwdw": dict()}                                         # default: pointwise -> depthwise pairs
+    for name, extra in variants.items():
+        e = {k: v for k, v in os.environ.items() if k not in ("SHL_MI355X_NO_FUSION", "SHL_MI355X_FUSE_ALL")}
+        e.update(extra)
         res = subprocess.run([sys.executable, "-c", WHOLE % dict(root=root)], capture_output=True, text=True,
                              timeout=600, env=e)
         assert "OUT" in res.stdout, res.stdout + res.stderr
         lines = dict(l.split(" ", 1) for l in res.stdout.strip().splitlines() if " " in l)
-        outs[env] = (int(lines["PAIRS"]), lines["OUT"])
-    assert outs["0"][0] == 13 and outs["1"][0] == 0
-    assert outs["0"][1] == outs["1"][1]
+        outs[name] = (int(lines["PAIRS"]), lines["OUT"])
+    assert outs["none"][0] == 0 and outs["dwpw"][0] == 13 and outs["pwdw"][0] == 12
+    assert outs["none"][1] == outs["dwpw"][1] == outs["pwdw"][1]
