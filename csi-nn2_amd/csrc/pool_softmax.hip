@@ -54,6 +54,40 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const void *in, voi
     store_requant(out, i, avg, dtype, so, zo);  // output is [N, 1, 1, C] / [N, C, 1, 1]: index n*C + c
 }
 
+// int8 NHWC with at most 64 pixels (every MobileNet / ResNet tail): a thread owns 4 consecutive
+// channels, requests ALL its H*W dwords up front (one memory round trip instead of H*W dependent
+// ones) and then adds them in the reference's (y, x) order.
+__global__ __launch_bounds__(256) void global_avgpool_nhwc_i8_kernel(const void *in, void *out, int64_t ngroups,
+                                                                     int cgroups, int HW, float si, float zi,
+                                                                     float so, float zo)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, channel group)
+    if (i >= ngroups) return;
+    const int64_t n = i / cgroups;
+    const int g = (int)(i - n * cgroups);
+    const uint32_t *src = static_cast<const uint32_t *>(in) + n * HW * cgroups + g;
+    uint32_t v[64];
+#pragma unroll
+    for (int p = 0; p < 64; ++p)
+        if (p < HW) v[p] = src[(int64_t)p * cgroups];
+    float total[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 64; ++p) {
+        if (p < HW) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = __fmul_rn(__fsub_rn((float)(int8_t)(v[p] >> (8 * e)), zi), si);
+                total[e] = __fadd_rn(total[e], x);
+            }
+        }
+    }
+    int q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        q[e] = sat8_from_float(__fadd_rn(rintf(__fdiv_rn(__fdiv_rn(total[e], (float)HW), so)), zo));
+    static_cast<uint32_t *>(out)[i] = pack4_i8(q[0], q[1], q[2], q[3]);
+}
+
 constexpr int SOFTMAX_MAX_CNT = 8192;  // doubles parked in LDS: 64 KiB
 
 __global__ __launch_bounds__(256) void softmax_kernel(const void *in, void *out, int dtype, int cnt,
@@ -82,7 +116,15 @@ __global__ __launch_bounds__(256) void softmax_kernel(const void *in, void *out,
     __syncthreads();
     if (tid == 0) {
         float acc = 0.f;  // `acc_exp += exp(...)`: double add, rounded to float every step
-        for (int j = 0; j < cnt; ++j) acc = (float)((double)acc + e[j]);
+        int j = 0;
+        for (; j + 8 <= cnt; j += 8) {  // eight LDS reads in flight, then the dependent chain
+            double b[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[k] = e[j + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc = (float)((double)acc + b[k]);
+        }
+        for (; j < cnt; ++j) acc = (float)((double)acc + e[j]);
         red[0] = acc;
     }
     __syncthreads();
@@ -103,6 +145,15 @@ extern "C" int shl_mi355x_global_avgpool2d(const void *input_dev, void *output_d
     }
     const int64_t nc = (int64_t)batch * channels;
     if (nc == 0) return SHL_MI355X_OK;
+    if (dtype == SHL_MI355X_I8 && layout == SHL_MI355X_NHWC && channels % 4 == 0 && pixels <= 64) {
+        const int64_t ngroups = nc / 4;
+        // 64 threads per workgroup: MobileNetV1's 1024 channels spread over 4 CUs
+        hipLaunchKernelGGL(shl::global_avgpool_nhwc_i8_kernel, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0,
+                           (hipStream_t)stream, input_dev, output_dev, ngroups, (int)(channels / 4), (int)pixels,
+                           in_scale, (float)in_zp, out_scale, (float)out_zp);
+        SHL_HIP(hipGetLastError());
+        return SHL_MI355X_OK;
+    }
     hipLaunchKernelGGL(shl::global_avgpool_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        input_dev, output_dev, (int)dtype, layout == SHL_MI355X_NHWC ? 1 : 0, nc, (int)channels,
                        (int)pixels, in_scale, (float)in_zp, out_scale, (float)out_zp);

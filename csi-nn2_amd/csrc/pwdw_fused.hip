@@ -281,6 +281,15 @@ bool pwdw_fusable(const ConvArgs &q, const ConvArgs &d, int pw_is_igemm, int dw_
     PwDwArgs f;
     if (!choose_rect(q, d, f)) return false;
     if ((int64_t)f.tiles_y * d.N > 65535 || f.tiles_x > 65535) return false;
+    // Latency regime only.  The fused kernel trades a launch and an HBM round trip for halo
+    // recomputation and a serial pointwise -> depthwise chain inside the workgroup: at batch 1 a
+    // MobileNetV1 pair drops from 6.7-7.9 us to 4.2-5.3 us, at batch 128 the stand-alone kernels
+    // (bandwidth-tuned, 1.3-3.4 TB/s) are 1.5-2x faster; the whole chain breaks even at batch 16
+    // (profiles/r01_notes.md).  Fuse while the workgroups fit a few rounds on the 256 CUs (MobileNetV1
+    // up to batch 8); SHL_MI355X_PWDW=2 lifts the limit (measurements).
+    static const char *sel = getenv("SHL_MI355X_PWDW");
+    const int64_t blocks = (int64_t)(q.Co >> 5) * f.tiles_x * f.tiles_y * d.N;
+    if (blocks > 2048 && !(sel && sel[0] == '2')) return false;
     return true;
 }
 
