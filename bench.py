@@ -296,7 +296,7 @@ def main():
         "images_per_sec": images / elapsed,
         "config": {"workload": "%s %s %s, %d conv layers in %d launches%s, batch %d per GPU, hipGraph replay via csinn_* C API"
                                % (args.workload, args.dtype, layout, len(layers), len(chain.units),
-                                  " (pointwise+depthwise pairs fused as csinn_session_setup does)" if fuse else "", batch),
+                                  " (pointwise+depthwise pairs fused as csinn_session_setup does)" if len(chain.units) < len(layers) else "", batch),
                    "per_gpu_batch": batch, "parallelism": "replicas x%d (batch shard, RCCL weight bcast)" % world,
                    "ops_per_image": chain.total_ops() // batch, "algorithmic_bytes_per_image": chain.total_bytes() // batch,
                    "device": arch.value.decode(), "compute_units": cus.value},
@@ -334,6 +334,7 @@ def main():
                 ("resnet50 3x3 set int8 NHWC batch 128 (BASELINE configs[2] shapes, NHWC)", wl.RESNET50_3X3, 128, "int8", "NHWC", "mfma", 3),
                 ("resnet50 3x3 set int8 NCHW batch 128 (BASELINE configs[2])", wl.RESNET50_3X3, 128, "int8", "NCHW", "mfma", 3),
                 ("mobilenetv1 fp16 NCHW batch 1 (BASELINE configs[3], c906_mobilenetv1_f16 shapes)", wl.MOBILENETV1, 1, "f16", "NCHW", "hbm", 20),
+                ("mobilenetv1 int8 NHWC batch 128 (throughput view of configs[1]; every layer its own launch)", wl.MOBILENETV1, 128, "int8", "NHWC", "hbm", 3),
             ]
             result["extra"] = []
             for name, layers_x, batch_x, dtype_x, layout_x, bound_x, reps_x in extras:

@@ -249,6 +249,9 @@ bool igemm_fuses_nchw_out(int64_t M, int64_t Co);   // the tile kernel stores NC
 bool dwconv_supports(const shl_mi355x_conv_desc &d);
 bool dwconv_dot4_supports(const shl_mi355x_conv_desc &d);  // int8 3x3: weights packed [C][3 dwords]
 void dwconv_dot4_pack(const shl_mi355x_conv_desc &d, const int8_t *hwo, uint32_t *dst);
+// depthwise 3x3 int8 NHWC on the matrix cores for bandwidth-bound sizes (dwconv_mfma.hip)
+bool dwconv_mfma_pick(int64_t M, int C, int H, int W, int Ho, int Wo, int sh, int sw);
+int launch_dwconv_mfma(const ConvArgs &a, hipStream_t s);
 bool stem_supports(const shl_mi355x_conv_desc &d);
 void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
 size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);

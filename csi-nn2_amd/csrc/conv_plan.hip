@@ -207,6 +207,10 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         if (dwconv_dot4_supports(d)) {
             p->kstride = 12;  // marks the [C][3 dwords] packing for launch_dwconv
             w_bytes = (size_t)d.in_c * 12;
+            if (d.dilation_h == 1 && d.dilation_w == 1 &&
+                dwconv_mfma_pick((int64_t)d.batch * d.out_h * d.out_w, d.in_c, d.in_h, d.in_w, d.out_h, d.out_w,
+                                 d.stride_h, d.stride_w))
+                p->kernel_name = "dwconv_mfma_i8";
         }
     } else {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_direct_i8" : "conv_direct_f16";

@@ -213,6 +213,9 @@ int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     }
     const int64_t total = (int64_t)a.M * (a.C / 4);
     if (total == 0) return SHL_MI355X_OK;
+    if (dtype == SHL_MI355X_I8 && a.kstride == 12 && a.dh == 1 && a.dw == 1 && a.C == a.Co &&
+        dwconv_mfma_pick(a.M, a.C, a.H, a.W, a.Ho, a.Wo, a.sh, a.sw))
+        return launch_dwconv_mfma(a, s);
     if (dtype == SHL_MI355X_I8 && a.kstride == 12) {  // plan packed the weights for the dot4 kernel
         const int64_t rows = (int64_t)a.N * a.Ho;
         const int64_t per_row = ((int64_t)a.Wo * (a.C / 4) + 255) / 256;
