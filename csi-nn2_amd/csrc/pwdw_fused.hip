@@ -41,26 +41,18 @@ struct PwDwArgs {
     int32_t rw;                // patch width  (bw - 1) * sw + 3
     int32_t npx;               // patch pixels rh * rw
     int32_t mt;                // 32-pixel MFMA tiles per patch
-    int32_t ks;                // K split: 1, 2 or 4
+    int32_t nwaves;            // waves per workgroup: 4 or 8
+    int32_t ks;                // K split: 1, 2, 4 or 8
     int32_t nsw;               // K sub-steps (32 B) per wave
     int32_t nsub;              // K sub-steps in all = C / 32
     uint32_t rw_magic;         // ceil(2^20 / rw): j / rw == (j * rw_magic) >> 20 for j < 4096
     uint32_t bw_magic;         // same for bw
 };
 
-// wave-uniform choice between the four epilogue code paths (common.h: EPI)
-__device__ __forceinline__ uint32_t requant4_i8_rt(int s0, int s1, int s2, int s3, const float4 &m, const float4 &b,
-                                                   const ConvArgs &a)
-{
-    const bool literal = a.act != SHL_MI355X_ACT_NONE && !a.act_clamp;
-    if (literal)
-        return a.div_exact ? requant4_i8_t<5>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<2>(s0, s1, s2, s3, m, b, a);
-    return a.div_exact ? requant4_i8_t<3>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<0>(s0, s1, s2, s3, m, b, a);
-}
-
-// MTW: MFMA tiles per wave (upper bound), NSW: K sub-steps per wave (upper bound)
-template <int MTW, int NSW>
-__global__ __launch_bounds__(256) void pwdw_fused_kernel(PwDwArgs f)
+// MTW: MFMA tiles per wave (upper bound), NSW: K sub-steps per wave (upper bound), MAXT: threads (the
+// 8-sub-step form needs more than the 256 registers a lane gets with two waves per SIMD)
+template <int MTW, int NSW, int MAXT>
+__global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvArgs &q = f.pw;
@@ -80,8 +72,11 @@ __global__ __launch_bounds__(256) void pwdw_fused_kernel(PwDwArgs f)
     const int ry0 = oy0 * d.sh - d.pt, rx0 = ox0 * d.sw - d.pl;  // patch origin in the image (may be -pad)
 
     // ---- constants of the finishing roles, requested first (they arrive under the K loop)
-    // pointwise: wave w finishes channels 8w + 4 half .. +3 of the slice, for every tile
-    const int pc = slice * 32 + 8 * wave + 4 * fhalf;
+    // pointwise: wave w finishes channels 8 (w & 3) + 4 half .. +3 of the slice, for every tile (with 8
+    // waves: waves 0-3 the even tiles, waves 4-7 the odd ones)
+    const int nwaves = f.nwaves;  // 4 or 8
+    const int fgrp = wave & 3;
+    const int pc = slice * 32 + 8 * fgrp + 4 * fhalf;
     const int4 p_ai = *reinterpret_cast<const int4 *>(q.acc_init + pc);
     const float4 p_mu = *reinterpret_cast<const float4 *>(q.mult + pc);
     const float4 p_bi = *reinterpret_cast<const float4 *>(q.bias + pc);
@@ -97,8 +92,8 @@ __global__ __launch_bounds__(256) void pwdw_fused_kernel(PwDwArgs f)
     // ---- pointwise: this wave's (tile, K part) pairs
     const int ks = f.ks;
     const int kpart = wave & (ks - 1);
-    const int mw = ks == 4 ? 0 : (ks == 2 ? wave >> 1 : wave);  // wave group over tiles
-    const int mwn = 4 / ks;                                      // number of wave groups
+    const int mw = ks == 8 ? 0 : (ks == 4 ? wave >> 2 : (ks == 2 ? wave >> 1 : wave));  // wave group over tiles
+    const int mwn = nwaves / ks;                                                        // number of wave groups
     const int sub0 = kpart * f.nsw;
     int nsw = f.nsub - sub0;
     nsw = nsw < f.nsw ? nsw : f.nsw;  // may be <= 0 for a ragged last part
@@ -159,12 +154,12 @@ __global__ __launch_bounds__(256) void pwdw_fused_kernel(PwDwArgs f)
     }
     __syncthreads();
     // ---- finish the pointwise layer: group `wave` of every tile -> int8 patch in LDS
-    for (int tile = 0; tile < f.mt; ++tile) {
-        v4i v = part[((tile * ks) * 4 + wave) * 64 + lane];
-        for (int k = 1; k < ks; ++k) v += part[((tile * ks + k) * 4 + wave) * 64 + lane];
+    for (int tile = wave >> 2; tile < f.mt; tile += nwaves >> 2) {
+        v4i v = part[((tile * ks) * 4 + fgrp) * 64 + lane];
+        for (int k = 1; k < ks; ++k) v += part[((tile * ks + k) * 4 + fgrp) * 64 + lane];
         const int j = tile * 32 + frow;
         const uint32_t packed = requant4_i8_rt(v[0] + p_ai.x, v[1] + p_ai.y, v[2] + p_ai.z, v[3] + p_ai.w, p_mu, p_bi, q);
-        if (j < f.npx) patch[j * 8 + ((2 * wave + fhalf) ^ ((j >> 2) & 7))] = packed;
+        if (j < f.npx) patch[j * 8 + ((2 * fgrp + fhalf) ^ ((j >> 2) & 7))] = packed;
     }
     __syncthreads();
 
@@ -173,7 +168,7 @@ __global__ __launch_bounds__(256) void pwdw_fused_kernel(PwDwArgs f)
     const uint32_t wk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
     const int nout = f.bh * f.bw;
     int8_t *out = static_cast<int8_t *>(d.out);
-    for (int po = tid >> 3; po < nout; po += 32) {
+    for (int po = tid >> 3; po < nout; po += nwaves * 8) {
         const int oyl = (int)(((uint32_t)po * f.bw_magic) >> 20);
         const int oxl = po - oyl * f.bw;
         const int oy = oy0 + oyl, ox = ox0 + oxl;
@@ -207,7 +202,16 @@ __global__ __launch_bounds__(256) void pwdw_fused_kernel(PwDwArgs f)
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int ks_for(int nsub) { return nsub >= 8 ? 4 : (nsub >= 4 ? 2 : 1); }
+static int waves_per_group()
+{
+    static const char *env = getenv("SHL_MI355X_PWDW_WAVES");  // 4 | 8 (A/B)
+    return env && env[0] == '8' ? 8 : 4;  // 8 waves measured slower on 11 of the 12 MobileNetV1 pairs
+}
+static int ks_for(int nsub, int nwaves)
+{
+    const int ks = nsub >= 8 ? 4 : (nsub >= 4 ? 2 : 1);
+    return nwaves == 8 && nsub >= 16 ? 8 : ks;
+}
 constexpr int PWDW_MTW = 4;  // tiles per wave the kernels are instantiated for
 
 static bool shapes_pair(const ConvArgs &q, const ConvArgs &d)
@@ -226,9 +230,11 @@ static bool shapes_pair(const ConvArgs &q, const ConvArgs &d)
 static bool choose_rect(const ConvArgs &q, const ConvArgs &d, PwDwArgs &f)
 {
     const int nsub = q.C >> 5;
-    const int ks = ks_for(nsub);
-    const int mt_max = (4 / ks) * PWDW_MTW;
+    const int nwaves = waves_per_group();
+    const int ks = ks_for(nsub, nwaves);
+    const int mt_max = (nwaves / ks) * PWDW_MTW;
     const int nsw = (nsub + ks - 1) / ks;
+    if (nwaves == 8 && nsw > 4) return false;  // the 8-sub-step kernel is built for 4 waves
     const int64_t slices = q.Co >> 5;
     int force_h = 0, force_w = 0;
     const char *env = getenv("SHL_MI355X_PWDW_TILE");  // "<bh>x<bw>": tuning override (tools/pair_bench.py)
@@ -244,6 +250,7 @@ static bool choose_rect(const ConvArgs &q, const ConvArgs &d, PwDwArgs &f)
             const int npx = rh * rw;
             const int mt = (npx + 31) / 32;
             if (mt > mt_max || rw > 256 || bw > 256 || npx >= 4096 || bh * bw >= 4096) continue;
+            if ((size_t)mt * ks * 4096 + (size_t)mt * 1024 > 96 * 1024) continue;  // partial sums + patch in LDS
             const int64_t blocks = slices * ((d.Ho + bh - 1) / bh) * ((d.Wo + bw - 1) / bw) * d.N;
             // Measured on MobileNetV1 at batch 1 (tools/pair_bench.py --sweep, profiles/r01_notes.md): what
             // a rectangle costs is the bytes its CU has to pull through its L1 -- (mt pixel tiles + 1
@@ -267,6 +274,7 @@ static bool choose_rect(const ConvArgs &q, const ConvArgs &d, PwDwArgs &f)
     f.rw = (f.bw - 1) * d.sw + 3;
     f.npx = ((f.bh - 1) * d.sh + 3) * f.rw;
     f.mt = (f.npx + 31) / 32;
+    f.nwaves = nwaves;
     f.ks = ks;
     f.nsw = nsw;
     f.nsub = nsub;
@@ -304,22 +312,22 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
     }
     const dim3 grid((unsigned)(q.Co >> 5), (unsigned)f.tiles_x, (unsigned)(f.tiles_y * d.N));
     const size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
-#define SHL_PWDW(NSWV)                                                                                         \
+#define SHL_PWDW(NSWV, MAXT)                                                                                         \
     do {                                                                                                       \
         static bool opted_in = false;                                                                          \
         if (lds > 64 * 1024 && !opted_in) {                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pwdw_fused_kernel<PWDW_MTW, NSWV>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
             opted_in = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((pwdw_fused_kernel<PWDW_MTW, NSWV>), grid, dim3(256), lds, s, f);                   \
+        hipLaunchKernelGGL((pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT>), grid, dim3(64 * f.nwaves), lds, s, f);                   \
     } while (0)
     if (f.nsw <= 2)
-        SHL_PWDW(2);
+        SHL_PWDW(2, 512);
     else if (f.nsw <= 4)
-        SHL_PWDW(4);
+        SHL_PWDW(4, 512);
     else
-        SHL_PWDW(8);
+        SHL_PWDW(8, 256);
 #undef SHL_PWDW
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
