@@ -57,6 +57,7 @@ struct ConvArgs {
     int32_t out_nchw;     // igemm tile kernel: write the output tensor as NCHW (input is still NHWC)
     int32_t halo_px;      // halo kernel: capacity of one LDS patch buffer in pixels (multiple of 16)
     int32_t halo_pps;     // halo kernel: patch pieces a producer wave requests per K step
+    const void *w_frag;   // pointwise int8: weights in MFMA fragment order [group][K/32][64][16 B], or null
 };
 
 // The pad page is 4 KiB so that concurrent readers can be spread over 32 cache lines instead of
@@ -292,6 +293,9 @@ void dwconv_dot4_pack(const shl_mi355x_conv_desc &d, const int8_t *hwo, uint32_t
 // depthwise 3x3 int8 NHWC on the matrix cores for bandwidth-bound sizes (dwconv_mfma.hip)
 bool dwconv_mfma_pick(int64_t M, int C, int H, int W, int Ho, int Wo, int sh, int sw);
 int launch_dwconv_mfma(const ConvArgs &a, hipStream_t s);
+// pointwise int8 NHWC with the weight slice in registers, for bandwidth-bound sizes (conv1x1_stream.hip)
+bool conv1x1_stream_pick(const ConvArgs &a);
+int launch_conv1x1_stream(const ConvArgs &a, hipStream_t s);
 bool stem_supports(const shl_mi355x_conv_desc &d);
 void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
 size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);

@@ -972,6 +972,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     (void)layout;  // the kernels see NHWC; NCHW callers were re-laid out by the plan
     const char *v = igemm_variant(a.M, a.Co);
     const bool i8 = dtype == SHL_MI355X_I8;
+    if (i8 && !variant_override()[0] && conv1x1_stream_pick(a)) return launch_conv1x1_stream(a, s);
     const int epi = i8 ? epi_code(a) : 0;
     const int esize = i8 ? 1 : 2;
     dim3 grid;

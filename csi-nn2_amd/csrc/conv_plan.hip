@@ -18,6 +18,7 @@ struct shl_mi355x_conv_plan {
     char *block;       // device
     size_t block_bytes;
     size_t off_w, off_acc, off_mult, off_bias, off_pad;
+    size_t off_wfrag;  // 0: absent; pointwise int8 weights in MFMA fragment order (conv1x1_stream.hip)
     // int8 epilogue shortcuts (see ConvArgs)
     int32_t div_exact, act_clamp;
     float clamp_lo, clamp_hi, inv_out_scale;
@@ -198,6 +199,15 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             p->kernel_name = i8 ? "conv_igemm_regs_i8_mfma32x32x32" : "conv_igemm_regs_f16_mfma32x32x16";
         else
             p->kernel_name = i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
+        if (i8 && d.layout == SHL_MI355X_NHWC) {  // pointwise at bandwidth-bound sizes (conv1x1_stream.hip)
+            ConvArgs probe = {};
+            probe.Kh = d.kernel_h, probe.Kw = d.kernel_w, probe.sh = d.stride_h, probe.sw = d.stride_w;
+            probe.pt = d.pad_top, probe.pl = d.pad_left, probe.H = d.in_h, probe.W = d.in_w, probe.Ho = d.out_h, probe.Wo = d.out_w;
+            probe.C = d.in_c, probe.Co = d.out_c, probe.kstride = p->kstride;
+            probe.w_frag = &probe;  // the copy is made below for exactly these shapes
+            probe.M = (int32_t)((int64_t)d.batch * d.out_h * d.out_w);
+            if (conv1x1_stream_pick(probe)) p->kernel_name = "conv1x1_stream_i8_mfma32x32x32";
+        }
     } else if (algo == SHL_MI355X_ALGO_STEM) {
         w_bytes = stem_weight_bytes(d);
         p->kernel_name = "conv_stem_i8_dot4";
@@ -223,6 +233,15 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     p->off_bias = p->off_mult + tab_bytes;
     p->off_pad = p->off_bias + tab_bytes;
     p->block_bytes = p->off_pad + PAD_PAGE_BYTES;
+    // pointwise int8 layers with K in {32 .. 512}: a second copy of the weights in fragment order
+    // [32-channel group][K / 32][64 lanes][16 B] so that a wave fetches an A fragment with one coalesced
+    // 1 KiB load (from [Cout][K] rows it is 64 lines per load instruction)
+    const bool frag_copy = algo == SHL_MI355X_ALGO_IGEMM && d.dtype == SHL_MI355X_I8 && d.kernel_h == 1 && d.kernel_w == 1 &&
+                           (d.in_c == 32 || d.in_c == 64 || d.in_c == 128 || d.in_c == 256 || d.in_c == 512) && d.out_c % 32 == 0;
+    if (frag_copy) {
+        p->off_wfrag = p->block_bytes;
+        p->block_bytes += (size_t)d.out_c * d.in_c;
+    }
     p->inv_out_scale = 1.0f / d.out_scale;
     if (d.dtype == SHL_MI355X_I8) {
         p->div_exact = is_pow2_scale(d.out_scale);
@@ -242,8 +261,16 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     memset(host.data() + p->off_pad, d.dtype == SHL_MI355X_I8 ? (d.in_zp & 0xFF) : 0, PAD_PAGE_BYTES);
     if (kernel_host) {
         const char *src = static_cast<const char *>(kernel_host);
-        if (algo == SHL_MI355X_ALGO_IGEMM)
+        if (algo == SHL_MI355X_ALGO_IGEMM) {
             pack_igemm(d, src, host.data() + p->off_w, p->kstride);
+            if (frag_copy) {
+                char *dst = host.data() + p->off_wfrag;
+                for (int g = 0; g < d.out_c / 32; ++g)
+                    for (int sub = 0; sub < d.in_c / 32; ++sub)
+                        for (int lane = 0; lane < 64; ++lane, dst += 16)
+                            memcpy(dst, host.data() + p->off_w + (size_t)(g * 32 + (lane & 31)) * p->kstride + sub * 32 + (lane >> 5) * 16, 16);
+            }
+        }
         else if (algo == SHL_MI355X_ALGO_STEM)
             stem_pack_weights(d, reinterpret_cast<const int8_t *>(src),
                               reinterpret_cast<int32_t *>(host.data() + p->off_w));
@@ -363,6 +390,7 @@ static int fill_args(const shl_mi355x_conv_plan *plan, const void *input_dev, vo
     a.in = input_dev;
     a.out = output_dev;
     a.w = plan->block + plan->off_w;
+    a.w_frag = plan->off_wfrag ? plan->block + plan->off_wfrag : nullptr;
     a.acc_init = reinterpret_cast<const int32_t *>(plan->block + plan->off_acc);
     a.mult = reinterpret_cast<const float *>(plan->block + plan->off_mult);
     a.bias = reinterpret_cast<const float *>(plan->block + plan->off_bias);
