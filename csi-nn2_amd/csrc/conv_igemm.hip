@@ -788,7 +788,12 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
         nsub = nsub_all - sub0 < per ? nsub_all - sub0 : per;
         if (nsub < 0) nsub = 0;
     }
-    const char *wp = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16 + (int64_t)sub0 * 32;
+    // pointwise layers carry a fragment-ordered copy of the weights (conv_plan.hip): one coalesced 1 KiB
+    // load per A fragment instead of 64 lines
+    const bool frag = a.w_frag != nullptr && (a.C & 63) == 0 && (a.Co & 31) == 0;
+    const char *wp = frag ? static_cast<const char *>(a.w_frag) + ((int64_t)tn * (a.C >> 5) + sub0) * 1024 + lane * 16
+                          : static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16 + (int64_t)sub0 * 32;
+    const int wstep = frag ? 1024 : 32;
     KCursor kc;
     kc.init(a, fhalf + 2 * sub0);  // sub-step s uses chunks 2s (lanes 0-31) and 2s+1 (lanes 32-63)
 
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
             FA[u] = *reinterpret_cast<const v4i *>(wp);                                   \
             FB[u] = *reinterpret_cast<const v4i *>(chunk_addr<ESIZE>(a, row, kc));        \
         }                                                                                 \
-        wp += 32;                                                                         \
+        wp += wstep;                                                                      \
         kc.advance(a, 2);                                                                 \
     }
     if (a.debug & 16) nsub = 0;

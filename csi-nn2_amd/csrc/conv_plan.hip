@@ -233,11 +233,11 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     p->off_bias = p->off_mult + tab_bytes;
     p->off_pad = p->off_bias + tab_bytes;
     p->block_bytes = p->off_pad + PAD_PAGE_BYTES;
-    // pointwise int8 layers with K in {32 .. 512}: a second copy of the weights in fragment order
+    // pointwise int8 layers with K a multiple of 32: a second copy of the weights in fragment order
     // [32-channel group][K / 32][64 lanes][16 B] so that a wave fetches an A fragment with one coalesced
     // 1 KiB load (from [Cout][K] rows it is 64 lines per load instruction)
     const bool frag_copy = algo == SHL_MI355X_ALGO_IGEMM && d.dtype == SHL_MI355X_I8 && d.kernel_h == 1 && d.kernel_w == 1 &&
-                           (d.in_c == 32 || d.in_c == 64 || d.in_c == 128 || d.in_c == 256 || d.in_c == 512) && d.out_c % 32 == 0;
+                           d.in_c % 32 == 0 && d.in_c <= 2048 && d.out_c % 32 == 0;
     if (frag_copy) {
         p->off_wfrag = p->block_bytes;
         p->block_bytes += (size_t)d.out_c * d.in_c;

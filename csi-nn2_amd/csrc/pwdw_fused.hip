@@ -99,11 +99,16 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     nsw = nsw < f.nsw ? nsw : f.nsw;  // may be <= 0 for a ragged last part
 
     const char *img = static_cast<const char *>(q.in) + (int64_t)n * q.H * q.W * q.C;
-    const char *wp = static_cast<const char *>(q.w) + (int64_t)(slice * 32 + frow) * q.kstride + fhalf * 16 + sub0 * 32;
+    // weights: from the plan's fragment-ordered copy when there is one (one coalesced 1 KiB load per
+    // fragment), else 16 bytes per lane out of the [Cout][K] rows
+    const bool frag = q.w_frag != nullptr;
+    const char *wp = frag ? static_cast<const char *>(q.w_frag) + ((int64_t)slice * f.nsub + sub0) * 1024 + lane * 16
+                          : static_cast<const char *>(q.w) + (int64_t)(slice * 32 + frow) * q.kstride + fhalf * 16 + sub0 * 32;
+    const int wstep = frag ? 1024 : 32;
     v4i fa[NSW];
 #pragma unroll
     for (int s = 0; s < NSW; ++s)
-        if (s < nsw) fa[s] = *reinterpret_cast<const v4i *>(wp + s * 32);
+        if (s < nsw) fa[s] = *reinterpret_cast<const v4i *>(wp + s * wstep);
     v4i fb[MTW][NSW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
