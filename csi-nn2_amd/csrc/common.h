@@ -311,6 +311,9 @@ int launch_dwpw_fused(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);
 // pointwise 1x1 + the depthwise 3x3 that consumes it in one launch (pwdw_fused.hip)
 bool pwdw_fusable(const ConvArgs &pw, const ConvArgs &dw, int pw_is_igemm, int dw_dot4_packed);
 int launch_pwdw_fused(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
+// stem 3x3 (3 -> 32) + the depthwise 3x3 consuming it in one launch (stemdw_fused.hip)
+bool stemdw_fusable(const ConvArgs &stem, const ConvArgs &dw);
+int launch_stemdw_fused(const ConvArgs &stem, const ConvArgs &dw, hipStream_t s);
 // the same pair in bandwidth form for large batches (pwdw_stream.hip)
 bool pwdw_stream_eligible(const ConvArgs &pw, const ConvArgs &dw);
 int launch_pwdw_stream(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);

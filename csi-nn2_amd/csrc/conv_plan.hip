@@ -521,13 +521,14 @@ int shl_mi355x_dwpw_forward(const shl_mi355x_conv_plan *dw, const shl_mi355x_con
 }
 
 /* which fused kernel runs the pair: 0 none, 1 latency form (pwdw_fused.hip: small grids), 2 bandwidth form
- * (pwdw_stream.hip).  The bandwidth form is opt-in (SHL_MI355X_PWDW_STREAM=1: whenever the pair is
+ * (pwdw_stream.hip), 3 stem + depthwise (stemdw_fused.hip).  The bandwidth form is opt-in (SHL_MI355X_PWDW_STREAM=1: whenever the pair is
  * eligible): at batch 128 it only breaks even with the two stand-alone kernels for K <= 128 and loses
  * for deeper K (profiles/r01_notes.md), so large batches keep one launch per layer by default. */
 static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, const ConvArgs &a,
                            const ConvArgs &b)
 {
     const int pw_igemm = pw->algo == SHL_MI355X_ALGO_IGEMM, dw_dot4 = dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12;
+    if (pw->algo == SHL_MI355X_ALGO_STEM) return dw_dot4 && stemdw_fusable(a, b) ? 3 : 0;  // stem + depthwise
     static const char *st = getenv("SHL_MI355X_PWDW_STREAM");
     if (st && st[0] == '1' && pw_igemm && dw_dot4 && pwdw_stream_eligible(a, b)) return 2;
     return pwdw_fusable(a, b, pw_igemm, dw_dot4) ? 1 : 0;
@@ -565,8 +566,11 @@ int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     if (rc == SHL_MI355X_OK) rc = fill_args(dw, input_dev, output_dev, batch, b);
     if (rc != SHL_MI355X_OK) return rc;
     if (b.M == 0) return SHL_MI355X_OK;
-    return pwdw_kernel_for(pw, dw, a, b) == 2 ? launch_pwdw_stream(a, b, (hipStream_t)stream)
-                                              : launch_pwdw_fused(a, b, (hipStream_t)stream);
+    switch (pwdw_kernel_for(pw, dw, a, b)) {
+        case 3: return launch_stemdw_fused(a, b, (hipStream_t)stream);
+        case 2: return launch_pwdw_stream(a, b, (hipStream_t)stream);
+        default: return launch_pwdw_fused(a, b, (hipStream_t)stream);
+    }
 }
 
 }  // extern "C"

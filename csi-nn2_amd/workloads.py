@@ -200,7 +200,9 @@ class LayerChain:
 
     def unit_kernel_name(self, u):
         idx = self.units[u]
-        return self.entries[idx[0]]["kernel_name"] if len(idx) == 1 else "pwdw_fused_i8"
+        if len(idx) == 1:
+            return self.entries[idx[0]]["kernel_name"]
+        return "stemdw_fused_i8" if self.entries[idx[0]]["kernel_name"].startswith("conv_stem") else "pwdw_fused_i8"
 
     def unit_name(self, u):
         return " + ".join(layer_name(self.entries[i]["layer"]) for i in self.units[u])

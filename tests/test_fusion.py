@@ -163,6 +163,48 @@ def test_pointwise_depthwise_pairs_that_do_not_qualify_are_refused(gpu):
         opt.shl_mi355x_release_params(p)
 
 
+STEM_PAIRS = [dict(hw=32, dw_stride=1), dict(hw=45, dw_stride=2, n=2), dict(hw=224, dw_stride=1, relu=(1, 0)),
+              dict(hw=19, dw_stride=1, exact=False)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(STEM_PAIRS)), ids=["hw%d_s%d" % (p["hw"], p["dw_stride"]) for p in STEM_PAIRS])
+def test_stem_depthwise_pair_equals_the_two_kernels_and_the_oracle(gpu, i):
+    """conv 3x3 s2 (3 -> 32) + the depthwise layer consuming it (csrc/stemdw_fused.hip)"""
+    fe, hip, opt = gpu
+    kw = STEM_PAIRS[i]
+    n, exact, relu = kw.get("n", 1), kw.get("exact", True), kw.get("relu", (1, 1))
+    st = cases.make_case(600 + i, n=n, h=kw["hw"], w=kw["hw"], c=3, co=32, stride=(2, 2), act=relu[0], exact=exact)
+    dw = cases.make_case(650 + i, n=n, h=st["ho"], w=st["wo"], c=32, depthwise=True, stride=(kw["dw_stride"],) * 2,
+                         act=relu[1], exact=exact)
+    dw["in_scale"], dw["in_zp"] = st["out_scale"], st["out_zp"]
+    dw["b_scale"] = (np.float32(dw["in_scale"]) * dw["k_scale"]).astype(np.float32)
+    dev = cases.HipDevice(hip)
+    keep = []
+    mid = cases.csinn_run(fe, pkg.API_MI355X, st, device=dev, keep_params=keep)
+    assert opt.shl_mi355x_params_kernel_name(keep[0][0]).decode() == "conv_stem_i8_dot4"
+    dw["input"] = mid
+    want = cases.csinn_run(fe, pkg.API_MI355X, dw, device=dev, keep_params=keep)
+    o_dw = dict(dw)
+    o_dw["input"] = cases.oracle_run(st, "exact")
+    nbad, worst = cases.mismatch_report(want, cases.oracle_run(o_dw, "exact"))
+    assert nbad == 0, "stand-alone kernels vs oracle: %d mismatches (max %d)" % (nbad, worst)
+    plan_st, plan_dw = (opt.shl_mi355x_registry_get(p) for p, _ in keep)
+    assert hip.shl_mi355x_pwdw_fusable(plan_st, plan_dw, n) == 1
+    d_in = dev.alloc(st["input"].nbytes)
+    dev.upload(d_in, st["input"])
+    d_out = dev.alloc(want.nbytes)
+    hip.shl_mi355x_memset(d_out, 0x55, want.nbytes, None)
+    pkg.check(hip.shl_mi355x_pwdw_forward(plan_st, plan_dw, d_in, d_out, n, None), hip, "pwdw_forward(stem)")
+    got = dev.download(d_out, want.shape, np.int8)
+    nbad, worst = cases.mismatch_report(got, want)
+    assert nbad == 0, "fused vs stand-alone: %d mismatches (max |d| %d)" % (nbad, worst)
+    dev.free(d_in)
+    dev.free(d_out)
+    for p, _ in keep:
+        opt.shl_mi355x_release_params(p)
+
+
 @pytest.mark.gpu
 def test_pairs_that_do_not_qualify_are_refused(gpu):
     fe, hip, opt = gpu
@@ -224,5 +266,5 @@ def test_whole_mobilenet_is_identical_with_and_without_fusion(gpu):
         assert "OUT" in res.stdout, res.stdout + res.stderr
         lines = dict(l.split(" ", 1) for l in res.stdout.strip().splitlines() if " " in l)
         outs[name] = (int(lines["PAIRS"]), lines["OUT"])
-    assert outs["none"][0] == 0 and outs["dwpw"][0] == 13 and outs["pwdw"][0] == 12
+    assert outs["none"][0] == 0 and outs["dwpw"][0] == 13 and outs["pwdw"][0] == 13   # 12 pointwise + the stem pair
     assert outs["none"][1] == outs["dwpw"][1] == outs["pwdw"][1]

@@ -31,6 +31,10 @@ FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kern
     ("dwconv3x3_i8_dot4_kernel", "dwconv_nhwc_i8"),
     ("dwpw_fused_kernel", "dwpw_fused_i8"),
     ("pwdw_fused_kernel", "pwdw_fused_i8"),
+    ("stemdw_fused_kernel", "stemdw_fused_i8"),
+    ("pwdw_stream_kernel", "pwdw_stream_i8"),
+    ("conv1x1_stream_kernel", "conv1x1_stream_i8_mfma32x32x32"),
+    ("dwconv3x3_i8_mfma_kernel", "dwconv_mfma_i8"),
     ("dwconv_nhwc_kernel<false", "dwconv_nhwc_f16"),
     ("conv_direct_kernel<true", "conv_direct_i8"),
     ("conv_direct_kernel<false", "conv_direct_f16"),
