@@ -87,6 +87,68 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a)
     }
 }
 
+// binary16 NCHW stem (3 input channels, 3x3, e.g. the first layer of c906_mobilenetv1_f16): the generic
+// kernel above walks its 27 taps with dependent loads, one output per thread (11 us at 224 x 224, batch 1).
+// Here a thread owns one output pixel x 8 output channels: the 27 input values are requested together,
+// the weights sit in LDS as [tap][Cout] (broadcast 16-byte reads), and the fp32 sums run in the same
+// ky -> kx -> ic order over in-image taps only, so results are bit-identical to the generic kernel.
+__global__ __launch_bounds__(256) void conv_stem_f16_nchw_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 w_lds[27 * 64];  // [k = (ky*3 + kx)*3 + ic][co]
+    const int co_pad = (a.Co + 7) & ~7;
+    const int groups = co_pad >> 3;
+    const int hw = a.Ho * a.Wo;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (n, channel group, pixel), pixel fastest
+    const int64_t total = (int64_t)a.N * groups * hw;
+    const int64_t gc = gid < total ? gid : total - 1;
+    const int p = (int)(gc % hw);
+    const int g = (int)((gc / hw) % groups);
+    const int n = (int)(gc / ((int64_t)hw * groups));
+    const int oy = p / a.Wo, ox = p - oy * a.Wo;
+    const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
+    const _Float16 *in = static_cast<const _Float16 *>(a.in) + (int64_t)n * 3 * a.H * a.W;
+    float xv[27];
+    bool ok[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int y = y0 + ky * a.dh, x = x0 + kx * a.dw;
+            const bool inb = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            ok[ky * 3 + kx] = inb;
+            const int yc = inb ? y : 0, xc = inb ? x : 0;
+#pragma unroll
+            for (int ic = 0; ic < 3; ++ic) xv[(ky * 3 + kx) * 3 + ic] = (float)in[((int64_t)ic * a.H + yc) * a.W + xc];
+        }
+    // weights -> LDS after the input values were requested: one exposed memory latency, not two
+    const _Float16 *w = static_cast<const _Float16 *>(a.w);  // OIHW: [co][ic][ky][kx]
+    for (int i = threadIdx.x; i < 27 * co_pad; i += 256) {
+        const int co = i % co_pad, k = i / co_pad;
+        const int ic = k % 3, kx = (k / 3) % 3, ky = k / 9;
+        w_lds[k * co_pad + co] = co < a.Co ? w[((co * 3 + ic) * 3 + ky) * 3 + kx] : (_Float16)0;
+    }
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const v8h wv = *reinterpret_cast<const v8h *>(&w_lds[k * co_pad + g * 8]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s = __fadd_rn(acc[e], __fmul_rn(xv[k], (float)wv[e]));
+            acc[e] = ok[k / 3] ? s : acc[e];
+        }
+    }
+    if (gid >= total) return;
+    uint16_t *out = static_cast<uint16_t *>(a.out);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int oc = g * 8 + e;
+        if (oc < a.Co) out[((int64_t)n * a.Co + oc) * hw + p] = finish_f16(acc[e], a.bias[oc], a);
+    }
+}
+
 template <typename T>
 static void launch_t(const ConvArgs &a, int layout, int dw_last, dim3 grid, hipStream_t s)
 {
@@ -105,6 +167,15 @@ int launch_conv_direct(const ConvArgs &a, int dtype, int layout, int dw_nhwc_wei
 {
     const int64_t total = (int64_t)a.M * a.Co;
     if (total == 0) return SHL_MI355X_OK;
+    if (dtype == SHL_MI355X_F16 && layout == SHL_MI355X_NCHW && a.C == 3 && a.group == 1 && a.Kh == 3 && a.Kw == 3 &&
+        a.Co <= 64) {
+        const int64_t threads = (int64_t)a.N * ((a.Co + 7) / 8) * a.Ho * a.Wo;
+        if ((threads + 255) / 256 < 0x7FFFFFFF) {
+            hipLaunchKernelGGL(conv_stem_f16_nchw_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+            SHL_HIP(hipGetLastError());
+            return SHL_MI355X_OK;
+        }
+    }
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 blocks per CU
     const dim3 grid((unsigned)blocks);

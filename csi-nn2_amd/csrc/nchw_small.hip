@@ -17,18 +17,21 @@
 //
 // Restates shl_ref_conv2d_nchw_f32 / shl_ref_depthwise_conv2d_nchw_f32
 // (source/reference/convolution.c:91-139, 206-269) inside the *_quant callbacks.
+#include <stdlib.h>
+
 #include "igemm_common.h"
 
 namespace shl {
 
 template <bool kI8>
-__global__ __launch_bounds__(256) void conv1x1_nchw_kernel(ConvArgs a)
+__global__ __launch_bounds__(1024) void conv1x1_nchw_kernel(ConvArgs a)
 {
     constexpr int ESIZE = kI8 ? 1 : 2;
     constexpr int KE = 16 / ESIZE;  // K elements per lane per MFMA sub-step (one 16-byte fragment)
-    __shared__ __attribute__((aligned(16))) int32_t red[4 * 3 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) int32_t red[4 * 15 * 64 * 4];  // [owner][source][lane] x 16 bytes
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;  // 4, 8 or 16 waves split K (deep K: the gathers are issue-bound per wave)
     const int HW = a.H * a.W;
     const int ptiles = (HW + 31) >> 5;  // pixel tiles per image
     const int tn = blockIdx.x;          // output-channel tile
@@ -36,9 +39,9 @@ __global__ __launch_bounds__(256) void conv1x1_nchw_kernel(ConvArgs a)
     const int p0 = (blockIdx.y - n * ptiles) << 5;
     const int frow = lane & 31, fhalf = lane >> 5;
 
-    // finishing role: wave w requantises register group w (channels ch0 + 8w .. +3)
+    // finishing role: wave w < 4 requantises register group w (channels ch0 + 8w .. +3)
     const int ch0 = tn * 32 + 4 * fhalf;
-    const int cfin = ch0 + 8 * wave;
+    const int cfin = ch0 + 8 * (wave & 3);
     const int4 ai = *reinterpret_cast<const int4 *>(a.acc_init + cfin);
     const float4 mu = *reinterpret_cast<const float4 *>(a.mult + cfin);
     const float4 bi = *reinterpret_cast<const float4 *>(a.bias + cfin);
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void conv1x1_nchw_kernel(ConvArgs a)
     const bool live = px < HW;
     px = live ? px : HW - 1;
     const int nsub_all = a.kstride / 32 * (kI8 ? 1 : 1);  // 32-byte K sub-steps of the packed rows
-    const int per = (nsub_all + 3) >> 2;
+    const int per = (nsub_all + nw - 1) / nw;
     const int sub0 = wave * per;
     int nsub = nsub_all - sub0 < per ? nsub_all - sub0 : per;
     if (nsub < 0) nsub = 0;
@@ -105,10 +108,12 @@ __global__ __launch_bounds__(256) void conv1x1_nchw_kernel(ConvArgs a)
             else
                 part[g][e] = __float_as_int(acc[4 * g + e]);
         }
+    const int nsrc = nw - 1;  // pieces an owner receives
 #pragma unroll
     for (int d = 0; d < 4; ++d)
-        if (d != wave) slots[(d * 3 + (wave < d ? wave : wave - 1)) * 64 + lane] = part[d];
+        if (d != wave) slots[(d * nsrc + (wave < d ? wave : wave - 1)) * 64 + lane] = part[d];
     __syncthreads();
+    if (wave >= 4) return;
     v4i mine = wave == 0 ? part[0] : wave == 1 ? part[1] : wave == 2 ? part[2] : part[3];
     int v_i[4];
     float v_f[4];
@@ -117,9 +122,8 @@ __global__ __launch_bounds__(256) void conv1x1_nchw_kernel(ConvArgs a)
         v_i[e] = mine[e];
         v_f[e] = __int_as_float(mine[e]);
     }
-#pragma unroll
-    for (int src = 0; src < 3; ++src) {
-        const v4i other = slots[(wave * 3 + src) * 64 + lane];
+    for (int src = 0; src < nsrc; ++src) {
+        const v4i other = slots[(wave * nsrc + src) * 64 + lane];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v_i[e] += other[e];
@@ -194,10 +198,17 @@ int launch_conv1x1_nchw(const ConvArgs &a, int dtype, hipStream_t s)
 {
     const int ptiles = (a.H * a.W + 31) / 32;
     const dim3 grid((unsigned)((a.Co + 31) / 32), (unsigned)(a.N * ptiles));
+    // more waves as long as each still gets >= 2 K sub-steps of 32 bytes (f16: 8 from K = 256, 16 from
+    // K = 512; int8: from K = 512 / 1024).  MobileNetV1 fp16 NCHW batch 1: 512 -> 512 @14 8.9 -> 6.9 us with 8
+    static const char *env = getenv("SHL_MI355X_NCHW_WAVES");  // 4 | 8 | 16 (A/B)
+    const int nsub = a.kstride / 32;
+    int threads = nsub >= 32 ? 1024 : (nsub >= 16 ? 512 : 256);
+    if (env) threads = 64 * atoi(env);
+    if (threads != 256 && threads != 512 && threads != 1024) threads = 256;
     if (dtype == SHL_MI355X_I8)
-        hipLaunchKernelGGL((conv1x1_nchw_kernel<true>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv1x1_nchw_kernel<true>), grid, dim3(threads), 0, s, a);
     else
-        hipLaunchKernelGGL((conv1x1_nchw_kernel<false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv1x1_nchw_kernel<false>), grid, dim3(threads), 0, s, a);
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }
