@@ -1,0 +1,95 @@
+// dw_patch.h -- depthwise 3x3 (int8, 32 channels) from an int8 patch [pixel][32 B] in LDS: the second
+// phase of the latency-form fused kernels (pwdw_fused.hip, stemdw_fused.hip).
+//
+// Patch layout: pixel j = r * rw + c of the rectangle's input patch, 8 dwords (4 channels each); the dword
+// of channel group g sits at index g ^ ((j >> 2) & 7) so that both the producer's stores (32 pixels
+// x one group) and the reads below (8 groups x 4 pixels per 32 lanes) are bank-conflict free.
+#pragma once
+
+#include "common.h"
+
+namespace shl {
+
+// where the producer phase must put channel group `group` (0..7) of patch pixel j
+__device__ __forceinline__ int dw_patch_slot(int j, int group) { return j * 8 + (group ^ ((j >> 2) & 7)); }
+
+struct DwPatchGeom {
+    int bh, bw;         // output rectangle of the workgroup
+    int rw;             // patch width in pixels
+    uint32_t bw_magic;  // po / bw == (po * bw_magic) >> 20 for po < 4096
+    int oy0, ox0;       // first output pixel of the rectangle
+    int ry0, rx0;       // patch origin in the depthwise layer's input image (may be negative: padding)
+    int n;              // image
+    int ch0;            // first of the 32 channels in the output tensor
+};
+
+// A thread's 4 channels (group tid & 7 of the 32 starting at ch0) are the same for every output it
+// computes: their dot4-packed weights and epilogue tables.  Request them at the top of the kernel so that
+// they arrive under the producer phase.
+struct DwThreadConsts {
+    uint4 w0, w1, w2;
+    int4 ai;
+    float4 mu, bi;
+};
+
+__device__ __forceinline__ DwThreadConsts dw_load_consts(const ConvArgs &d, int ch0, int tid)
+{
+    const int dc = ch0 + (tid & 7) * 4;
+    const uint4 *dwp = reinterpret_cast<const uint4 *>(static_cast<const char *>(d.w) + (int64_t)dc * 12);
+    DwThreadConsts k;
+    k.w0 = dwp[0], k.w1 = dwp[1], k.w2 = dwp[2];
+    k.ai = *reinterpret_cast<const int4 *>(d.acc_init + dc);
+    k.mu = *reinterpret_cast<const float4 *>(d.mult + dc);
+    k.bi = *reinterpret_cast<const float4 *>(d.bias + dc);
+    return k;
+}
+
+// thread = (output pixel, 4 channels): nine dwords from the patch (the padding value for taps outside the
+// image), byte transposes + v_dot4_i32_i8 against the plan's dot4-packed weights, requantise, one dword
+// store.  `threads` = workgroup size (a multiple of 8).  Restates shl_ref_depthwise_conv2d_quant
+// (source/reference/convolution.c:416-460) + relu variants.
+__device__ __forceinline__ void depthwise_from_patch(const ConvArgs &d, const uint32_t *patch, const DwPatchGeom &g,
+                                                     const DwThreadConsts &k, int tid, int threads)
+{
+    const int cg = tid & 7;
+    const int dc = g.ch0 + cg * 4;
+    const uint4 w0 = k.w0, w1 = k.w1, w2 = k.w2;
+    const int4 d_ai = k.ai;
+    const float4 d_mu = k.mu, d_bi = k.bi;
+    const uint32_t zp4 = (uint32_t)(d.in_zp & 0xff) * 0x01010101u;
+    const uint32_t wk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    const int nout = g.bh * g.bw;
+    int8_t *out = static_cast<int8_t *>(d.out);
+    for (int po = tid >> 3; po < nout; po += threads >> 3) {
+        const int oyl = (int)(((uint32_t)po * g.bw_magic) >> 20);
+        const int oxl = po - oyl * g.bw;
+        const int oy = g.oy0 + oyl, ox = g.ox0 + oxl;
+        if (oy >= d.Ho || ox >= d.Wo) continue;
+        uint32_t iv[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int r = oyl * d.sh + ky, c = oxl * d.sw + kx;
+                const bool ok = (unsigned)(g.ry0 + r) < (unsigned)d.H && (unsigned)(g.rx0 + c) < (unsigned)d.W;
+                const uint32_t v = patch[dw_patch_slot(r * g.rw + c, cg)];
+                iv[ky * 3 + kx] = ok ? v : zp4;
+            }
+        const uint32_t r0[4] = {iv[0], iv[1], iv[2], iv[3]}, r1[4] = {iv[4], iv[5], iv[6], iv[7]};
+        uint32_t t0[4], t1[4];
+        transpose4x4_bytes(r0, t0);  // t0[ch] = taps 0..3 of channel ch
+        transpose4x4_bytes(r1, t1);  // taps 4..7
+        int a4[4] = {d_ai.x, d_ai.y, d_ai.z, d_ai.w};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const uint32_t t2 = __builtin_amdgcn_ubfe(iv[8], 8 * ch, 8);  // tap 8 in byte 0, zeros above
+            a4[ch] = __builtin_amdgcn_sdot4((int)t0[ch], (int)wk[3 * ch + 0], a4[ch], false);
+            a4[ch] = __builtin_amdgcn_sdot4((int)t1[ch], (int)wk[3 * ch + 1], a4[ch], false);
+            a4[ch] = __builtin_amdgcn_sdot4((int)t2, (int)wk[3 * ch + 2], a4[ch], false);
+        }
+        const int64_t o = (((int64_t)g.n * d.Ho + oy) * d.Wo + ox) * d.C + dc;
+        *reinterpret_cast<uint32_t *>(out + o) = requant4_i8_rt(a4[0], a4[1], a4[2], a4[3], d_mu, d_bi, d);
+    }
+}
+
+}  // namespace shl

@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "dw_patch.h"
 #include "igemm_common.h"
 
 namespace shl {
@@ -80,14 +81,8 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     const int4 p_ai = *reinterpret_cast<const int4 *>(q.acc_init + pc);
     const float4 p_mu = *reinterpret_cast<const float4 *>(q.mult + pc);
     const float4 p_bi = *reinterpret_cast<const float4 *>(q.bias + pc);
-    // depthwise: thread handles channel group tid & 7 of the slice for every output it computes
-    const int cg = tid & 7;
-    const int dc = slice * 32 + cg * 4;
-    const uint4 *dwp = reinterpret_cast<const uint4 *>(static_cast<const char *>(d.w) + (int64_t)dc * 12);
-    const uint4 w0 = dwp[0], w1 = dwp[1], w2 = dwp[2];
-    const int4 d_ai = *reinterpret_cast<const int4 *>(d.acc_init + dc);
-    const float4 d_mu = *reinterpret_cast<const float4 *>(d.mult + dc);
-    const float4 d_bi = *reinterpret_cast<const float4 *>(d.bias + dc);
+
+    const DwThreadConsts dwk = dw_load_consts(d, slice * 32, tid);  // depthwise constants, requested early
 
     // ---- pointwise: this wave's (tile, K part) pairs
     const int ks = f.ks;
@@ -164,46 +159,15 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
         for (int k = 1; k < ks; ++k) v += part[((tile * ks + k) * 4 + fgrp) * 64 + lane];
         const int j = tile * 32 + frow;
         const uint32_t packed = requant4_i8_rt(v[0] + p_ai.x, v[1] + p_ai.y, v[2] + p_ai.z, v[3] + p_ai.w, p_mu, p_bi, q);
-        if (j < f.npx) patch[j * 8 + ((2 * fgrp + fhalf) ^ ((j >> 2) & 7))] = packed;
+        if (j < f.npx) patch[dw_patch_slot(j, 2 * fgrp + fhalf)] = packed;
     }
     __syncthreads();
 
-    // ---- depthwise 3x3 on the slice's 32 channels, from the LDS patch
-    const uint32_t zp4 = (uint32_t)(d.in_zp & 0xff) * 0x01010101u;
-    const uint32_t wk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-    const int nout = f.bh * f.bw;
-    int8_t *out = static_cast<int8_t *>(d.out);
-    for (int po = tid >> 3; po < nout; po += nwaves * 8) {
-        const int oyl = (int)(((uint32_t)po * f.bw_magic) >> 20);
-        const int oxl = po - oyl * f.bw;
-        const int oy = oy0 + oyl, ox = ox0 + oxl;
-        if (oy >= d.Ho || ox >= d.Wo) continue;
-        uint32_t iv[9];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int r = oyl * d.sh + ky, c = oxl * d.sw + kx;
-                const int j = r * f.rw + c;
-                const bool ok = (unsigned)(ry0 + r) < (unsigned)d.H && (unsigned)(rx0 + c) < (unsigned)d.W;
-                const uint32_t v = patch[j * 8 + (cg ^ ((j >> 2) & 7))];
-                iv[ky * 3 + kx] = ok ? v : zp4;
-            }
-        const uint32_t r0[4] = {iv[0], iv[1], iv[2], iv[3]}, r1[4] = {iv[4], iv[5], iv[6], iv[7]};
-        uint32_t t0[4], t1[4];
-        transpose4x4_bytes(r0, t0);
-        transpose4x4_bytes(r1, t1);
-        int a4[4] = {d_ai.x, d_ai.y, d_ai.z, d_ai.w};
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            const uint32_t t2 = __builtin_amdgcn_ubfe(iv[8], 8 * ch, 8);
-            a4[ch] = __builtin_amdgcn_sdot4((int)t0[ch], (int)wk[3 * ch + 0], a4[ch], false);
-            a4[ch] = __builtin_amdgcn_sdot4((int)t1[ch], (int)wk[3 * ch + 1], a4[ch], false);
-            a4[ch] = __builtin_amdgcn_sdot4((int)t2, (int)wk[3 * ch + 2], a4[ch], false);
-        }
-        const int64_t o = (((int64_t)n * d.Ho + oy) * d.Wo + ox) * d.C + dc;
-        *reinterpret_cast<uint32_t *>(out + o) = requant4_i8_rt(a4[0], a4[1], a4[2], a4[3], d_mu, d_bi, d);
-    }
+    // ---- depthwise 3x3 on the slice's 32 channels, from the LDS patch (dw_patch.h)
+    DwPatchGeom g;
+    g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic;
+    g.oy0 = oy0, g.ox0 = ox0, g.ry0 = ry0, g.rx0 = rx0, g.n = n, g.ch0 = slice * 32;
+    depthwise_from_patch(d, patch, g, dwk, tid, nwaves * 64);
 }
 
 // ---- host side ---------------------------------------------------------------------------------

@@ -7,11 +7,11 @@
 //              pixel x 16 channels, exactly as conv_stem.hip does (27 input bytes packed into 7 dwords,
 //              weights [k/4][32] in LDS, v_dot4_i32_i8, the stem's requantisation) and leaves the int8
 //              result in an LDS patch [pixel][32 B]; patch pixels outside the image are never read
-//   phase 2    the depthwise layer from the patch exactly as pwdw_fused.hip does (thread = output pixel
-//              x 4 channels, byte transposes + v_dot4_i32_i8 against the dot4-packed weights)
+//   phase 2    the depthwise layer from the patch: dw_patch.h, shared with pwdw_fused.hip (thread = output
+//              pixel x 4 channels, byte transposes + v_dot4_i32_i8 against the dot4-packed weights)
 // Bit-identical to the two stand-alone launches.  Restates shl_ref_conv2d_quant followed by
 // shl_ref_depthwise_conv2d_quant (source/reference/convolution.c:370-400, 416-460) + relu variants.
-#include "common.h"
+#include "dw_patch.h"
 
 namespace shl {
 
@@ -46,13 +46,7 @@ __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
     }
     const int oy0 = ty * f.bh, ox0 = tx * f.bw;
     const int ry0 = oy0 * d.sh - d.pt, rx0 = ox0 * d.sw - d.pl;  // patch origin in stem-output coordinates
-    // depthwise constants of this thread's 4 channels, requested early
-    const int cg = tid & 7;
-    const uint4 *dwp = reinterpret_cast<const uint4 *>(static_cast<const char *>(d.w) + cg * 48);
-    const uint4 w0 = dwp[0], w1 = dwp[1], w2 = dwp[2];
-    const int4 d_ai = *reinterpret_cast<const int4 *>(d.acc_init + cg * 4);
-    const float4 d_mu = *reinterpret_cast<const float4 *>(d.mult + cg * 4);
-    const float4 d_bi = *reinterpret_cast<const float4 *>(d.bias + cg * 4);
+    const DwThreadConsts dwk = dw_load_consts(d, 0, tid);  // depthwise constants, requested early
 
     // ---- phase 1: stem output of (patch pixel, 16 channels) per task
     const int8_t *img = static_cast<const int8_t *>(q.in) + (int64_t)n * q.H * q.W * 3;
@@ -106,47 +100,16 @@ __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
             const float4 bi = *reinterpret_cast<const float4 *>(t_tab + 64 + c);
             const uint32_t pk = requant4_i8_rt(acc[4 * v] + ai.x, acc[4 * v + 1] + ai.y, acc[4 * v + 2] + ai.z,
                                                acc[4 * v + 3] + ai.w, mu, bi, q);
-            if (valid) patch[j * 8 + ((c >> 2) ^ ((j >> 2) & 7))] = pk;
+            if (valid) patch[dw_patch_slot(j, c >> 2)] = pk;
         }
     }
     __syncthreads();
 
-    // ---- phase 2: depthwise 3x3 from the patch (pwdw_fused.hip, phase 3)
-    const uint32_t zp4 = (uint32_t)(d.in_zp & 0xff) * 0x01010101u;
-    const uint32_t wk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-    const int nout = f.bh * f.bw;
-    int8_t *out = static_cast<int8_t *>(d.out);
-    for (int po = tid >> 3; po < nout; po += 32) {
-        const int oyl = (int)(((uint32_t)po * f.bw_magic) >> 20);
-        const int oxl = po - oyl * f.bw;
-        const int oy = oy0 + oyl, ox = ox0 + oxl;
-        if (oy >= d.Ho || ox >= d.Wo) continue;
-        uint32_t iv[9];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int r = oyl * d.sh + ky, c = oxl * d.sw + kx;
-                const int j = r * f.rw + c;
-                const bool ok = (unsigned)(ry0 + r) < (unsigned)d.H && (unsigned)(rx0 + c) < (unsigned)d.W;
-                const uint32_t v = patch[j * 8 + (cg ^ ((j >> 2) & 7))];
-                iv[ky * 3 + kx] = ok ? v : zp4;
-            }
-        const uint32_t r0[4] = {iv[0], iv[1], iv[2], iv[3]}, r1[4] = {iv[4], iv[5], iv[6], iv[7]};
-        uint32_t t0[4], t1[4];
-        transpose4x4_bytes(r0, t0);
-        transpose4x4_bytes(r1, t1);
-        int a4[4] = {d_ai.x, d_ai.y, d_ai.z, d_ai.w};
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            const uint32_t t2 = __builtin_amdgcn_ubfe(iv[8], 8 * ch, 8);
-            a4[ch] = __builtin_amdgcn_sdot4((int)t0[ch], (int)wk[3 * ch + 0], a4[ch], false);
-            a4[ch] = __builtin_amdgcn_sdot4((int)t1[ch], (int)wk[3 * ch + 1], a4[ch], false);
-            a4[ch] = __builtin_amdgcn_sdot4((int)t2, (int)wk[3 * ch + 2], a4[ch], false);
-        }
-        const int64_t o = (((int64_t)n * d.Ho + oy) * d.Wo + ox) * 32 + cg * 4;
-        *reinterpret_cast<uint32_t *>(out + o) = requant4_i8_rt(a4[0], a4[1], a4[2], a4[3], d_mu, d_bi, d);
-    }
+    // ---- phase 2: depthwise 3x3 from the patch (dw_patch.h)
+    DwPatchGeom g;
+    g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic;
+    g.oy0 = oy0, g.ox0 = ox0, g.ry0 = ry0, g.rx0 = rx0, g.n = n, g.ch0 = 0;
+    depthwise_from_patch(d, patch, g, dwk, tid, 256);
 }
 
 static bool stemdw_geometry(const ConvArgs &q, const ConvArgs &d, StemDwArgs &f)
