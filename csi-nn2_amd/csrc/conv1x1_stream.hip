@@ -19,6 +19,7 @@
 // Restates shl_ref_conv2d_quant (source/reference/convolution.c:370-400) + relu variants for 1x1 kernels.
 #include <stdlib.h>
 
+#include "dw_mfma.h"
 #include "igemm_common.h"
 
 namespace shl {
@@ -143,19 +144,9 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(ConvArgs a)
             for (int g = 0; g < 4; ++g)
                 pk[g] = requant4_i8_rt(acc[t][4 * g] + ai[g].x, acc[t][4 * g + 1] + ai[g].y, acc[t][4 * g + 2] + ai[g].z,
                                        acc[t][4 * g + 3] + ai[g].w, mu[g], bi[g], a);
-            // lanes 0-31 hold channels {0-3, 8-11, 16-19, 24-27}, lanes 32-63 {4-7, 12-15, 20-23, 28-31}:
-            // swap(pk0, pk2) / swap(pk1, pk3) leave every lane with 16 consecutive channels
-            const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-            const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+            const uint4 v = tile_channels_16(pk);  // 16 consecutive channels per lane (dw_mfma.h)
             const int p = p0 + (th + WPC * t) * 32 + row;
-            if (p < a.M) {
-                uint4 v;
-                v.x = s02[0];
-                v.y = s02[1];
-                v.z = s13[0];
-                v.w = s13[1];
-                *reinterpret_cast<uint4 *>(outp + (int64_t)p * a.Co) = v;
-            }
+            if (p < a.M) *reinterpret_cast<uint4 *>(outp + (int64_t)p * a.Co) = v;
         }
     }
 }

@@ -30,6 +30,7 @@
 // Restates shl_ref_depthwise_conv2d_quant (source/reference/convolution.c:416-460) + relu variants.
 #include <stdlib.h>
 
+#include "dw_mfma.h"
 #include "igemm_common.h"
 
 namespace shl {
@@ -62,13 +63,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_mfma_kernel(ConvArgs a, DwmG
     const int ix0 = ox0 * a.sw - a.pl, iy0 = oy0 * a.sh - a.pt;  // patch origin in the image
     const int nch = g.cb >> 4, nch_mask = nch - 1;               // 16-byte slots per pixel
     const int nch_shift = nch == 8 ? 3 : (nch == 4 ? 2 : 1);
-    // 16-byte slot swizzle of patch pixel (pr, pc).  A ds_read_b128 is served in groups of 16 lanes =
-    // 4 consecutive pixels of 4 consecutive tile rows; with 128-byte pixels the bank is (pixel parity,
-    // slot), so the 16 pixels need 16 different (pc & 1, slot) pairs: stride 1 takes bit 1 of the
-    // column and two bits of the row (conflict-free for even patch widths), stride 2 -- where the
-    // lanes' columns and rows are 2 apart -- two column bits and one row bit (2-way at best).
     const bool s2 = a.sw == 2;
-    auto swz = [&](int pr, int pc) { return s2 ? (((pc >> 1) & 3) | (((pr >> 1) & 1) << 2)) : (((pc >> 1) & 1) | ((pr & 3) << 1)); };
+    auto swz = [&](int pr, int pc) { return dw_patch_swizzle(s2, pr, pc); };  // slot swizzle (dw_mfma.h)
 
     // ---- patch -> LDS: piece k fills LDS bytes [k * 1024, +1024), lane = one 16-byte slot
     const char *img = static_cast<const char *>(a.in) + (int64_t)n * a.H * a.W * a.C + cblk * g.cb;
@@ -105,16 +101,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_mfma_kernel(ConvArgs a, DwmG
     const int ch0 = cblk * g.cb + cgl * 32;  // first channel of the group
     const uint32_t *wq = reinterpret_cast<const uint32_t *>(static_cast<const char *>(a.w) + (int64_t)(ch0 + row) * 12);
     const uint32_t wd[3] = {wq[0], wq[1], wq[2]};  // taps 0-3 | 4-7 | 8
-    // lane (row, half) holds k = 16 half .. +15 of matrix row `row`: one non-zero byte
-    const bool active = (row >> 4) == half;
-    const int mydw = (row & 15) >> 2, sh = 8 * (row & 3);
     v4i fa[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const uint32_t wb = active ? (__builtin_amdgcn_ubfe(wd[t >> 2], 8 * (t & 3), 8) << sh) : 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fa[t][k] = k == mydw ? (int)wb : 0;
-    }
+    dw_diag_fragments(wd, row, half, fa);  // one non-zero byte per lane (dw_mfma.h)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -155,21 +143,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_mfma_kernel(ConvArgs a, DwmG
             const float4 bi = *reinterpret_cast<const float4 *>(tab_l + 2 * tab_stride + q * 32);
             pk[q] = requant4_i8_t<EPI>(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], mu, bi, a);
         }
-        // lanes 0-31 hold channels {0-3, 8-11, 16-19, 24-27}, lanes 32-63 {4-7, 12-15, 20-23, 28-31} of
-        // their pixel; v_permlane32_swap(x, y) exchanges x[32..63] with y[0..31]:
-        //   swap(pk0, pk2): low lanes  pk0 = 0-3,   pk2 = 4-7   | high lanes pk0 = 16-19, pk2 = 20-23
-        //   swap(pk1, pk3): low lanes  pk1 = 8-11,  pk3 = 12-15 | high lanes pk1 = 24-27, pk3 = 28-31
-        const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-        const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+        const uint4 v = tile_channels_16(pk);  // 16 consecutive channels per lane (dw_mfma.h)
         const int oy = oy0 + py, ox = ox0 + px;
-        if (oy < a.Ho && ox < a.Wo) {
-            uint4 v;
-            v.x = s02[0];
-            v.y = s02[1];
-            v.z = s13[0];
-            v.w = s13[1];
-            *reinterpret_cast<uint4 *>(outp + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * a.C) = v;
-        }
+        if (oy < a.Ho && ox < a.Wo) *reinterpret_cast<uint4 *>(outp + (((int64_t)n * a.Ho + oy) * a.Wo + ox) * a.C) = v;
     }
 }
 

@@ -25,6 +25,7 @@
 // (source/reference/convolution.c:370-400, 416-460) incl. the relu variants (convolution_relu.c).
 #include <stdlib.h>
 
+#include "dw_mfma.h"
 #include "igemm_common.h"
 
 namespace shl {
@@ -161,18 +162,13 @@ __global__ __launch_bounds__(512) void pwdw_stream_kernel(PwDwStreamArgs f)
                 for (int g = 0; g < 4; ++g)
                     pk[g] = requant4_i8_rt(acc[t][4 * g] + ai[g].x, acc[t][4 * g + 1] + ai[g].y, acc[t][4 * g + 2] + ai[g].z,
                                            acc[t][4 * g + 3] + ai[g].w, mu[g], bi[g], q);
-                const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-                const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+                const uint4 own = tile_channels_16(pk);
                 const int j = (th + 2 * t) * 32 + row;
                 const int pr = (int)__umulhi((uint32_t)j, f.pw_magic);
                 const int pc = j - pr * f.pw_px;
                 const bool inside = (unsigned)(iy0 + pr) < (unsigned)d.H && (unsigned)(ix0 + pc) < (unsigned)d.W;
-                uint4 v;
-                v.x = inside ? s02[0] : zp4;
-                v.y = inside ? s02[1] : zp4;
-                v.z = inside ? s13[0] : zp4;
-                v.w = inside ? s13[1] : zp4;
-                const int sz = s2 ? (((pc >> 1) & 3) | (((pr >> 1) & 1) << 2)) : (((pc >> 1) & 1) | ((pr & 3) << 1));
+                const uint4 v = inside ? own : make_uint4(zp4, zp4, zp4, zp4);
+                const int sz = dw_patch_swizzle(s2, pr, pc);
                 if (j < f.npix) *reinterpret_cast<uint4 *>(patch + j * 128 + (((cgw * 2 + half) ^ sz) << 4)) = v;
             }
         }
@@ -180,15 +176,8 @@ __global__ __launch_bounds__(512) void pwdw_stream_kernel(PwDwStreamArgs f)
 
     // ---- phase 2: depthwise 3x3 on this wave's channel group (the patch of a group was written by two waves)
     __syncthreads();
-    const bool active = (row >> 4) == half;
-    const int mydw = (row & 15) >> 2, sh = 8 * (row & 3);
     v4i fa[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const uint32_t wb = active ? (__builtin_amdgcn_ubfe(wd[t >> 2], 8 * (t & 3), 8) << sh) : 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fa[t][k] = k == mydw ? (int)wb : 0;
-    }
+    dw_diag_fragments(wd, row, half, fa);
     const char *d_ai = tab + 1536 + (cgw * 32 + 4 * half) * 4, *d_mu = d_ai + 512, *d_bi = d_ai + 1024;
     const int lchunk = cgw * 2 + half;
     const bool s2 = d.sw == 2;
@@ -212,7 +201,7 @@ __global__ __launch_bounds__(512) void pwdw_stream_kernel(PwDwStreamArgs f)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int pr = py * d.sh + ky, pc = px * d.sw + kx;
-                const int sz = s2 ? (((pc >> 1) & 3) | (((pr >> 1) & 1) << 2)) : (((pc >> 1) & 1) | ((pr & 3) << 1));
+                const int sz = dw_patch_swizzle(s2, pr, pc);
                 fb[kx] = *reinterpret_cast<const v4i *>(patch + (pr * f.pw_px + pc) * 128 + ((lchunk ^ sz) << 4));
             }
 #pragma unroll
@@ -225,17 +214,9 @@ __global__ __launch_bounds__(512) void pwdw_stream_kernel(PwDwStreamArgs f)
             const float4 bi = *reinterpret_cast<const float4 *>(d_bi + g * 32);
             pk[g] = requant4_i8_rt(a2[4 * g], a2[4 * g + 1], a2[4 * g + 2], a2[4 * g + 3], mu, bi, d);
         }
-        const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-        const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+        const uint4 v = tile_channels_16(pk);
         const int oy = oy0 + py, ox = ox0 + px;
-        if (oy < d.Ho && ox < d.Wo) {
-            uint4 v;
-            v.x = s02[0];
-            v.y = s02[1];
-            v.z = s13[0];
-            v.w = s13[1];
-            *reinterpret_cast<uint4 *>(outp + (((int64_t)n * d.Ho + oy) * d.Wo + ox) * d.C) = v;
-        }
+        if (oy < d.Ho && ox < d.Wo) *reinterpret_cast<uint4 *>(outp + (((int64_t)n * d.Ho + oy) * d.Wo + ox) * d.C) = v;
     }
 }
 
