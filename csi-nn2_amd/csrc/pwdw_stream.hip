@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void pwdw_stream_kernel(PwDwStreamArgs f)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0;
 
     // ---- phase 1: pointwise GEMM over the K stages
-    const int aswz = (row >> 1) & (NCH - 1);  // (pixel >> 1) & mask with pixel = t * 32 + row: t * 16 drops out for NCH <= 8... see below
+    const int aswz = (row >> 1) & (NCH - 1);  // (pixel >> 1) & mask for pixel = tile * 32 + row (tile * 16 drops out: NCH <= 8)
     static_for<NKC>([&](auto kc_c) {
         constexpr int kc = decltype(kc_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
