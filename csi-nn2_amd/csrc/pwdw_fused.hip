@@ -136,6 +136,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
         }
     }
 
+    if (q.debug & 256) return;  // ablation (tools/pair_bench.py): stop after loads + MFMA
     // ---- partial sums -> LDS: part[((tile * ks + kpart) * 4 + group) * 64 + lane] = 4 channels
     v4i *part = reinterpret_cast<v4i *>(smem);
     uint32_t *patch = reinterpret_cast<uint32_t *>(smem + (size_t)f.mt * ks * 4096);  // [pixel][8 dwords]
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
         }
     }
     __syncthreads();
+    if (q.debug & 512) return;  // ablation: stop after the partial sums met in LDS
     // ---- finish the pointwise layer: group `wave` of every tile -> int8 patch in LDS
     for (int tile = wave >> 2; tile < f.mt; tile += nwaves >> 2) {
         v4i v = part[((tile * ks) * 4 + fgrp) * 64 + lane];
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     }
     __syncthreads();
 
+    if (q.debug & 1024) return;  // ablation: stop after the pointwise epilogue
     // ---- depthwise 3x3 on the slice's 32 channels, from the LDS patch (dw_patch.h)
     DwPatchGeom g;
     g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic;
@@ -179,7 +182,8 @@ static int waves_per_group()
 static int ks_for(int nsub, int nwaves)
 {
     const int ks = nsub >= 8 ? 4 : (nsub >= 4 ? 2 : 1);
-    return nwaves == 8 && nsub >= 16 ? 8 : ks;
+    static const char *k8 = getenv("SHL_MI355X_PWDW_KS8");  // A/B: 8-way K split with 8 waves
+    return nwaves == 8 && nsub >= 16 && k8 && k8[0] == '1' ? 8 : ks;
 }
 constexpr int PWDW_MTW = 4;  // tiles per wave the kernels are instantiated for
 

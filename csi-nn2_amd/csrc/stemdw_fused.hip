@@ -11,6 +11,9 @@
 //              pixel x 4 channels, byte transposes + v_dot4_i32_i8 against the dot4-packed weights)
 // Bit-identical to the two stand-alone launches.  Restates shl_ref_conv2d_quant followed by
 // shl_ref_depthwise_conv2d_quant (source/reference/convolution.c:370-400, 416-460) + relu variants.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "dw_patch.h"
 
 namespace shl {
@@ -120,6 +123,10 @@ static bool stemdw_geometry(const ConvArgs &q, const ConvArgs &d, StemDwArgs &f)
     if (d.pt < 0 || d.pl < 0 || d.pt > 2 || d.pl > 2) return false;
     f.bh = d.Ho < 2 ? d.Ho : 2;
     f.bw = d.Wo < 28 ? d.Wo : 28;
+    if (const char *e = getenv("SHL_MI355X_STEMDW_TILE")) {  // "<bh>x<bw>": tuning override
+        int h = 0, w = 0;
+        if (sscanf(e, "%dx%d", &h, &w) == 2 && h > 0 && w > 0) f.bh = h < d.Ho ? h : d.Ho, f.bw = w < d.Wo ? w : d.Wo;
+    }
     f.tiles_y = (d.Ho + f.bh - 1) / f.bh;
     f.tiles_x = (d.Wo + f.bw - 1) / f.bw;
     f.rw = (f.bw - 1) * d.sw + 3;
