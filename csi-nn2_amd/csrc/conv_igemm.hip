@@ -790,8 +790,8 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
     }
     // pointwise layers carry a fragment-ordered copy of the weights (conv_plan.hip): one coalesced 1 KiB
     // load per A fragment instead of 64 lines
-    const bool frag = a.w_frag != nullptr && (a.C & 63) == 0 && (a.Co & 31) == 0;
-    const char *wp = frag ? static_cast<const char *>(a.w_frag) + ((int64_t)tn * (a.C >> 5) + sub0) * 1024 + lane * 16
+    const bool frag = a.w_frag != nullptr && a.Kh * a.Kw == 1 && ((a.C * ESIZE) & 63) == 0 && (a.Co & 31) == 0;
+    const char *wp = frag ? static_cast<const char *>(a.w_frag) + ((int64_t)tn * ((a.C * ESIZE) >> 5) + sub0) * 1024 + lane * 16
                           : static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16 + (int64_t)sub0 * 32;
     const int wstep = frag ? 1024 : 32;
     KCursor kc;

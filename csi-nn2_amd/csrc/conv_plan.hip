@@ -233,14 +233,14 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     p->off_bias = p->off_mult + tab_bytes;
     p->off_pad = p->off_bias + tab_bytes;
     p->block_bytes = p->off_pad + PAD_PAGE_BYTES;
-    // pointwise int8 layers with K a multiple of 32: a second copy of the weights in fragment order
+    // pointwise layers whose K row is a multiple of 32 bytes: a second copy of the weights in fragment order
     // [32-channel group][K / 32][64 lanes][16 B] so that a wave fetches an A fragment with one coalesced
     // 1 KiB load (from [Cout][K] rows it is 64 lines per load instruction)
-    const bool frag_copy = algo == SHL_MI355X_ALGO_IGEMM && d.dtype == SHL_MI355X_I8 && d.kernel_h == 1 && d.kernel_w == 1 &&
-                           d.in_c % 32 == 0 && d.in_c <= 2048 && d.out_c % 32 == 0;
+    const bool frag_copy = algo == SHL_MI355X_ALGO_IGEMM && d.kernel_h == 1 && d.kernel_w == 1 &&
+                           (d.in_c * es) % 32 == 0 && d.in_c * es <= 4096 && d.out_c % 32 == 0;
     if (frag_copy) {
         p->off_wfrag = p->block_bytes;
-        p->block_bytes += (size_t)d.out_c * d.in_c;
+        p->block_bytes += (size_t)d.out_c * d.in_c * es;
     }
     p->inv_out_scale = 1.0f / d.out_scale;
     if (d.dtype == SHL_MI355X_I8) {
@@ -266,7 +266,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             if (frag_copy) {
                 char *dst = host.data() + p->off_wfrag;
                 for (int g = 0; g < d.out_c / 32; ++g)
-                    for (int sub = 0; sub < d.in_c / 32; ++sub)
+                    for (int sub = 0; sub < d.in_c * es / 32; ++sub)
                         for (int lane = 0; lane < 64; ++lane, dst += 16)
                             memcpy(dst, host.data() + p->off_w + (size_t)(g * 32 + (lane & 31)) * p->kstride + sub * 32 + (lane >> 5) * 16, 16);
             }

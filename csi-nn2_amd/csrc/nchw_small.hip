@@ -56,7 +56,11 @@ __global__ __launch_bounds__(1024) void conv1x1_nchw_kernel(ConvArgs a)
     const int sub0 = wave * per;
     int nsub = nsub_all - sub0 < per ? nsub_all - sub0 : per;
     if (nsub < 0) nsub = 0;
-    const char *wp = static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16 + (int64_t)sub0 * 32;
+    // A fragments from the plan's fragment-ordered copy when there is one (one coalesced 1 KiB load each)
+    const bool frag = a.w_frag != nullptr && (a.C * ESIZE) % 32 == 0 && a.kstride == a.C * ESIZE && (a.Co & 31) == 0;
+    const char *wp = frag ? static_cast<const char *>(a.w_frag) + ((int64_t)tn * nsub_all + sub0) * 1024 + lane * 16
+                          : static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16 + (int64_t)sub0 * 32;
+    const int wstep = frag ? 1024 : 32;
     // B: channel of element e of sub-step s for this lane = (s * 32 / ESIZE) + fhalf * KE + e
     const char *xin = static_cast<const char *>(a.in) + ((int64_t)n * a.C * HW + px) * ESIZE;
 
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(1024) void conv1x1_nchw_kernel(ConvArgs a)
 #pragma unroll
         for (int u = 0; u < WU; ++u) {
             if (s0 + u >= nsub) continue;
-            fa[u] = *reinterpret_cast<const v4i *>(wp + (s0 + u) * 32);
+            fa[u] = *reinterpret_cast<const v4i *>(wp + (s0 + u) * wstep);
             const int c_first = (sub0 + s0 + u) * (32 / ESIZE) + fhalf * KE;
             uint32_t packed[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -94,6 +98,194 @@ __global__ __launch_bounds__(1024) void conv1x1_nchw_kernel(ConvArgs a)
 #pragma unroll
         for (int u = 0; u < WU; ++u)
             if (s0 + u < nsub) acc = mfma<kI8>(fa[u], fb[u], acc);
+    }
+
+    // reduce-scatter: wave w owns register group w
+    v4i *slots = reinterpret_cast<v4i *>(red);
+    v4i part[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (kI8)
+                part[g][e] = acc[4 * g + e];
+            else
+                part[g][e] = __float_as_int(acc[4 * g + e]);
+        }
+    const int nsrc = nw - 1;  // pieces an owner receives
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        if (d != wave) slots[(d * nsrc + (wave < d ? wave : wave - 1)) * 64 + lane] = part[d];
+    __syncthreads();
+    if (wave >= 4) return;
+    v4i mine = wave == 0 ? part[0] : wave == 1 ? part[1] : wave == 2 ? part[2] : part[3];
+    int v_i[4];
+    float v_f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v_i[e] = mine[e];
+        v_f[e] = __int_as_float(mine[e]);
+    }
+    for (int src = 0; src < nsrc; ++src) {
+        const v4i other = slots[(wave * nsrc + src) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v_i[e] += other[e];
+            v_f[e] += __int_as_float(other[e]);
+        }
+    }
+    if (!live) return;
+    // NCHW store: channel cfin + e, pixel px -- 32 consecutive pixels per half-wave
+    const int a4[4] = {ai.x, ai.y, ai.z, ai.w};
+    const float m4[4] = {mu.x, mu.y, mu.z, mu.w};
+    const float b4[4] = {bi.x, bi.y, bi.z, bi.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = cfin + e;
+        if (c >= a.Co) break;
+        const int64_t o = ((int64_t)n * a.Co + c) * HW + px;
+        if constexpr (kI8)
+            static_cast<int8_t *>(a.out)[o] = (int8_t)requant_i8_fast(v_i[e] + a4[e], m4[e], b4[e], a);
+        else
+            static_cast<uint16_t *>(a.out)[o] = finish_f16(v_f[e], b4[e], a);
+    }
+}
+
+// The same tile with the B operand staged K-major in LDS and read back transposed: no per-element
+// gathers (14 of MobileNetV1's fp16 NCHW layers; see the header of the kernel body).
+template <bool kI8>
+__global__ __launch_bounds__(1024) void conv1x1_nchw_tr_kernel(ConvArgs a)
+{
+    constexpr int ESIZE = kI8 ? 1 : 2;
+    constexpr int KE = 16 / ESIZE;  // K elements per lane per MFMA sub-step (one 16-byte fragment)
+    __shared__ __attribute__((aligned(16))) int32_t red[4 * 15 * 64 * 4];  // [owner][source][lane] x 16 bytes
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;  // 4, 8 or 16 waves split K (deep K: the gathers are issue-bound per wave)
+    const int HW = a.H * a.W;
+    const int ptiles = (HW + 31) >> 5;  // pixel tiles per image
+    const int tn = blockIdx.x;          // output-channel tile
+    const int n = blockIdx.y / ptiles;  // image
+    const int p0 = (blockIdx.y - n * ptiles) << 5;
+    const int frow = lane & 31, fhalf = lane >> 5;
+
+    // finishing role: wave w < 4 requantises register group w (channels ch0 + 8w .. +3)
+    const int ch0 = tn * 32 + 4 * fhalf;
+    const int cfin = ch0 + 8 * (wave & 3);
+    const int4 ai = *reinterpret_cast<const int4 *>(a.acc_init + cfin);
+    const float4 mu = *reinterpret_cast<const float4 *>(a.mult + cfin);
+    const float4 bi = *reinterpret_cast<const float4 *>(a.bias + cfin);
+
+    int oc = tn * 32 + frow;
+    oc = oc < a.Co ? oc : a.Co - 1;
+    int px = p0 + frow;
+    const bool live = px < HW;
+    px = live ? px : HW - 1;
+    const int nsub_all = a.kstride / 32 * (kI8 ? 1 : 1);  // 32-byte K sub-steps of the packed rows
+    const int per = (nsub_all + nw - 1) / nw;
+    const int sub0 = wave * per;
+    int nsub = nsub_all - sub0 < per ? nsub_all - sub0 : per;
+    if (nsub < 0) nsub = 0;
+    // A fragments from the plan's fragment-ordered copy when there is one (one coalesced 1 KiB load each)
+    const bool frag = a.w_frag != nullptr && (a.C * ESIZE) % 32 == 0 && a.kstride == a.C * ESIZE && (a.Co & 31) == 0;
+    const char *wp = frag ? static_cast<const char *>(a.w_frag) + ((int64_t)tn * nsub_all + sub0) * 1024 + lane * 16
+                          : static_cast<const char *>(a.w) + (int64_t)oc * a.kstride + fhalf * 16 + (int64_t)sub0 * 32;
+    const int wstep = frag ? 1024 : 32;
+
+    using acc_t = typename AccT<kI8>::type;
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+
+    // ---- stage this wave's channels x 32 pixels K-major in LDS ([channel][32 pixels], rows of 32 * ESIZE
+    // bytes): every 16-byte piece is a coalesced run of pixels of one NCHW plane.  Wave-private region: no
+    // barrier, LDS operations of one wave complete in order.
+    extern __shared__ __attribute__((aligned(16))) char stage_all[];
+    constexpr int CH = 32 / ESIZE;     // channels per K sub-step
+    constexpr int ROWB = 32 * ESIZE;   // bytes per staged row
+    constexpr int NCHK = ROWB / 16;    // 16-byte pieces per row
+    constexpr int EPC = 16 / ESIZE;    // pixels per piece
+    char *stage = stage_all + wave * per * 1024;
+    const int c_first = sub0 * CH;
+    const char *plane0 = static_cast<const char *>(a.in) + (int64_t)n * a.C * HW * ESIZE;
+    for (int t0 = 0; t0 < nsub; t0 += 4) {
+        uint4 st[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            st[u] = make_uint4(0, 0, 0, 0);
+            if (t0 + u >= nsub) continue;
+            const int i = (t0 + u) * 64 + lane;  // piece index inside the wave's region
+            const int rowl = i / NCHK, chk = i % NCHK;
+            const int c = c_first + rowl;
+            const int pfirst = p0 + chk * EPC;
+            if (c >= a.C || pfirst >= HW) continue;  // K padding multiplies zeros; pixels past the image are not stored
+            const char *src = plane0 + ((int64_t)c * HW + pfirst) * ESIZE;
+            // a piece that runs over the end of its plane only picks up pixels that are never stored; what
+            // matters is that the 16 bytes stay inside the tensor
+            const int64_t tensor_bytes = (int64_t)a.N * a.C * HW * ESIZE;
+            const bool inside = ((int64_t)(n * a.C + c) * HW + pfirst) * ESIZE + 16 <= tensor_bytes;
+            if (inside) {
+                typedef uint4 __attribute__((aligned(1))) uint4_u;  // planes of odd sizes are not 16-byte aligned
+                st[u] = *reinterpret_cast<const uint4_u *>(src);
+            } else {  // the last pieces of the tensor: element by element
+                uint32_t w4[4] = {0, 0, 0, 0};
+                for (int e = 0; e < EPC && pfirst + e < HW; ++e) {
+                    if constexpr (kI8)
+                        w4[e >> 2] |= (uint32_t) * reinterpret_cast<const uint8_t *>(src + e) << (8 * (e & 3));
+                    else
+                        w4[e >> 1] |= (uint32_t) * reinterpret_cast<const uint16_t *>(src + 2 * e) << (16 * (e & 1));
+                }
+                st[u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + u < nsub) *reinterpret_cast<uint4 *>(stage + ((t0 + u) * 64 + lane) * 16) = st[u];
+    }
+    // ---- B fragments by transposing LDS reads (semantics measured with tools/probes/lds_tr_read.hip):
+    // one ds_read_b64_tr_* hands every lane of a 16-lane group 8 bytes = 4 (f16) / 8 (int8) consecutive
+    // CHANNELS of its pixel; two of them make the 16-byte fragment.  Lane addresses:
+    //   f16 : lane i of the group -> row k0 + (i >> 2), pixels 16 g + 4 (i & 3)       (four 4 x 4 matrices)
+    //   int8: even lane 2j -> row k0 + j, pixels 16 g; odd lane 2j + 1 -> row k0 + j, pixels 16 g + 8
+    const int li = lane & 15, gp = (lane >> 4) & 1;  // position in the group; which half of the 32 pixels
+    uint32_t tr_addr;
+    if constexpr (kI8)
+        tr_addr = (uint32_t)(uintptr_t)stage + (16 * fhalf + (li >> 1)) * ROWB + 16 * gp + 8 * (li & 1);
+    else
+        tr_addr = (uint32_t)(uintptr_t)stage + (8 * fhalf + (li >> 2)) * ROWB + (16 * gp + 4 * (li & 3)) * 2;
+    constexpr int WU = 4;  // sub-steps per group: one asm block issues its 8 transposing reads
+    for (int s0 = 0; s0 < nsub; s0 += WU) {
+        v4i fa[WU];
+#pragma unroll
+        for (int u = 0; u < WU; ++u)
+            if (s0 + u < nsub) fa[u] = *reinterpret_cast<const v4i *>(wp + (s0 + u) * wstep);
+        uint2 r[8];
+        // sub-step u starts CH rows = 1024 bytes further, the second half of a fragment 256 bytes
+        // (f16: 4 rows x 64 B, int8: 8 rows x 32 B) after the first
+        if constexpr (kI8)
+            asm volatile(
+                "ds_read_b64_tr_b8 %0, %8\n ds_read_b64_tr_b8 %1, %8 offset:256\n"
+                "ds_read_b64_tr_b8 %2, %8 offset:1024\n ds_read_b64_tr_b8 %3, %8 offset:1280\n"
+                "ds_read_b64_tr_b8 %4, %8 offset:2048\n ds_read_b64_tr_b8 %5, %8 offset:2304\n"
+                "ds_read_b64_tr_b8 %6, %8 offset:3072\n ds_read_b64_tr_b8 %7, %8 offset:3328\n s_waitcnt lgkmcnt(0)"
+                : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                : "v"(tr_addr + s0 * 1024)
+                : "memory");
+        else
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %8\n ds_read_b64_tr_b16 %1, %8 offset:256\n"
+                "ds_read_b64_tr_b16 %2, %8 offset:1024\n ds_read_b64_tr_b16 %3, %8 offset:1280\n"
+                "ds_read_b64_tr_b16 %4, %8 offset:2048\n ds_read_b64_tr_b16 %5, %8 offset:2304\n"
+                "ds_read_b64_tr_b16 %6, %8 offset:3072\n ds_read_b64_tr_b16 %7, %8 offset:3328\n s_waitcnt lgkmcnt(0)"
+                : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                : "v"(tr_addr + s0 * 1024)
+                : "memory");
+#pragma unroll
+        for (int u = 0; u < WU; ++u)
+            if (s0 + u < nsub) {
+                const v4i fb = {(int)r[2 * u].x, (int)r[2 * u].y, (int)r[2 * u + 1].x, (int)r[2 * u + 1].y};
+                acc = mfma<kI8>(fa[u], fb, acc);
+            }
     }
 
     // reduce-scatter: wave w owns register group w
@@ -205,6 +397,26 @@ int launch_conv1x1_nchw(const ConvArgs &a, int dtype, hipStream_t s)
     int threads = nsub >= 32 ? 1024 : (nsub >= 16 ? 512 : 256);
     if (env) threads = 64 * atoi(env);
     if (threads != 256 && threads != 512 && threads != 1024) threads = 256;
+    // B operand staged in LDS + transposing reads whenever the staging fits (K <= 1024 f16 / 2048 int8)
+    const int nw = threads / 64, per = (nsub + nw - 1) / nw;
+    const size_t lds = (size_t)nw * per * 1024;
+    static const char *tr_env = getenv("SHL_MI355X_NCHW_TR");  // "0": the gather kernel (A/B)
+    if (lds <= 64 * 1024 && !(tr_env && tr_env[0] == '0')) {
+        static bool opted[2] = {false, false};
+        const int ki = dtype == SHL_MI355X_I8 ? 0 : 1;
+        if (!opted[ki]) {
+            (void)hipFuncSetAttribute(ki == 0 ? reinterpret_cast<const void *>(conv1x1_nchw_tr_kernel<true>)
+                                              : reinterpret_cast<const void *>(conv1x1_nchw_tr_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            opted[ki] = true;
+        }
+        if (dtype == SHL_MI355X_I8)
+            hipLaunchKernelGGL((conv1x1_nchw_tr_kernel<true>), grid, dim3(threads), lds, s, a);
+        else
+            hipLaunchKernelGGL((conv1x1_nchw_tr_kernel<false>), grid, dim3(threads), lds, s, a);
+        SHL_HIP(hipGetLastError());
+        return SHL_MI355X_OK;
+    }
     if (dtype == SHL_MI355X_I8)
         hipLaunchKernelGGL((conv1x1_nchw_kernel<true>), grid, dim3(threads), 0, s, a);
     else
