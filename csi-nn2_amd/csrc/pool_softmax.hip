@@ -13,8 +13,11 @@
 //   softmax           shl_ref_softmax_f32 (softmax.c:21-66): max over the axis, then
 //                     acc(float) += exp(double(x - max)) in index order, then
 //                     float(exp(double(x - max)) / acc).  One block per (outer, inner) row: the
-//                     max and the exponentials are computed in parallel (order-independent), the
-//                     float accumulation is replayed sequentially by one lane from LDS.
+//                     max and the exponentials are computed in parallel (order-independent); the
+//                     float running sum is reproduced EXACTLY by a wave-parallel scan (see
+//                     running_sum_exact below).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace shl {
@@ -88,10 +91,75 @@ __global__ __launch_bounds__(256) void global_avgpool_nhwc_i8_kernel(const void 
     static_cast<uint32_t *>(out)[i] = pack4_i8(q[0], q[1], q[2], q[3]);
 }
 
+// The reference's running sum  acc = (float)((double)acc + e[j]),  j = 0 .. cnt-1  (softmax.c:21-66) is a
+// chain of three dependent double-precision instructions per element: ~15 us for 1 000 classes on one lane.
+// It is nevertheless NOT inherently sequential.  While acc stays inside one binade [2^E, 2^(E+1)) it is
+// m * u with u = 2^(E-23) and an integer m in [2^23, 2^24), and one step is
+//     d    = RN_double(m u + e)         the sum stays in the binade, where doubles are spaced u * 2^-29:
+//                                       d / u = m + t'  with  t' = RN_{2^-29}(e / u)  -- m is an integer, so
+//                                       t' (ties included: m * 2^29 is even) does not depend on m
+//     acc' = RN_float(d) = (m + rint(t')) u            unless t' is exactly half-way (then m's parity decides)
+// so the integer increments k_j = rint(t'_j) of a whole block of elements are independent of each other and
+// the block advances by their prefix sum.  A wave evaluates 64 elements per round (t' = ((2^E + e) - 2^E) / u
+// in double arithmetic, exact), scans the increments and stops at the first element that either is a tie
+// or would carry acc out of the binade (m + prefix >= 2^24, conservatively); that element takes the literal
+// step and the next round starts from the new acc (and binade).  Bit-identical to the literal loop --
+// tests/test_tail.py compares the two forms on adversarial rows.
+__device__ __forceinline__ float running_sum_exact(const double *e, int cnt, int lane)
+{
+    float acc = 0.f;  // wave-uniform
+    int j = 0;
+    while (j < cnt) {
+        if (!(acc >= 1.17549435e-38f)) {  // zero or subnormal: literal step
+            acc = (float)((double)acc + e[j]);
+            ++j;
+            continue;
+        }
+        int ex;
+        (void)__builtin_frexpf(acc, &ex);  // acc = f * 2^ex, f in [0.5, 1)  ->  E = ex - 1
+        const int E = ex - 1;
+        const double base = __builtin_ldexp(1.0, E), inv_u = __builtin_ldexp(1.0, 23 - E);
+        const uint32_t m = (uint32_t)((double)acc * inv_u);  // exact
+        const int idx = j + lane;
+        const bool valid = idx < cnt;
+        const double ev = valid ? e[idx] : 0.0;
+        const double tp = ((base + ev) - base) * inv_u;  // t'
+        const bool big = !(tp < 8388608.0);              // >= 2^23: leaves the binade for sure
+        const double fl = __builtin_floor(tp);
+        const bool tie = (tp - fl) == 0.5;
+        uint32_t p = big ? 0x01000000u : (uint32_t)__builtin_rint(tp);  // this lane's increment
+        // inclusive prefix sum over the wave (increments <= 2^24 each: no overflow in 32 bits), on DPP:
+        // row_shr 1, 2, 4, 8 scan the 16-lane rows, row_bcast15 / row_bcast31 carry the row totals
+        // (six VALU instructions instead of six LDS-crossbar shuffles)
+        p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x111, 0xf, 0xf, true);
+        p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x112, 0xf, 0xf, true);
+        p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x114, 0xf, 0xf, true);
+        p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x118, 0xf, 0xf, true);
+        p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x142, 0xa, 0xf, false);
+        p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x143, 0xc, 0xf, false);
+        const bool stop = valid && (tie || big || m + p >= 0x01000000u);
+        const unsigned long long mask = __ballot(stop);
+        int nvalid = cnt - j;
+        nvalid = nvalid < 64 ? nvalid : 64;
+        int c = mask ? __builtin_ctzll(mask) : 64;
+        c = c < nvalid ? c : nvalid;
+        if (c > 0) {
+            const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)p, c - 1);  // c is wave-uniform
+            acc = (float)((double)(m + pc) * __builtin_ldexp(1.0, E - 23));  // exact: m + pc < 2^24
+            j += c;
+        }
+        if (c < nvalid) {  // the stopping element: literal step (may change the binade)
+            acc = (float)((double)acc + e[j]);
+            ++j;
+        }
+    }
+    return acc;
+}
+
 constexpr int SOFTMAX_MAX_CNT = 8192;  // doubles parked in LDS: 64 KiB
 
 __global__ __launch_bounds__(256) void softmax_kernel(const void *in, void *out, int dtype, int cnt,
-                                                      int64_t inner, float si, float zi, float so, float zo)
+                                                      int64_t inner, float si, float zi, float so, float zo, int seq_sum)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *e = reinterpret_cast<double *>(smem);          // [cnt]
@@ -103,29 +171,41 @@ __global__ __launch_bounds__(256) void softmax_kernel(const void *in, void *out,
     // max (fmax over floats: exact whatever the order)
     float m = -3.402823466e+38f;
     for (int j = tid; j < cnt; j += 256) m = fmaxf(m, load_dequant(in, base + j * inner, dtype, si, zi));
-    red[tid] = m;
+    // wave maximum on DPP (inclusive max-scan, lane 63 holds the result), then one LDS hand-over of the four
+    // wave results instead of an eight-barrier tree
+#define SHL_MAX_DPP(CTRL, ROWS) \
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), CTRL, ROWS, 0xf, false)))
+    SHL_MAX_DPP(0x111, 0xf);
+    SHL_MAX_DPP(0x112, 0xf);
+    SHL_MAX_DPP(0x114, 0xf);
+    SHL_MAX_DPP(0x118, 0xf);
+    SHL_MAX_DPP(0x142, 0xa);
+    SHL_MAX_DPP(0x143, 0xc);
+#undef SHL_MAX_DPP
+    if ((tid & 63) == 63) red[tid >> 6] = m;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
-        __syncthreads();
-    }
-    m = red[0];
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     for (int j = tid; j < cnt; j += 256)
         e[j] = exp((double)__fsub_rn(load_dequant(in, base + j * inner, dtype, si, zi), m));
     __syncthreads();
-    if (tid == 0) {
-        float acc = 0.f;  // `acc_exp += exp(...)`: double add, rounded to float every step
-        int j = 0;
-        for (; j + 8 <= cnt; j += 8) {  // eight LDS reads in flight, then the dependent chain
-            double b[8];
+    if (seq_sum) {
+        if (tid == 0) {
+            float acc = 0.f;  // `acc_exp += exp(...)`: double add, rounded to float every step
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) {  // eight LDS reads in flight, then the dependent chain
+                double b[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) b[k] = e[j + k];
+                for (int k = 0; k < 8; ++k) b[k] = e[j + k];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc = (float)((double)acc + b[k]);
+                for (int k = 0; k < 8; ++k) acc = (float)((double)acc + b[k]);
+            }
+            for (; j < cnt; ++j) acc = (float)((double)acc + e[j]);
+            red[0] = acc;
         }
-        for (; j < cnt; ++j) acc = (float)((double)acc + e[j]);
-        red[0] = acc;
+    } else if (tid < 64) {
+        const float acc = running_sum_exact(e, cnt, tid);
+        if (tid == 0) red[0] = acc;
     }
     __syncthreads();
     const double acc = (double)red[0];
@@ -187,8 +267,10 @@ extern "C" int shl_mi355x_softmax(const void *input_dev, void *output_dev, int32
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         opted_in = true;
     }
+    static const char *seq_env = getenv("SHL_MI355X_SOFTMAX_SEQ");  // "1": the literal one-lane running sum (A/B, tests)
     hipLaunchKernelGGL(shl::softmax_kernel, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, input_dev,
-                       output_dev, (int)dtype, (int)count, inner, in_scale, (float)in_zp, out_scale, (float)out_zp);
+                       output_dev, (int)dtype, (int)count, inner, in_scale, (float)in_zp, out_scale, (float)out_zp,
+                       seq_env && seq_env[0] == '1' ? 1 : 0);
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }
