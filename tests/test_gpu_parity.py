@@ -88,6 +88,9 @@ SHAPES = [
     dict(c=3, co=24, h=9, w=9, pad=(0, 2, 1, 0), n=2), dict(c=3, co=40, h=12, w=12, dilation=(2, 2), pad=(2, 2, 2, 2), act=2),
     # split-K wave kernel edges: K not divisible by 4 sub-step groups, tiny M
     dict(c=1024, co=96, k=(1, 1), pad=(0, 0, 0, 0), h=5, w=5), dict(c=256, co=16, h=6, w=6), dict(c=2048, co=40, k=(1, 1), pad=(0, 0, 0, 0), h=4, w=4), dict(c=208, co=64, h=6, w=6), dict(c=144, co=32, k=(1, 1), pad=(0, 0, 0, 0), h=3, w=3),
+    # NCHW pointwise at latency-bound sizes (transposing LDS reads): odd planes, ragged tiles, deep K over 8 / 16 waves
+    dict(layout=NCHW, c=64, co=64, k=(1, 1), pad=(0, 0, 0, 0), h=7, w=7, n=2), dict(layout=NCHW, c=512, co=64, k=(1, 1), pad=(0, 0, 0, 0), h=14, w=14, act=1),
+    dict(layout=NCHW, c=1024, co=32, k=(1, 1), pad=(0, 0, 0, 0), h=7, w=7), dict(layout=NCHW, c=48, co=40, k=(1, 1), pad=(0, 0, 0, 0), h=5, w=9),
 ]
 
 
@@ -108,6 +111,12 @@ F16_SHAPES = [
     dict(c=40, co=24, k=(1, 1), pad=(0, 0, 0, 0)), dict(layout=NCHW, c=16, co=16), dict(depthwise=True, c=32),
     dict(depthwise=True, layout=NCHW, c=8), dict(depthwise=True, c=64, act=1, stride=(2, 2)), dict(fc=True, n=4, c=128, co=40),
     dict(c=256, co=64, h=7, w=7, act=2), dict(c=1024, co=32, k=(1, 1), pad=(0, 0, 0, 0), h=4, w=4),
+    # the binary16 NCHW stem kernel (conv_direct.hip: conv_stem_f16_nchw_kernel): 3 input channels, 3x3
+    dict(layout=NCHW, c=3, co=32, h=15, w=17, stride=(2, 2), n=2, act=1), dict(layout=NCHW, c=3, co=20, h=9, w=9),
+    dict(layout=NCHW, c=3, co=64, h=12, w=12, pad=(0, 0, 1, 1), stride=(2, 2)), dict(layout=NCHW, c=3, co=8, h=5, w=5, dilation=(2, 2), pad=(2, 2, 2, 2)),
+    # NCHW pointwise through the transposing-LDS-read kernel: odd plane sizes (misaligned planes), ragged tiles
+    dict(layout=NCHW, c=64, co=64, k=(1, 1), pad=(0, 0, 0, 0), h=7, w=7, n=2), dict(layout=NCHW, c=512, co=32, k=(1, 1), pad=(0, 0, 0, 0), h=14, w=14),
+    dict(layout=NCHW, c=48, co=40, k=(1, 1), pad=(0, 0, 0, 0), h=5, w=9, act=1),
 ]
 
 
