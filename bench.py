@@ -78,7 +78,7 @@ def cpu_baseline_worker(args):
     kind = "reference" if cases.have_reference() else "port"
     cores = 1
     if kind == "reference":
-        fe = pkg.load_frontend("reference")
+        fe = cases.load_reference_frontend()
     else:
         cores = cases.oracle_lib().oracle_num_threads()
     budget = args.cpu_seconds

@@ -145,10 +145,6 @@ def lib_path(name):
     return os.path.join(LIB_DIR, name)
 
 
-def reference_lib_path():
-    return os.path.join(ROOT, "oracle", "_ref", "libshl_ref_x86.so")
-
-
 _loaded = {}
 
 
@@ -248,17 +244,18 @@ _CONV_OPS = ["csinn_conv2d", "csinn_conv2d_relu", "csinn_conv2d_relu6", "csinn_d
              "csinn_depthwise_conv2d_relu", "csinn_fullyconnected"] + list(_SISO_OPS)
 
 
-def load_frontend(kind="standalone", local=False):
-    """kind: 'standalone' (this repo's libcsinn_nn2.so) or 'reference' (oracle/_ref genuine lib;
-    test infrastructure only).  local=True keeps the library's symbols out of the global scope
-    (needed when both front-ends live in one process: the backend library binds its front-end
-    symbols to whichever was loaded globally first)."""
+def load_frontend(kind="standalone", local=False, path=None):
+    """The csinn_* front-end the backend plugs into: this repo's libcsinn_nn2.so ('standalone'), or --
+    with `path` -- any library exporting the CSI-NN2 C API (INTEGRATION.md option A: the user's own
+    libshl with the backend loaded next to it).  local=True keeps the library's symbols out of the
+    global scope (needed when two front-ends live in one process: the backend library binds its
+    front-end symbols to whichever was loaded globally first)."""
     mode = C.RTLD_LOCAL if local else C.RTLD_GLOBAL
-    if kind == "standalone":
+    if path is not None:
+        lib = _cdll(path, mode)
+        kind = "external"
+    elif kind == "standalone":
         lib = _cdll(lib_path("libcsinn_nn2.so"), mode)
-    elif kind == "reference":
-        C.CDLL("libgomp.so.1", mode=C.RTLD_GLOBAL)
-        lib = _cdll(reference_lib_path(), mode)
     else:
         raise ValueError(kind)
     if getattr(lib, "_typed", False):
@@ -300,6 +297,8 @@ def load_backend(frontend):
         opt.shl_mi355x_session_fused_pairs.argtypes = [C.POINTER(Session)]
         opt.shl_mi355x_session_stream.argtypes = [C.POINTER(Session)]
         opt.shl_mi355x_session_stream.restype = C.c_void_p
+        opt.shl_mi355x_session_set_stream.argtypes = [C.POINTER(Session), C.c_void_p]
+        opt.shl_mi355x_session_set_stream.restype = None
         opt._typed = True
     # the dispatch tables exist after the first csinn_alloc_session (source/nn2/setup.c:77-84)
     s = frontend.csinn_alloc_session()

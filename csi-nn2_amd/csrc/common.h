@@ -261,9 +261,20 @@ __device__ __forceinline__ uint16_t float_to_f16_bits_ref(float x)
 __device__ __forceinline__ uint16_t finish_f16(float acc, float bias_f, const ConvArgs &a)
 {
     float f = __fadd_rn(acc, bias_f);
-    if (a.scale_out) f = __fmul_rn(f, a.inv_out_scale);
+    if (a.scale_out) {
+        // float_to_f16 with qinfo->scale != 1 (source/nn2/utils.c:1191-1205): "*= 1 / scale", then narrow;
+        // a fused relu / relu6 is shl_ref_relu(6)_quant on the STORED tensor (convolution_relu.c:34-45,
+        // relu6.c:21-43): widen, "*= scale", clamp, "*= 1 / scale", narrow -- the clamp acts on the
+        // dequantised value, i.e. at 6 / scale in the stored domain, after one extra f16 rounding
+        f = __fmul_rn(f, a.inv_out_scale);
+        if (a.act == SHL_MI355X_ACT_NONE) return float_to_f16_bits_ref(f);
+        float x = __fmul_rn(f16_bits_to_float(float_to_f16_bits_ref(f)), a.out_scale);
+        x = x > 0.0f ? x : 0.0f;
+        if (a.act == SHL_MI355X_ACT_RELU6) x = fminf(x, 6.0f);
+        return float_to_f16_bits_ref(__fmul_rn(x, a.inv_out_scale));
+    }
     if (a.act != SHL_MI355X_ACT_NONE) {
-        // relu after rounding == rounding after relu (monotone, sign-preserving, 6.0 exact)
+        // scale == 1: relu after rounding == rounding after relu (monotone, sign-preserving, 6.0 exact)
         f = f > 0.0f ? f : 0.0f;
         if (a.act == SHL_MI355X_ACT_RELU6) f = fminf(f, 6.0f);
     }

@@ -17,6 +17,7 @@
  * callback logs it through shl_debug_error and returns CSINN_FALSE.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "mi355x_internal.h"
@@ -121,13 +122,26 @@ static int build_tables(const struct shl_mi355x_conv_desc *d, struct csinn_tenso
     return CSINN_TRUE;
 }
 
-static int create_plan(void *params_key, struct shl_mi355x_conv_desc *d, struct csinn_tensor *input,
+static int create_plan(struct csinn_session *sess, struct shl_mi355x_conv_desc *d, struct csinn_tensor *input,
                        struct csinn_tensor *output, struct csinn_tensor *kernel,
-                       struct csinn_tensor *bias, int fuse_zp2bias)
+                       struct csinn_tensor *bias, int fuse_zp2bias, shl_mi355x_conv_plan **plan_out)
 {
+    *plan_out = NULL;
     if (kernel->data == NULL || kernel->mtype == CSINN_MEM_TYPE_DMABUF) {
         shl_debug_error("mi355x: the kernel tensor must be host resident at init time\n");
         return CSINN_FALSE;
+    }
+    if (input->qinfo == NULL || output->qinfo == NULL || kernel->qinfo == NULL) {
+        shl_debug_error("mi355x: convolution tensors need quantisation records\n");
+        return CSINN_FALSE;
+    }
+    if (input->quant_channel > 1 || output->quant_channel > 1) {
+        /* csinn_tensor_data_convert honours per-channel records on activations
+         * (source/nn2/utils.c:1504-1642); the device path carries ONE record per activation tensor:
+         * refuse rather than compute with record 0 */
+        shl_debug_error("mi355x: per-channel quantised activations (%d / %d records) are not supported\n",
+                        input->quant_channel, output->quant_channel);
+        return CSINN_UNSUPPORT_DTYPE;
     }
     if (d->dtype == SHL_MI355X_I8) {
         d->in_zp = input->qinfo->zero_point;
@@ -140,14 +154,11 @@ static int create_plan(void *params_key, struct shl_mi355x_conv_desc *d, struct 
     const int dw_last = d->group > 1 && d->layout == SHL_MI355X_NHWC;
     int rc = build_tables(d, input, kernel, bias, fuse_zp2bias, dw_last, mult, bias_f);
     if (rc == CSINN_TRUE) {
-        shl_mi355x_conv_plan *plan = NULL;
-        int st = shl_mi355x_conv_plan_create(d, kernel->data, mult, bias_f, shl_mi355x_get_stream(),
-                                             &plan);
+        int st = shl_mi355x_conv_plan_create(d, kernel->data, mult, bias_f,
+                                             shl_mi355x_ctx_stream(shl_mi355x_ctx_of(sess)), plan_out);
         if (st != SHL_MI355X_OK) {
             shl_debug_error("mi355x: plan creation failed (%d): %s\n", st, shl_mi355x_last_error());
             rc = st == SHL_MI355X_ENOTSUP ? CSINN_UNSUPPORT_LAYOUT : CSINN_FALSE;
-        } else {
-            shl_mi355x_registry_put(params_key, plan);
         }
     }
     shl_mem_free(mult);
@@ -164,9 +175,8 @@ static int create_plan(void *params_key, struct shl_mi355x_conv_desc *d, struct 
  *        and writes block i * (N*Ho*Wo*Cout/g) -- i.e. the buffers are treated as G consecutive
  *        NHWC tensors, NOT as channel-interleaved groups.  Restated literally: identical results
  *        are the contract.
- * One device plan per group (key: params + 1 + i); slices start at arbitrary byte offsets, so the
- * plans use the alignment-free direct kernel. */
-static void *group_key(void *params, int i) { return (char *)params + 1 + i; }
+ * One device plan per group (kept together under the layer's params block); slices start at arbitrary
+ * byte offsets, so the plans use the alignment-free direct kernel. */
 
 static int group_conv_init(struct shl_mi355x_conv_desc *d, struct csinn_tensor *input,
                            struct csinn_tensor *output, struct csinn_tensor *kernel,
@@ -186,6 +196,8 @@ static int group_conv_init(struct shl_mi355x_conv_desc *d, struct csinn_tensor *
     const int es = d->dtype == SHL_MI355X_I8 ? 1 : 2;
     const int64_t ksz = (int64_t)sub.out_c * sub.in_c * d->kernel_h * d->kernel_w; /* elements per group */
     const int has_bias = bias != NULL && bias->dim_count != 0 && bias->data != NULL;
+    shl_mi355x_conv_plan **plans = calloc((size_t)G, sizeof(*plans));
+    if (plans == NULL) return CSINN_FALSE;
     for (int i = 0; i < G; i++) {
         struct csinn_tensor k = *kernel, b;
         k.data = (char *)kernel->data + i * ksz * es;
@@ -203,10 +215,15 @@ static int group_conv_init(struct shl_mi355x_conv_desc *d, struct csinn_tensor *
                 b.quant_channel = sub.out_c;
             }
         }
-        int rc = create_plan(group_key(params, i), &sub, input, output, &k, has_bias ? &b : bias,
-                             params->conv_extra.fuse_zp2bias);
-        if (rc != CSINN_TRUE) return rc;
+        int rc = create_plan(params->base.sess, &sub, input, output, &k, has_bias ? &b : bias,
+                             params->conv_extra.fuse_zp2bias, &plans[i]);
+        if (rc != CSINN_TRUE) {
+            for (int j = 0; j < i; j++) shl_mi355x_conv_plan_destroy(plans[j]);
+            free(plans);
+            return rc;
+        }
     }
+    shl_mi355x_registry_put_group(params, plans, G);
     params->base.cb->exec = shl_mi355x_group_conv2d_exec;
     return CSINN_TRUE;
 }
@@ -222,14 +239,15 @@ int shl_mi355x_group_conv2d_exec(CSINN_CONV_ARGS)
     const int64_t in_all = csinn_tensor_size(input), out_all = csinn_tensor_size(output);
     const int64_t isz = nhwc ? in_all / G : in_all / ((int64_t)N * G);  /* elements per slice */
     const int64_t osz = nhwc ? out_all / G : out_all / ((int64_t)N * G);
-    void *stream = shl_mi355x_get_stream();
-    const char *in_dev = shl_mi355x_stage_in(input, 0);
-    char *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    struct shl_mi355x_ctx *ctx = shl_mi355x_ctx_of(params->base.sess);
+    void *stream = shl_mi355x_ctx_stream(ctx);
+    const char *in_dev = shl_mi355x_stage_in(ctx, input, 0);
+    char *out_dev = shl_mi355x_stage_out_begin(ctx, output, 1);
     if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
     const int images = nhwc ? 1 : N;
     for (int j = 0; j < images; j++)
         for (int i = 0; i < G; i++) {
-            shl_mi355x_conv_plan *plan = shl_mi355x_registry_get(group_key(params, i));
+            shl_mi355x_conv_plan *plan = shl_mi355x_registry_get_group(params, i);
             if (plan == NULL) {
                 shl_debug_error("mi355x: group_conv2d called without a successful init\n");
                 return CSINN_FALSE;
@@ -242,7 +260,7 @@ int shl_mi355x_group_conv2d_exec(CSINN_CONV_ARGS)
                 return CSINN_FALSE;
             }
         }
-    return shl_mi355x_stage_out_end(output, out_dev);
+    return shl_mi355x_stage_out_end(ctx, output, out_dev);
 }
 
 /* ------------------------------------------------------------------------ conv2d family */
@@ -283,9 +301,16 @@ static int conv_init_common(struct csinn_tensor *input, struct csinn_tensor *out
     d.dilation_w = params->dilation_width > 0 ? params->dilation_width : 1;
     d.group = params->group > 0 ? params->group : 1;
 
-    if (d.group > 1 && d.group != d.in_c) return group_conv_init(&d, input, output, kernel, bias, params);
-    int rc = create_plan(params, &d, input, output, kernel, bias, params->conv_extra.fuse_zp2bias);
+    /* depthwise = group == Cin AND a kernel with one input channel per filter ([1,Kh,Kw,O] / [O,1,Kh,Kw]),
+     * the front-end's own rule (source/nn2/convolution.c:36-47).  group == Cin with any other kernel
+     * shape is a grouped convolution with the reference's slice semantics. */
+    const int k_in = kernel->dim[nhwc ? 0 : 1];
+    const int depthwise = d.group > 1 && d.group == d.in_c && k_in == 1;
+    if (d.group > 1 && !depthwise) return group_conv_init(&d, input, output, kernel, bias, params);
+    shl_mi355x_conv_plan *plan = NULL;
+    int rc = create_plan(params->base.sess, &d, input, output, kernel, bias, params->conv_extra.fuse_zp2bias, &plan);
     if (rc != CSINN_TRUE) return rc;
+    shl_mi355x_registry_put(params, plan);
     /* the way every optimised backend of the reference selects its kernel */
     params->base.cb->exec = shl_mi355x_conv2d_exec;
     return CSINN_TRUE;
@@ -304,31 +329,32 @@ int shl_mi355x_conv2d_relu6_init(CSINN_CONV_ARGS)
     return conv_init_common(input, output, kernel, bias, params, SHL_MI355X_ACT_RELU6);
 }
 
-static int run_plan(void *params_key, struct csinn_tensor *input, struct csinn_tensor *output,
+static int run_plan(struct csinn_params_base *base, struct csinn_tensor *input, struct csinn_tensor *output,
                     int batch, const char *what)
 {
-    shl_mi355x_conv_plan *plan = shl_mi355x_registry_get(params_key);
+    shl_mi355x_conv_plan *plan = shl_mi355x_registry_get(base);
     if (plan == NULL) {
         shl_debug_error("mi355x: %s called without a successful init\n", what);
         return CSINN_FALSE;
     }
-    void *stream = shl_mi355x_get_stream();
-    const void *in_dev = shl_mi355x_stage_in(input, 0);
-    void *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    struct shl_mi355x_ctx *ctx = shl_mi355x_ctx_of(base->sess);
+    void *stream = shl_mi355x_ctx_stream(ctx);
+    const void *in_dev = shl_mi355x_stage_in(ctx, input, 0);
+    void *out_dev = shl_mi355x_stage_out_begin(ctx, output, 1);
     if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
     int st = shl_mi355x_conv_forward(plan, in_dev, out_dev, batch, stream);
     if (st != SHL_MI355X_OK) {
         shl_debug_error("mi355x: %s launch failed (%d): %s\n", what, st, shl_mi355x_last_error());
         return CSINN_FALSE;
     }
-    return shl_mi355x_stage_out_end(output, out_dev);
+    return shl_mi355x_stage_out_end(ctx, output, out_dev);
 }
 
 int shl_mi355x_conv2d_exec(CSINN_CONV_ARGS)
 {
     (void)kernel;
     (void)bias;
-    return run_plan(params, input, output, input->dim[0], "conv2d");
+    return run_plan(&params->base, input, output, input->dim[0], "conv2d");
 }
 
 /* ------------------------------------------------------------------------ fullyconnected
@@ -358,8 +384,10 @@ int shl_mi355x_fullyconnected_init(struct csinn_tensor *input, struct csinn_tens
     d.group = 1;
     d.out_c = weights->dim[weights->dim_count - 2];
     d.in_c = weights->dim[weights->dim_count - 1];
-    int rc = create_plan(params, &d, input, output, weights, bias, params->fc_extra.fuse_zp2bias);
+    shl_mi355x_conv_plan *plan = NULL;
+    int rc = create_plan(params->base.sess, &d, input, output, weights, bias, params->fc_extra.fuse_zp2bias, &plan);
     if (rc != CSINN_TRUE) return rc;
+    shl_mi355x_registry_put(params, plan);
     params->base.cb->exec = shl_mi355x_fullyconnected_exec;
     return CSINN_TRUE;
 }
@@ -372,12 +400,12 @@ int shl_mi355x_fullyconnected_exec(struct csinn_tensor *input, struct csinn_tens
     (void)bias;
     int batches = 1;
     for (int i = 0; i < output->dim_count - 1; i++) batches *= output->dim[i];
-    return run_plan(params, input, output, batches, "fullyconnected");
+    return run_plan(&params->base, input, output, batches, "fullyconnected");
 }
 
 /* ------------------------------------------------------------------------ relu / relu6 */
 
-static int relu_common(struct csinn_tensor *input, struct csinn_tensor *output, int relu6)
+static int relu_common(struct csinn_tensor *input, struct csinn_tensor *output, struct csinn_relu_params *params, int relu6)
 {
     const int i8 = input->dtype == CSINN_DTYPE_INT8 && output->dtype == CSINN_DTYPE_INT8;
     const int f16 = input->dtype == CSINN_DTYPE_FLOAT16 && output->dtype == CSINN_DTYPE_FLOAT16;
@@ -389,33 +417,36 @@ static int relu_common(struct csinn_tensor *input, struct csinn_tensor *output, 
         shl_debug_error("mi355x: fp16 relu with qinfo scale != 1 is not supported\n");
         return CSINN_FALSE;
     }
-    const void *in_dev = shl_mi355x_stage_in(input, 0);
-    void *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    if (input->qinfo == NULL || output->qinfo == NULL || input->quant_channel > 1 || output->quant_channel > 1) {
+        shl_debug_error("mi355x: relu needs one quantisation record per tensor\n");
+        return CSINN_UNSUPPORT_DTYPE;
+    }
+    struct shl_mi355x_ctx *ctx = shl_mi355x_ctx_of(params->base.sess);
+    const void *in_dev = shl_mi355x_stage_in(ctx, input, 0);
+    void *out_dev = shl_mi355x_stage_out_begin(ctx, output, 1);
     if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
     int st;
     if (i8)
         st = shl_mi355x_relu_i8(in_dev, out_dev, (size_t)csinn_tensor_size(input), input->qinfo->scale,
                                 input->qinfo->zero_point, output->qinfo->scale, output->qinfo->zero_point, relu6,
-                                shl_mi355x_get_stream());
+                                shl_mi355x_ctx_stream(ctx));
     else
-        st = shl_mi355x_relu_f16(in_dev, out_dev, (size_t)csinn_tensor_size(input), relu6, shl_mi355x_get_stream());
+        st = shl_mi355x_relu_f16(in_dev, out_dev, (size_t)csinn_tensor_size(input), relu6, shl_mi355x_ctx_stream(ctx));
     if (st != SHL_MI355X_OK) {
         shl_debug_error("mi355x: relu launch failed (%d): %s\n", st, shl_mi355x_last_error());
         return CSINN_FALSE;
     }
-    return shl_mi355x_stage_out_end(output, out_dev);
+    return shl_mi355x_stage_out_end(ctx, output, out_dev);
 }
 
 int shl_mi355x_relu_exec(struct csinn_tensor *input, struct csinn_tensor *output,
                          struct csinn_relu_params *params)
 {
-    (void)params;
-    return relu_common(input, output, 0);
+    return relu_common(input, output, params, 0);
 }
 
 int shl_mi355x_relu6_exec(struct csinn_tensor *input, struct csinn_tensor *output,
                           struct csinn_relu_params *params)
 {
-    (void)params;
-    return relu_common(input, output, 1);
+    return relu_common(input, output, params, 1);
 }

@@ -6,18 +6,27 @@
 #include "shl_mi355x_backend.h"
 
 /* params-block -> device plan association (struct csinn_fc_params has no spare pointer, so a
- * side table serves every op uniformly) */
+ * side table serves every op uniformly); grouped convolutions keep one plan per group */
 void shl_mi355x_registry_put(void *params, shl_mi355x_conv_plan *plan);
+void shl_mi355x_registry_put_group(void *params, shl_mi355x_conv_plan **plans, int n); /* takes the array */
 shl_mi355x_conv_plan *shl_mi355x_registry_get(void *params);
+shl_mi355x_conv_plan *shl_mi355x_registry_get_group(void *params, int i);
+
+/* Per-session execution context: the stream exec callbacks enqueue on and the session's own HBM
+ * staging buffers (setup.c).  ctx_of(NULL) is the context of session-less calls. */
+struct shl_mi355x_ctx;
+struct shl_mi355x_ctx *shl_mi355x_ctx_of(struct csinn_session *sess);
+void *shl_mi355x_ctx_stream(struct shl_mi355x_ctx *ctx);
+void shl_mi355x_ctx_release(struct csinn_session *sess);
 
 /* Host <-> HBM staging for tensors that do not already live on the device.
  * slot: 0 = first input, 1 = output, 2 = second input.
  *   stage_in        device address holding the tensor's bytes (uploads host tensors)
  *   stage_out_begin device address the kernel should write
  *   stage_out_end   downloads + synchronises for host tensors; CSINN_TRUE on success */
-const void *shl_mi355x_stage_in(struct csinn_tensor *t, int slot);
-void *shl_mi355x_stage_out_begin(struct csinn_tensor *t, int slot);
-int shl_mi355x_stage_out_end(struct csinn_tensor *t, void *dev);
+const void *shl_mi355x_stage_in(struct shl_mi355x_ctx *ctx, struct csinn_tensor *t, int slot);
+void *shl_mi355x_stage_out_begin(struct shl_mi355x_ctx *ctx, struct csinn_tensor *t, int slot);
+int shl_mi355x_stage_out_end(struct shl_mi355x_ctx *ctx, struct csinn_tensor *t, void *dev);
 
 float shl_mi355x_half_to_float(uint16_t h);
 

@@ -26,6 +26,12 @@ static int check_io(const char *op, struct csinn_tensor *input, struct csinn_ten
         shl_debug_error("mi355x: %s needs quantisation records\n", op);
         return CSINN_FALSE;
     }
+    if (input->quant_channel > 1 || output->quant_channel > 1) {
+        /* the reference's converters honour per-channel activation records
+         * (source/nn2/utils.c:1504-1642); the device path carries one record per activation tensor */
+        shl_debug_error("mi355x: %s: per-channel quantised activations are not supported\n", op);
+        return CSINN_UNSUPPORT_DTYPE;
+    }
     if (*dtype == SHL_MI355X_F16 && (input->qinfo->scale != 1.0f || output->qinfo->scale != 1.0f)) {
         /* f16_to_float / float_to_f16 scale by qinfo->scale when it differs from 1
          * (source/nn2/utils.c:1175-1205); not carried to the device */
@@ -57,18 +63,19 @@ int shl_mi355x_global_avgpool2d_exec(struct csinn_tensor *input, struct csinn_te
     } else {
         return CSINN_UNSUPPORT_LAYOUT;
     }
-    const void *in_dev = shl_mi355x_stage_in(input, 0);
-    void *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    struct shl_mi355x_ctx *ctx = shl_mi355x_ctx_of(params->base.sess);
+    const void *in_dev = shl_mi355x_stage_in(ctx, input, 0);
+    void *out_dev = shl_mi355x_stage_out_begin(ctx, output, 1);
     if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
     int st = shl_mi355x_global_avgpool2d(in_dev, out_dev, dtype, layout, input->dim[0], c, hw,
                                          input->qinfo->scale, input->qinfo->zero_point,
                                          output->qinfo->scale, output->qinfo->zero_point,
-                                         shl_mi355x_get_stream());
+                                         shl_mi355x_ctx_stream(ctx));
     if (st != SHL_MI355X_OK) {
         shl_debug_error("mi355x: global_avgpool2d failed (%d): %s\n", st, shl_mi355x_last_error());
         return CSINN_FALSE;
     }
-    return shl_mi355x_stage_out_end(output, out_dev);
+    return shl_mi355x_stage_out_end(ctx, output, out_dev);
 }
 
 int shl_mi355x_softmax_exec(struct csinn_tensor *input, struct csinn_tensor *output,
@@ -85,17 +92,18 @@ int shl_mi355x_softmax_exec(struct csinn_tensor *input, struct csinn_tensor *out
     int64_t outer = 1, inner = 1;
     for (int i = 0; i < axis; i++) outer *= input->dim[i];
     for (int i = axis + 1; i < input->dim_count; i++) inner *= input->dim[i];
-    const void *in_dev = shl_mi355x_stage_in(input, 0);
-    void *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    struct shl_mi355x_ctx *ctx = shl_mi355x_ctx_of(params->base.sess);
+    const void *in_dev = shl_mi355x_stage_in(ctx, input, 0);
+    void *out_dev = shl_mi355x_stage_out_begin(ctx, output, 1);
     if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
     int st = shl_mi355x_softmax(in_dev, out_dev, dtype, outer, input->dim[axis], inner, input->qinfo->scale,
                                 input->qinfo->zero_point, output->qinfo->scale, output->qinfo->zero_point,
-                                shl_mi355x_get_stream());
+                                shl_mi355x_ctx_stream(ctx));
     if (st != SHL_MI355X_OK) {
         shl_debug_error("mi355x: softmax failed (%d): %s\n", st, shl_mi355x_last_error());
         return CSINN_FALSE;
     }
-    return shl_mi355x_stage_out_end(output, out_dev);
+    return shl_mi355x_stage_out_end(ctx, output, out_dev);
 }
 
 /* residual add, two same-shape inputs (source/reference/add.c:21-41); shapes that would need the
@@ -103,11 +111,10 @@ int shl_mi355x_softmax_exec(struct csinn_tensor *input, struct csinn_tensor *out
 int shl_mi355x_add_exec(struct csinn_tensor *input0, struct csinn_tensor *input1, struct csinn_tensor *output,
                         struct csinn_diso_params *params)
 {
-    (void)params;
     int dtype;
     int rc = check_io("add", input0, output, &dtype);
     if (rc != CSINN_TRUE) return rc;
-    if (dtype_code(input1) != dtype || input1->qinfo == NULL ||
+    if (dtype_code(input1) != dtype || input1->qinfo == NULL || input1->quant_channel > 1 ||
         (dtype == SHL_MI355X_F16 && input1->qinfo->scale != 1.0f)) {
         shl_debug_error("mi355x: add: second input dtype / quantisation unsupported\n");
         return CSINN_UNSUPPORT_DTYPE;
@@ -121,16 +128,17 @@ int shl_mi355x_add_exec(struct csinn_tensor *input0, struct csinn_tensor *input1
             shl_debug_error("mi355x: add: broadcasting is not supported\n");
             return CSINN_FALSE;
         }
-    const void *a_dev = shl_mi355x_stage_in(input0, 0);
-    const void *b_dev = shl_mi355x_stage_in(input1, 2);
-    void *out_dev = shl_mi355x_stage_out_begin(output, 1);
+    struct shl_mi355x_ctx *ctx = shl_mi355x_ctx_of(params->base.sess);
+    const void *a_dev = shl_mi355x_stage_in(ctx, input0, 0);
+    const void *b_dev = shl_mi355x_stage_in(ctx, input1, 2);
+    void *out_dev = shl_mi355x_stage_out_begin(ctx, output, 1);
     if (a_dev == NULL || b_dev == NULL || out_dev == NULL) return CSINN_FALSE;
     int st = shl_mi355x_add(a_dev, b_dev, out_dev, (size_t)csinn_tensor_size(output), dtype, input0->qinfo->scale,
                             input0->qinfo->zero_point, input1->qinfo->scale, input1->qinfo->zero_point,
-                            output->qinfo->scale, output->qinfo->zero_point, shl_mi355x_get_stream());
+                            output->qinfo->scale, output->qinfo->zero_point, shl_mi355x_ctx_stream(ctx));
     if (st != SHL_MI355X_OK) {
         shl_debug_error("mi355x: add failed (%d): %s\n", st, shl_mi355x_last_error());
         return CSINN_FALSE;
     }
-    return shl_mi355x_stage_out_end(output, out_dev);
+    return shl_mi355x_stage_out_end(ctx, output, out_dev);
 }

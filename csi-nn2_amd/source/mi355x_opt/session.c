@@ -39,6 +39,7 @@ struct dev_session {
     struct dev_tensor *t;
     int nt;
     void *stream;
+    void *prev_stream; /* the session's stream before it became device resident */
     void *graph_exec;
     unsigned char *fused; /* per layer: 1 = runs fused with the next layer (depthwise + pointwise) */
     int nfused;
@@ -59,7 +60,11 @@ static void free_session(struct dev_session *ds)
     if (ds->graph_exec) shl_mi355x_graph_destroy(ds->graph_exec);
     for (int i = 0; i < ds->nt; i++)
         if (ds->t[i].dev && !ds->t[i].borrowed) shl_mi355x_free(ds->t[i].dev);
-    if (ds->stream) shl_mi355x_stream_destroy(ds->stream);
+    if (ds->stream) {
+        shl_mi355x_stream_sync(ds->stream);
+        shl_mi355x_session_set_stream(ds->sess, ds->prev_stream); /* the host path keeps working */
+        shl_mi355x_stream_destroy(ds->stream);
+    }
     free(ds->t);
     free(ds->fused);
     free(ds);
@@ -196,7 +201,7 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
             int (*fwd)(const shl_mi355x_conv_plan *, const shl_mi355x_conv_plan *, const void *, void *, int32_t,
                        void *) = ds->fused[i] == 2 ? shl_mi355x_pwdw_forward : shl_mi355x_dwpw_forward;
             int st = fwd(shl_mi355x_registry_get(n->data), shl_mi355x_registry_get(nx->data), in->dev, out2->dev,
-                         in->shadow.dim[0], shl_mi355x_get_stream());
+                         in->shadow.dim[0], ds->stream);
             rc = st == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
             i++;
         } else if (op_arity(n->type) == 1) {
@@ -222,8 +227,7 @@ static int capture(struct dev_session *ds, struct shl_ref_graph *g)
         shl_mi355x_graph_destroy(ds->graph_exec);
         ds->graph_exec = NULL;
     }
-    void *prev = shl_mi355x_get_stream();
-    shl_mi355x_set_stream(ds->stream);
+    /* the layers' exec callbacks enqueue on the session's own stream (its context, setup.c) */
     int built = CSINN_FALSE;
     if (shl_mi355x_graph_begin(ds->stream) == SHL_MI355X_OK) {
         built = enqueue_layers(ds, g);
@@ -233,7 +237,6 @@ static int capture(struct dev_session *ds, struct shl_ref_graph *g)
             ds->graph_exec = NULL;
         }
     }
-    shl_mi355x_set_stream(prev);
     return built;
 }
 
@@ -300,6 +303,8 @@ int shl_mi355x_session_setup(struct csinn_session *sess)
     ds->t = calloc((size_t)tensors + 1, sizeof(struct dev_tensor));
     ds->stream = shl_mi355x_stream_create();
     int ok = ds->stream != NULL;
+    ds->prev_stream = shl_mi355x_session_stream(sess);
+    if (ok) shl_mi355x_session_set_stream(sess, ds->stream); /* every exec callback of this session enqueues here */
     for (int i = 0; ok && i < g->input_num; i++) ok = adopt(ds, g->input[i]) != NULL;
     for (int i = 0; ok && i < g->layer_index; i++) {
         struct shl_node *n = g->layer[i];
@@ -383,10 +388,7 @@ int shl_mi355x_session_run(struct csinn_session *sess)
     if (ds->graph_exec) {
         if (shl_mi355x_graph_launch(ds->graph_exec, ds->stream) != SHL_MI355X_OK) status = CSINN_FALSE;
     } else {
-        void *prev = shl_mi355x_get_stream();
-        shl_mi355x_set_stream(ds->stream);
         if (enqueue_layers(ds, g) != CSINN_TRUE) status = CSINN_FALSE;
-        shl_mi355x_set_stream(prev);
     }
     for (int i = 0; i < g->output_num; i++) {
         struct dev_tensor *d = lookup(ds, g->output[i]);
@@ -408,15 +410,15 @@ int shl_mi355x_session_run(struct csinn_session *sess)
 void shl_mi355x_session_deinit(struct csinn_session *sess)
 {
     drop_session(sess);
+    /* the device plans of the session's layers and its staging buffers die with it (the reference's
+     * optimised backends leak theirs: "XXX: memory leak", thead_rvv/int8/convolution.c:177) */
+    struct shl_ref_graph *g = shl_gref_get_graph(sess);
+    if (g)
+        for (int i = 0; i < g->layer_index; i++)
+            if (g->layer[i] && g->layer[i]->data) shl_mi355x_release_params(g->layer[i]->data);
+    shl_mi355x_ctx_release(sess);
     void (*gref_deinit)(struct csinn_session *) = shl_gref_runtime_callback(CSINN_SESSION_DEINIT);
     if (gref_deinit) gref_deinit(sess);
-}
-
-/* the stream a device-resident session runs on (NULL for host-staged sessions) */
-void *shl_mi355x_session_stream(struct csinn_session *sess)
-{
-    struct dev_session *ds = find_session(sess);
-    return ds ? ds->stream : NULL;
 }
 
 /* number of depthwise + pointwise pairs that run as one launch in `sess` */

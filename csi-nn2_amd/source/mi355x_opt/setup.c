@@ -57,15 +57,100 @@ struct csinn_callback *shl_cb_map_mi355x(int op, int dtype)
     return NULL;
 }
 
-/* ------------------------------------------------------------------------ stream */
-static void *g_stream;
-void shl_mi355x_set_stream(void *stream) { g_stream = stream; }
-void *shl_mi355x_get_stream(void) { return g_stream; }
+/* ------------------------------------------------------------------------ execution contexts
+ * SURVEY 8(b) "Threading": a GPU backend serialises its own stream use PER SESSION.  Every csinn
+ * session (layer-mode sessions included: params->base.sess) owns one context = the HIP stream its exec
+ * callbacks enqueue on + the HBM staging buffers host tensors travel through.  Two sessions therefore
+ * never share a staging buffer or an ordering assumption; a layer-mode call cannot disturb a session
+ * graph in flight.  A context without an explicit stream uses the process default set by
+ * shl_mi355x_set_stream (NULL = HIP's default stream). */
+struct shl_mi355x_ctx {
+    struct csinn_session *sess;
+    void *stream;
+    int own_stream; /* stream was set for this session explicitly */
+    struct {
+        void *dev;
+        size_t bytes;
+    } stage[3]; /* 0: first input, 1: output, 2: second input */
+    struct shl_mi355x_ctx *next;
+};
 
-/* ------------------------------------------------------------------------ plan registry */
+static void *g_default_stream;
+static struct shl_mi355x_ctx *g_ctx;
+static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
+
+void shl_mi355x_set_stream(void *stream) { g_default_stream = stream; }
+void *shl_mi355x_get_stream(void) { return g_default_stream; }
+
+struct shl_mi355x_ctx *shl_mi355x_ctx_of(struct csinn_session *sess)
+{
+    pthread_mutex_lock(&g_ctx_lock);
+    struct shl_mi355x_ctx *c = g_ctx;
+    while (c && c->sess != sess) c = c->next;
+    if (c == NULL) {
+        c = calloc(1, sizeof(*c));
+        if (c) {
+            c->sess = sess;
+            c->next = g_ctx;
+            g_ctx = c;
+        }
+    }
+    pthread_mutex_unlock(&g_ctx_lock);
+    return c;
+}
+
+void *shl_mi355x_ctx_stream(struct shl_mi355x_ctx *ctx)
+{
+    return ctx && ctx->own_stream ? ctx->stream : g_default_stream;
+}
+
+static int ctx_has_staging(struct shl_mi355x_ctx *c) { return c->stage[0].dev || c->stage[1].dev || c->stage[2].dev; }
+
+void shl_mi355x_session_set_stream(struct csinn_session *sess, void *stream)
+{
+    struct shl_mi355x_ctx *c = shl_mi355x_ctx_of(sess);
+    if (c == NULL) return;
+    /* staged uploads still queued on the previous stream must land before another stream reuses
+     * the staging buffers */
+    if (ctx_has_staging(c)) shl_mi355x_stream_sync(shl_mi355x_ctx_stream(c));
+    c->stream = stream;
+    c->own_stream = 1;
+}
+
+void *shl_mi355x_session_stream(struct csinn_session *sess)
+{
+    return shl_mi355x_ctx_stream(shl_mi355x_ctx_of(sess));
+}
+
+/* drop the context of `sess`: waits for its stream, frees its staging buffers (the stream itself
+ * belongs to whoever created it) */
+void shl_mi355x_ctx_release(struct csinn_session *sess)
+{
+    pthread_mutex_lock(&g_ctx_lock);
+    struct shl_mi355x_ctx **pp = &g_ctx, *dead = NULL;
+    while (*pp) {
+        if ((*pp)->sess == sess) {
+            dead = *pp;
+            *pp = dead->next;
+            break;
+        }
+        pp = &(*pp)->next;
+    }
+    pthread_mutex_unlock(&g_ctx_lock);
+    if (dead == NULL) return;
+    if (ctx_has_staging(dead)) shl_mi355x_stream_sync(shl_mi355x_ctx_stream(dead));
+    for (int i = 0; i < 3; i++)
+        if (dead->stage[i].dev) shl_mi355x_free(dead->stage[i].dev);
+    free(dead);
+}
+
+/* ------------------------------------------------------------------------ plan registry
+ * params block -> device plan(s).  A grouped convolution keeps one plan per group in `sub`. */
 struct slot {
     void *key;
     shl_mi355x_conv_plan *plan;
+    shl_mi355x_conv_plan **sub;
+    int nsub;
 };
 static struct slot *g_slots;
 static size_t g_cap, g_used;
@@ -98,28 +183,45 @@ static void rehash(size_t cap)
     free(old);
 }
 
-void shl_mi355x_registry_put(void *params, shl_mi355x_conv_plan *plan)
+static void destroy_contents(struct slot *s)
+{
+    if (s->plan) shl_mi355x_conv_plan_destroy(s->plan);
+    for (int i = 0; i < s->nsub; i++)
+        if (s->sub[i]) shl_mi355x_conv_plan_destroy(s->sub[i]);
+    free(s->sub);
+}
+
+/* (re)binds `params` to a plan, or to `nsub` per-group plans (ownership of the array passes) */
+static void registry_store(void *params, shl_mi355x_conv_plan *plan, shl_mi355x_conv_plan **sub, int nsub)
 {
     pthread_mutex_lock(&g_lock);
     if (g_cap == 0 || (g_used + 1) * 2 > g_cap) rehash(g_cap ? g_cap * 2 : 64);
     size_t h = hash_ptr(params, g_cap);
-    shl_mi355x_conv_plan *stale = NULL;
+    struct slot stale = {0};
     for (;;) {
         if (g_slots[h].key == params) { /* re-init of the same layer replaces the plan */
-            stale = g_slots[h].plan;
-            g_slots[h].plan = plan;
+            stale = g_slots[h];
             break;
         }
         if (g_slots[h].key == NULL) {
             g_slots[h].key = params;
-            g_slots[h].plan = plan;
             g_used++;
             break;
         }
         h = (h + 1) & (g_cap - 1);
     }
+    g_slots[h].plan = plan;
+    g_slots[h].sub = sub;
+    g_slots[h].nsub = nsub;
     pthread_mutex_unlock(&g_lock);
-    if (stale) shl_mi355x_conv_plan_destroy(stale);
+    destroy_contents(&stale);
+}
+
+void shl_mi355x_registry_put(void *params, shl_mi355x_conv_plan *plan) { registry_store(params, plan, NULL, 0); }
+
+void shl_mi355x_registry_put_group(void *params, shl_mi355x_conv_plan **plans, int n)
+{
+    registry_store(params, NULL, plans, n);
 }
 
 static struct slot *find(void *params)
@@ -143,30 +245,31 @@ shl_mi355x_conv_plan *shl_mi355x_registry_get(void *params)
     return p;
 }
 
+shl_mi355x_conv_plan *shl_mi355x_registry_get_group(void *params, int i)
+{
+    pthread_mutex_lock(&g_lock);
+    struct slot *s = find(params);
+    shl_mi355x_conv_plan *p = s && i >= 0 && i < s->nsub ? s->sub[i] : NULL;
+    pthread_mutex_unlock(&g_lock);
+    return p;
+}
+
 int shl_mi355x_release_params(void *params)
 {
     pthread_mutex_lock(&g_lock);
     struct slot *s = find(params);
-    shl_mi355x_conv_plan *p = NULL;
+    struct slot dead = {0};
     if (s) {
-        p = s->plan;
+        dead = *s;
         s->key = TOMBSTONE;
         s->plan = NULL;
-    }
-    /* grouped convolutions keep one plan per group under the keys params + 1 + i */
-    shl_mi355x_conv_plan *sub[64];
-    int nsub = 0;
-    for (int i = 0; i < 64; i++) {
-        struct slot *g = find((char *)params + 1 + i);
-        if (g == NULL) break;
-        sub[nsub++] = g->plan;
-        g->key = TOMBSTONE;
-        g->plan = NULL;
+        s->sub = NULL;
+        s->nsub = 0;
     }
     pthread_mutex_unlock(&g_lock);
-    for (int i = 0; i < nsub; i++) shl_mi355x_conv_plan_destroy(sub[i]);
-    if (p == NULL) return nsub > 0 ? CSINN_TRUE : CSINN_FALSE;
-    return shl_mi355x_conv_plan_destroy(p) == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
+    if (dead.plan == NULL && dead.nsub == 0) return CSINN_FALSE;
+    destroy_contents(&dead);
+    return CSINN_TRUE;
 }
 
 int shl_mi355x_live_plans(int64_t *hbm_bytes)
@@ -175,10 +278,16 @@ int shl_mi355x_live_plans(int64_t *hbm_bytes)
     int64_t bytes = 0;
     pthread_mutex_lock(&g_lock);
     for (size_t i = 0; i < g_cap; i++) {
-        if (g_slots[i].key && g_slots[i].key != TOMBSTONE && g_slots[i].plan) {
+        if (g_slots[i].key == NULL || g_slots[i].key == TOMBSTONE) continue;
+        if (g_slots[i].plan) {
             n++;
             bytes += (int64_t)shl_mi355x_conv_plan_bytes(g_slots[i].plan);
         }
+        for (int k = 0; k < g_slots[i].nsub; k++)
+            if (g_slots[i].sub[k]) {
+                n++;
+                bytes += (int64_t)shl_mi355x_conv_plan_bytes(g_slots[i].sub[k]);
+            }
     }
     pthread_mutex_unlock(&g_lock);
     if (hbm_bytes) *hbm_bytes = bytes;
@@ -194,63 +303,62 @@ void *shl_mi355x_params_const_block(void *params, size_t *bytes)
 const char *shl_mi355x_params_kernel_name(void *params)
 {
     shl_mi355x_conv_plan *p = shl_mi355x_registry_get(params);
+    if (p == NULL) p = shl_mi355x_registry_get_group(params, 0);
     return p ? shl_mi355x_conv_plan_kernel_name(p) : "";
 }
 
 /* ------------------------------------------------------------------------ staging */
-static struct {
-    void *dev;
-    size_t bytes;
-} g_stage[3]; /* 0: first input, 1: output, 2: second input */
-
-static void *stage_buffer(int slot, size_t bytes)
+static void *stage_buffer(struct shl_mi355x_ctx *c, int slot, size_t bytes)
 {
-    if (g_stage[slot].bytes >= bytes && g_stage[slot].dev) return g_stage[slot].dev;
-    if (g_stage[slot].dev) {
+    if (c->stage[slot].bytes >= bytes && c->stage[slot].dev) return c->stage[slot].dev;
+    if (c->stage[slot].dev) {
         /* kernels that still read the old buffer must finish before it is freed */
-        shl_mi355x_stream_sync(g_stream);
-        shl_mi355x_free(g_stage[slot].dev);
+        shl_mi355x_stream_sync(shl_mi355x_ctx_stream(c));
+        shl_mi355x_free(c->stage[slot].dev);
     }
     size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
-    g_stage[slot].dev = shl_mi355x_malloc(want);
-    g_stage[slot].bytes = g_stage[slot].dev ? want : 0;
-    if (g_stage[slot].dev == NULL)
+    c->stage[slot].dev = shl_mi355x_malloc(want);
+    c->stage[slot].bytes = c->stage[slot].dev ? want : 0;
+    if (c->stage[slot].dev == NULL)
         shl_debug_error("mi355x: cannot allocate %zu bytes of HBM: %s\n", want, shl_mi355x_last_error());
-    return g_stage[slot].dev;
+    return c->stage[slot].dev;
 }
 
-const void *shl_mi355x_stage_in(struct csinn_tensor *t, int slot)
+const void *shl_mi355x_stage_in(struct shl_mi355x_ctx *c, struct csinn_tensor *t, int slot)
 {
     if (t->data == NULL) {
         shl_debug_error("mi355x: input tensor has no data\n");
         return NULL;
     }
     if (t->mtype == CSINN_MEM_TYPE_DMABUF) return t->data;
+    if (c == NULL) return NULL;
     const size_t bytes = (size_t)csinn_tensor_byte_size(t);
-    void *dev = stage_buffer(slot, bytes);
+    void *dev = stage_buffer(c, slot, bytes);
     if (dev == NULL) return NULL;
-    if (shl_mi355x_upload(dev, t->data, bytes, g_stream) != SHL_MI355X_OK) {
+    if (shl_mi355x_upload(dev, t->data, bytes, shl_mi355x_ctx_stream(c)) != SHL_MI355X_OK) {
         shl_debug_error("mi355x: upload failed: %s\n", shl_mi355x_last_error());
         return NULL;
     }
     return dev;
 }
 
-void *shl_mi355x_stage_out_begin(struct csinn_tensor *t, int slot)
+void *shl_mi355x_stage_out_begin(struct shl_mi355x_ctx *c, struct csinn_tensor *t, int slot)
 {
     if (t->data == NULL) {
         shl_debug_error("mi355x: output tensor has no data\n");
         return NULL;
     }
     if (t->mtype == CSINN_MEM_TYPE_DMABUF) return t->data;
-    return stage_buffer(slot, (size_t)csinn_tensor_byte_size(t));
+    if (c == NULL) return NULL;
+    return stage_buffer(c, slot, (size_t)csinn_tensor_byte_size(t));
 }
 
-int shl_mi355x_stage_out_end(struct csinn_tensor *t, void *dev)
+int shl_mi355x_stage_out_end(struct shl_mi355x_ctx *c, struct csinn_tensor *t, void *dev)
 {
     if (t->mtype == CSINN_MEM_TYPE_DMABUF) return CSINN_TRUE; /* stays in HBM, stays async */
-    if (shl_mi355x_download(t->data, dev, (size_t)csinn_tensor_byte_size(t), g_stream) != SHL_MI355X_OK ||
-        shl_mi355x_stream_sync(g_stream) != SHL_MI355X_OK) {
+    void *stream = shl_mi355x_ctx_stream(c);
+    if (shl_mi355x_download(t->data, dev, (size_t)csinn_tensor_byte_size(t), stream) != SHL_MI355X_OK ||
+        shl_mi355x_stream_sync(stream) != SHL_MI355X_OK) {
         shl_debug_error("mi355x: download failed: %s\n", shl_mi355x_last_error());
         return CSINN_FALSE;
     }

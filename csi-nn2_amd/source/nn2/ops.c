@@ -33,14 +33,30 @@ static int classify(struct csinn_tensor *input, struct csinn_tensor *kernel,
     return grouped;
 }
 
-static int map_and_init(struct csinn_params_base *base, int op, int dtype, void *a, void *b,
-                        void *c, void *d, void *params)
+/* The arity of a callback is a property of the operator, never of the data: a convolution without a
+ * bias tensor still passes all five arguments (bias == NULL), as the reference front-end does
+ * (source/nn2/convolution.c:45-52). */
+static int map_and_init5(struct csinn_params_base *base, int op, int dtype, void *a, void *b,
+                         void *c, void *d, void *params)
 {
     int rc = shl_op_callback_map(base, op, dtype);
     if (rc != CSINN_TRUE) return rc;
     int (*init)() = shl_get_init_cb(base);
     if (init != NULL) {
-        rc = d ? init(a, b, c, d, params) : init(a, b, params);
+        rc = init(a, b, c, d, params);
+        if (rc != CSINN_TRUE) return rc;
+    }
+    return CSINN_TRUE;
+}
+
+static int map_and_init3(struct csinn_params_base *base, int op, int dtype, void *a, void *b,
+                         void *params)
+{
+    int rc = shl_op_callback_map(base, op, dtype);
+    if (rc != CSINN_TRUE) return rc;
+    int (*init)() = shl_get_init_cb(base);
+    if (init != NULL) {
+        rc = init(a, b, params);
         if (rc != CSINN_TRUE) return rc;
     }
     return CSINN_TRUE;
@@ -67,8 +83,8 @@ static int run3(struct csinn_params_base *base, void *a, void *b, void *params)
     {                                                                                        \
         int op = classify(input, kernel, params, PLAIN, DW, GROUP);                          \
         if (op < 0) return op;                                                               \
-        return map_and_init(&params->base, op, input->dtype, input, output, kernel, bias,    \
-                            params);                                                         \
+        return map_and_init5(&params->base, op, input->dtype, input, output, kernel, bias,   \
+                             params);                                                         \
     }                                                                                        \
     int fn_name(CSINN_CONV_ARGS) { return run5(&params->base, input, output, kernel, bias, params); }
 
@@ -80,8 +96,8 @@ CONV_FAMILY(csinn_conv2d_relu6, CSINN_OP_CONV2D_RELU6, CSINN_OP_DEPTHWISE_CONV2D
 
 int csinn_depthwise_conv2d_init(CSINN_CONV_ARGS)
 {
-    return map_and_init(&params->base, CSINN_OP_DEPTHWISE_CONV2D, input->dtype, input, output,
-                        kernel, bias, params);
+    return map_and_init5(&params->base, CSINN_OP_DEPTHWISE_CONV2D, input->dtype, input, output,
+                         kernel, bias, params);
 }
 int csinn_depthwise_conv2d(CSINN_CONV_ARGS)
 {
@@ -90,8 +106,8 @@ int csinn_depthwise_conv2d(CSINN_CONV_ARGS)
 
 int csinn_depthwise_conv2d_relu_init(CSINN_CONV_ARGS)
 {
-    return map_and_init(&params->base, CSINN_OP_DEPTHWISE_CONV2D_RELU, input->dtype, input,
-                        output, kernel, bias, params);
+    return map_and_init5(&params->base, CSINN_OP_DEPTHWISE_CONV2D_RELU, input->dtype, input,
+                         output, kernel, bias, params);
 }
 int csinn_depthwise_conv2d_relu(CSINN_CONV_ARGS)
 {
@@ -102,8 +118,8 @@ int csinn_fullyconnected_init(struct csinn_tensor *input, struct csinn_tensor *o
                               struct csinn_tensor *weights, struct csinn_tensor *bias,
                               struct csinn_fc_params *params)
 {
-    return map_and_init(&params->base, CSINN_OP_FULLYCONNECTED, input->dtype, input, output,
-                        weights, bias, params);
+    return map_and_init5(&params->base, CSINN_OP_FULLYCONNECTED, input->dtype, input, output,
+                         weights, bias, params);
 }
 int csinn_fullyconnected(struct csinn_tensor *input, struct csinn_tensor *output,
                          struct csinn_tensor *weights, struct csinn_tensor *bias,
@@ -115,8 +131,7 @@ int csinn_fullyconnected(struct csinn_tensor *input, struct csinn_tensor *output
 int csinn_relu_init(struct csinn_tensor *input, struct csinn_tensor *output,
                     struct csinn_relu_params *params)
 {
-    return map_and_init(&params->base, CSINN_OP_RELU, input->dtype, input, output, NULL, NULL,
-                        params);
+    return map_and_init3(&params->base, CSINN_OP_RELU, input->dtype, input, output, params);
 }
 int csinn_relu(struct csinn_tensor *input, struct csinn_tensor *output,
                struct csinn_relu_params *params)
@@ -127,8 +142,7 @@ int csinn_relu(struct csinn_tensor *input, struct csinn_tensor *output,
 int csinn_relu6_init(struct csinn_tensor *input, struct csinn_tensor *output,
                      struct csinn_relu_params *params)
 {
-    return map_and_init(&params->base, CSINN_OP_RELU6, input->dtype, input, output, NULL, NULL,
-                        params);
+    return map_and_init3(&params->base, CSINN_OP_RELU6, input->dtype, input, output, params);
 }
 int csinn_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
                 struct csinn_relu_params *params)
@@ -139,8 +153,7 @@ int csinn_relu6(struct csinn_tensor *input, struct csinn_tensor *output,
 int csinn_global_avgpool2d_init(struct csinn_tensor *input, struct csinn_tensor *output,
                                 struct csinn_pool_params *params)
 {
-    return map_and_init(&params->base, CSINN_OP_GLOBAL_AVGPOOL2D, input->dtype, input, output, NULL,
-                        NULL, params);
+    return map_and_init3(&params->base, CSINN_OP_GLOBAL_AVGPOOL2D, input->dtype, input, output, params);
 }
 int csinn_global_avgpool2d(struct csinn_tensor *input, struct csinn_tensor *output,
                            struct csinn_pool_params *params)
@@ -151,8 +164,7 @@ int csinn_global_avgpool2d(struct csinn_tensor *input, struct csinn_tensor *outp
 int csinn_softmax_init(struct csinn_tensor *input, struct csinn_tensor *output,
                        struct csinn_softmax_params *params)
 {
-    return map_and_init(&params->base, CSINN_OP_SOFTMAX, input->dtype, input, output, NULL, NULL,
-                        params);
+    return map_and_init3(&params->base, CSINN_OP_SOFTMAX, input->dtype, input, output, params);
 }
 int csinn_softmax(struct csinn_tensor *input, struct csinn_tensor *output,
                   struct csinn_softmax_params *params)

@@ -173,10 +173,16 @@ void *csinn_alloc_params(int params_size, struct csinn_session *session)
     return p;
 }
 
+/* present when the MI355X backend is loaded: device plans attached to a params block by an init
+ * callback die with the block (the reference has no such hook and its optimised backends leak their
+ * packed weights: thead_rvv/int8/convolution.c:177 "XXX: memory leak") */
+int shl_mi355x_release_params(void *params) __attribute__((weak));
+
 void csinn_free_params(void *params)
 {
     struct csinn_params_base *p = params;
     if (p == NULL) return;
+    if (shl_mi355x_release_params) shl_mi355x_release_params(params);
     if (p->cb) shl_mem_free(p->cb);
     shl_mem_free(p);
 }

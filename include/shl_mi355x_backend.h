@@ -28,9 +28,14 @@ void shl_target_init_mi355x(void);
 struct csinn_callback *shl_cb_map_mi355x(int op, int dtype);
 void *shl_mi355x_runtime_callback(int runtime_op);
 
-/* stream (opaque hipStream_t) on which subsequent exec callbacks enqueue; NULL = default */
+/* Streams.  Every csinn session (layer-mode sessions included) has its own execution context: the
+ * HIP stream its exec callbacks enqueue on and its own HBM staging buffers, so two sessions never race
+ * (SURVEY 8b "Threading": serialise per session).  shl_mi355x_session_set_stream binds an opaque
+ * hipStream_t to one session; sessions without one use the process default of shl_mi355x_set_stream
+ * (NULL = HIP's default stream).  A device-resident graph session creates and owns its stream. */
 void shl_mi355x_set_stream(void *stream);
 void *shl_mi355x_get_stream(void);
+void shl_mi355x_session_set_stream(struct csinn_session *sess, void *stream);
 
 /* release the device plan attached to a params block by an init callback (the reference's
  * optimised backends leak theirs: "XXX: memory leak", thead_rvv/int8/convolution.c:177) */
@@ -71,8 +76,8 @@ int shl_mi355x_session_run(struct csinn_session *sess);
 void shl_mi355x_session_deinit(struct csinn_session *sess);
 /* 0: host-staged (executor's own run), 1: device-resident eager, 2: device-resident hipGraph */
 int shl_mi355x_session_is_device_resident(struct csinn_session *sess);
-/* stream of a device-resident session: when every graph output is a DMABUF tensor csinn_session_run
- * only enqueues (no synchronisation); wait with shl_mi355x_stream_sync on this stream */
+/* the stream `sess` enqueues on.  When every graph output of a device-resident session is a DMABUF tensor
+ * csinn_session_run only enqueues (no synchronisation); wait with shl_mi355x_stream_sync on this stream */
 void *shl_mi355x_session_stream(struct csinn_session *sess);
 /* depthwise + pointwise pairs of `sess` that run as one fused launch (graph-level fusion) */
 int shl_mi355x_session_fused_pairs(struct csinn_session *sess);

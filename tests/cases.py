@@ -281,14 +281,29 @@ def oracle_group_run(case, formulation="ref"):
     return out.reshape(case["out_shape"])
 
 
+# ---------------------------------------------------------------------------------- genuine reference
+# oracle/_ref/libshl_ref_x86.so = the reference's own sources compiled by oracle/Makefile.ref.  Test
+# infrastructure: the product package knows nothing about it.
+def reference_lib_path():
+    return os.path.join(ROOT, "oracle", "_ref", "libshl_ref_x86.so")
+
+
 def have_reference():
-    return os.path.exists(pkg.reference_lib_path())
+    return os.path.exists(reference_lib_path())
+
+
+def load_reference_frontend(local=False):
+    """the genuine library as a csinn front-end (its .so carries no libgomp DT_NEEDED: preload it)"""
+    C.CDLL("libgomp.so.1", mode=C.RTLD_GLOBAL)
+    fe = pkg.load_frontend(path=reference_lib_path(), local=local)
+    fe.kind = "reference"
+    return fe
 
 
 def reference_run(case):
     """Genuine reference (CSINN_REF, layer mode).  The x86 NCHW path only computes image 0
     (SURVEY 0.5), so NCHW batches are driven one image at a time."""
-    fe = pkg.load_frontend("reference", local=True)
+    fe = load_reference_frontend(local=True)
     if case["layout"] == NCHW and case["n"] > 1 and not case["depthwise"]:
         outs = []
         for i in range(case["n"]):

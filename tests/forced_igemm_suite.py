@@ -1,0 +1,90 @@
+"""Parity suite for ONE forced implicit-GEMM variant (run by tests/test_igemm_variants.py in a sub-process).
+
+The variant switches (SHL_MI355X_IGEMM / _TILE / _PIPE / _HALO / _P8) are read once per process, so every
+combination gets its own interpreter: `python -m pytest tests/forced_igemm_suite.py -m gpu` with the
+switches in the environment.  Every shape runs int8 in the exact regime AND with general scales (both must
+equal oracle formulation X bit for bit), in NHWC and in NCHW (NCHW planes of 64 / 196 / 784 elements take
+the fused NCHW epilogue with 16- and 4-byte stores, 49-element planes the re-layout pass), and a subset in
+binary16 (1e-3 relative: the MFMA kernel sums in a different order).  Shapes are ragged against every tile
+(M not a multiple of 128 / 256, Cout not a multiple of 32 / 64 / 128 / 256, tiles straddling images, K
+chunks straddling taps).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_util
+from cases import NCHW, NHWC, pkg
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    dict(c=64, co=64, h=28, w=28, n=2),                              # Cout = 64 tile, planes of 784
+    dict(c=64, co=200, h=13, w=11, n=3),                             # ragged M and Cout; odd planes (143)
+    dict(c=128, co=128, h=14, w=14, n=3, stride=(2, 2)),             # 7x7 output planes
+    dict(c=128, co=136, h=14, w=14, n=2),                            # planes of 196: 4-byte NCHW stores
+    dict(c=16, co=16),                                               # K chunks straddle taps
+    dict(c=48, co=130, h=5, w=5),
+    dict(c=32, co=24, h=9, w=7),
+    dict(c=256, co=320, h=8, w=8, n=5),                              # M = 320, three 128-wide channel tiles
+    dict(c=64, co=32, dilation=(2, 2), pad=(2, 2, 2, 2), h=12, w=12),
+    dict(c=80, co=48, pad=(0, 1, 2, 0), stride=(1, 2), h=10, w=10),
+    dict(c=512, co=64, k=(1, 1), pad=(0, 0, 0, 0), h=7, w=7, n=6),   # pointwise, deep K
+    dict(c=64, co=64, k=(1, 1), pad=(0, 0, 0, 0), h=20, w=20),
+    dict(c=16, co=8, k=(5, 3), pad=(2, 1, 2, 1)),
+    dict(c=192, co=64, h=6, w=6, act=1),
+    dict(c=64, co=128, h=16, w=16, act=2, per_channel=True),
+    dict(c=64, co=72, h=56, w=9, n=1),                               # tall image: halo patches spanning rows
+    dict(c=128, co=256, h=12, w=12, n=4, act=1),                     # 256-wide channel tile exactly
+]
+F16_IDX = [0, 3, 4, 7, 10, 14, 16]
+
+EXPECT = os.environ.get("SHL_EXPECT_KERNEL", "")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    fe = pkg.load_frontend("standalone")
+    hip, opt = pkg.load_backend(fe)
+    if hip.shl_mi355x_device_count() < 1:
+        pytest.fail("no gfx950 device visible: " + hip.shl_mi355x_last_error().decode())
+    return fe, hip, opt, cases.HipDevice(hip)
+
+
+def _run(gpu, case):
+    fe, hip, opt, dev = gpu
+    kept = []
+    got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+    name = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
+    assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
+    return got, name
+
+
+@pytest.mark.parametrize("layout", [NHWC, NCHW])
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("idx", range(len(SHAPES)))
+def test_forced_variant_int8_equals_formulation_x(gpu, idx, exact, layout):
+    case = cases.make_case(8000 + idx, exact=exact, layout=layout, **SHAPES[idx])
+    got, kname = _run(gpu, case)
+    if EXPECT:
+        assert EXPECT in kname, "expected a %s kernel, the plan chose %s" % (EXPECT, kname)
+    want = cases.oracle_run(case, "exact")
+    count, worst = cases.mismatch_report(got, want)
+    assert count == 0, "shape %d %s via %s: %d mismatches vs formulation X (max %d)" % (idx, layout, kname, count, worst)
+    golden_util.compare(case, got, cases.oracle_run(case, "ref"), "shape %d via %s vs formulation R" % (idx, kname))
+
+
+@pytest.mark.parametrize("layout", [NHWC, NCHW])
+@pytest.mark.parametrize("idx", F16_IDX)
+def test_forced_variant_fp16_within_tolerance(gpu, idx, layout):
+    kw = dict(SHAPES[idx])
+    kw.pop("per_channel", None)
+    if kw.get("act") == 2:
+        kw["act"] = 1
+    case = cases.make_case(8500 + idx, dtype="f16", layout=layout, **kw)
+    got, kname = _run(gpu, case)
+    if EXPECT:
+        assert EXPECT in kname, "expected a %s kernel, the plan chose %s" % (EXPECT, kname)
+    golden_util.compare_f16_tol(got, cases.oracle_run(case, "f16"), "fp16 shape %d %s via %s" % (idx, layout, kname))

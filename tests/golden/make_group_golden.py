@@ -27,7 +27,7 @@ GROUP_CASES = [
 
 
 def main():
-    fe = pkg.load_frontend("reference")
+    fe = cases.load_reference_frontend()
     blob = {}
     for i, (name, kw) in enumerate(GROUP_CASES):
         case = cases.make_case(700 + i, **kw)

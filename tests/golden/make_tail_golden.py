@@ -19,7 +19,7 @@ from cases import pkg  # noqa: E402
 
 
 def main():
-    fe = pkg.load_frontend("reference")
+    fe = cases.load_reference_frontend()
     blob = {}
     for case in tail.tail_cases():
         out = tail.siso_run(fe, pkg.API_REF, case)

@@ -209,7 +209,7 @@ def test_data_convert_matches_reference_semantics(built, frontend):
     oracle's scalar primitives; when the genuine library is present it must agree too."""
     if frontend == "reference" and not cases.have_reference():
         pytest.skip("oracle/_ref not built")
-    lib = pkg.load_frontend(frontend, local=(frontend == "reference"))
+    lib = cases.load_reference_frontend(local=True) if frontend == "reference" else pkg.load_frontend(frontend)
     keep = pkg.Keep()
     orc = cases.oracle_lib()
     rng = np.random.default_rng(8)

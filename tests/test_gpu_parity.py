@@ -128,6 +128,23 @@ def test_fp16_against_oracle(gpu, idx):
     _check(case, got, want, "fp16 shape %d via %s" % (idx, kname), kname)
 
 
+@pytest.mark.parametrize("kw,scale", [(dict(c=64, co=64, h=14, w=14, act=2), 0.37), (dict(c=16, co=16, act=2), 2.0),
+                                      (dict(depthwise=True, c=32, act=1), 0.011), (dict(c=3, co=16, act=2), 1.7),
+                                      (dict(c=64, co=48, k=(1, 1), pad=(0, 0, 0, 0), act=0), 0.5),
+                                      (dict(layout=NCHW, c=64, co=32, k=(1, 1), pad=(0, 0, 0, 0), h=7, w=7, act=2), 0.25)])
+def test_fp16_output_scale_with_fused_activation(gpu, kw, scale):
+    """float_to_f16 multiplies by 1/scale before narrowing and the fused relu / relu6 acts on the DEQUANTISED
+    stored tensor (source/nn2/utils.c:1191-1205, reference/relu6.c:21-43): the clamp sits at 6/scale in
+    the stored domain, after one extra f16 rounding."""
+    case = cases.make_case(5300, dtype="f16", **kw)
+    case["out_scale"] = scale
+    case["input"] = (case["input"].astype(np.float32) * 3).astype(np.float16)   # reach beyond 6
+    got, kname = _run(gpu, case, device_tensors=True)
+    want = cases.oracle_run(case, "f16")
+    assert float(want.astype(np.float32).max()) > 0
+    _check(case, got, want, "fp16 out_scale %g via %s" % (scale, kname), kname)
+
+
 def _plan_forward(hip, dev, case, algo):
     """Drive the C-ABI directly with a forced algorithm."""
     d = pkg.ConvDesc()
@@ -314,7 +331,7 @@ sys.path.insert(0, %(tests)r)
 import numpy as np
 import cases
 from cases import pkg
-fe = pkg.load_frontend("reference")          # genuine libshl_ref_x86.so, unmodified
+fe = cases.load_reference_frontend()          # genuine libshl_ref_x86.so, unmodified
 hip, opt = pkg.load_backend(fe)              # backend registers itself in slot CSINN_ASP (14)
 dev = cases.HipDevice(hip)
 bad = 0

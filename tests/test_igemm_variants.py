@@ -1,0 +1,111 @@
+"""The MFMA tile kernels behind BASELINE configs[2] (ResNet-50 3x3, batch 128) against the oracle.
+
+The automatic selection only reaches the block-tile kernels from >= 128 block tiles, which no small parity
+shape does.  Two nets close that hole:
+
+  * every implicit-GEMM variant is FORCED in a sub-process (the switches are read once per process) over
+    tests/forced_igemm_suite.py: ragged shapes, int8 exact + general scales (bit-exact vs oracle
+    formulation X), binary16 (1e-3), NHWC and NCHW (fused NCHW epilogue);
+  * the seven ResNet-50 3x3 shapes at their full batch-128 size, NHWC and NCHW, automatic selection: the
+    plan must pick a block-tile MFMA kernel; sampled images are compared with the oracle bit for bit, more
+    sampled images with their own single-image run (no cross-image leakage in the M tiling), and the whole
+    batch through a linear checksum identity (the output of the all-(zp_in) image is the requantised bias,
+    so every image's interior must differ from it somewhere -- a never-written tile would show up as the
+    poison value the output buffer was filled with).
+
+Reference: source/reference/convolution.c:91-139 (NCHW), :28-89 (NHWC), :370-400 (quantised wrapper).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+from cases import NCHW, NHWC, pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUITE = os.path.join(ROOT, "tests", "forced_igemm_suite.py")
+
+# (environment, substring the chosen kernel's name must contain)
+VARIANTS = [
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="128", SHL_MI355X_PIPE="0"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="128", SHL_MI355X_PIPE="4"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="128", SHL_MI355X_PIPE="8"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x64", SHL_MI355X_PIPE="0", SHL_MI355X_HALO="0"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x64", SHL_MI355X_PIPE="4", SHL_MI355X_HALO="0"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x128"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x256"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="128", SHL_MI355X_HALO="1"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x64", SHL_MI355X_HALO="1"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x128", SHL_MI355X_HALO="1"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile"), "tile"),                      # the tile kernel's own automatic flavour choice
+    (dict(SHL_MI355X_IGEMM="regs"), "regs"),
+]
+
+
+def _id(v):
+    return "-".join("%s=%s" % (k.replace("SHL_MI355X_", ""), val) for k, val in sorted(v[0].items()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", VARIANTS, ids=[_id(v) for v in VARIANTS])
+def test_forced_igemm_variant_is_bit_exact(variant):
+    extra, expect = variant
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SHL_MI355X_")}
+    env.update(extra)
+    env["SHL_EXPECT_KERNEL"] = expect
+    res = subprocess.run([sys.executable, "-m", "pytest", SUITE, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-2000:]
+    assert " passed" in res.stdout
+
+
+# ---- BASELINE configs[2] at its own size ---------------------------------------------------------------
+RESNET_3X3 = [dict(c=64, co=64, h=56, w=56), dict(c=128, co=128, h=56, w=56, stride=(2, 2)),
+              dict(c=128, co=128, h=28, w=28), dict(c=256, co=256, h=28, w=28, stride=(2, 2)),
+              dict(c=256, co=256, h=14, w=14), dict(c=512, co=512, h=14, w=14, stride=(2, 2)),
+              dict(c=512, co=512, h=7, w=7)]
+BLOCK_TILE_KERNELS = ("tile", "p8", "halo")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    fe = pkg.load_frontend("standalone")
+    hip, opt = pkg.load_backend(fe)
+    if hip.shl_mi355x_device_count() < 1:
+        pytest.fail("no gfx950 device visible: " + hip.shl_mi355x_last_error().decode())
+    return fe, hip, opt, cases.HipDevice(hip)
+
+
+def _one_image(case, i):
+    return dict(case, n=1, input=np.ascontiguousarray(case["input"][i:i + 1]), in_shape=(1,) + tuple(case["in_shape"][1:]),
+                out_shape=(1,) + tuple(case["out_shape"][1:]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [NHWC, NCHW])
+@pytest.mark.parametrize("idx", range(len(RESNET_3X3)), ids=["%d_%d_at%d" % (s["c"], s["co"], s["h"]) for s in RESNET_3X3])
+def test_resnet50_3x3_batch128_full_size(gpu, idx, layout):
+    fe, hip, opt, dev = gpu
+    batch = 128
+    case = cases.make_case(9100 + idx, n=batch, layout=layout, act=1, **RESNET_3X3[idx])
+    kept = []
+    got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+    kname = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
+    assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
+    assert "igemm" in kname and any(k in kname for k in BLOCK_TILE_KERNELS), \
+        "batch-128 ResNet-50 3x3 must run on a block-tile MFMA kernel, the plan chose " + kname
+    # (1) oracle, bit for bit, on sampled images (first, last, two inside: tiles straddle image boundaries)
+    for i in (0, 41, 86, batch - 1):
+        want = cases.oracle_run(_one_image(case, i), "exact")
+        n, worst = cases.mismatch_report(got[i:i + 1], want)
+        assert n == 0, "%s image %d via %s: %d mismatches vs the oracle (max %d)" % (layout, i, kname, n, worst)
+    # (2) more images against their own single-image run through the product (a different kernel at M/128)
+    for i in (1, 63, 64, 100, 126):
+        single = cases.csinn_run(fe, pkg.API_MI355X, _one_image(case, i), device=dev)
+        assert np.array_equal(single, got[i:i + 1]), "%s image %d differs from its single-image run" % (layout, i)
+    # (3) every image was written: a batch output is never constant over an image (random inputs)
+    flat = got.reshape(batch, -1)
+    assert np.all(flat.max(axis=1) != flat.min(axis=1))

@@ -84,7 +84,7 @@ import sys
 sys.path.insert(0, %r)
 import numpy as np, cases, tail
 from cases import pkg
-fe = pkg.load_frontend("reference")
+fe = cases.load_reference_frontend()
 rng = np.random.default_rng(3)
 bad = 0
 for i in range(12):
@@ -201,7 +201,7 @@ sys.path.insert(0, %(tests)r)
 import numpy as np
 import cases, tail
 from cases import pkg
-fe = pkg.load_frontend("reference")          # genuine libshl_ref_x86.so: its own gref builds the graph
+fe = cases.load_reference_frontend()          # genuine libshl_ref_x86.so: its own gref builds the graph
 hip, opt = pkg.load_backend(fe)
 bad = 0
 for dtype, layout in (("int8", "NHWC"), ("f16", "NCHW")):

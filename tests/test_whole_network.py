@@ -1,0 +1,164 @@
+"""Whole-network parity for BASELINE configs[1] and configs[3]: the 28 MobileNetV1 layers of
+example/c906_mobilenetv1_f16.c:20-27,1888-1947 CHAINED through the oracle and through the HIP path.
+
+  * int8 NHWC batch 1 (configs[1]): every layer's output of the HIP chain -- with the default graph rewrite
+    (pointwise + the depthwise layer consuming it = one launch) and with every layer its own launch -- must
+    equal the oracle chain bit for bit (exact regime: the reference's fp32 arithmetic is exact, formulation
+    R == X), i.e. errors cannot hide behind a self-comparison.  The same network through
+    csinn_session_setup / csinn_session_run (global_avgpool2d + classifier + softmax included) is compared
+    with the oracle's replay of the whole model.
+  * binary16 NCHW batch 1 (configs[3], the c906 example's own dtype and layout, real layer shapes): every
+    layer's HIP output against the oracle applied to the HIP chain's OWN input of that layer (1e-3
+    relative, north_star's fp16 bar, layer by layer), plus the end-to-end drift of the free-running chains.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import cases
+import golden_util
+import tail
+from cases import pkg
+
+wl = importlib.import_module("csi-nn2_amd.workloads")
+
+SEED = 1234
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    fe = pkg.load_frontend("standalone")
+    hip, opt = pkg.load_backend(fe)
+    if hip.shl_mi355x_device_count() < 1:
+        pytest.fail("no gfx950 device visible: " + hip.shl_mi355x_last_error().decode())
+    return fe, hip, opt, cases.HipDevice(hip)
+
+
+def layer_case(L, ops, dtype, layout, x):
+    """cases.py problem description of workloads layer L with the chain's seeded operands"""
+    case = cases.make_case(1, layout=layout, dtype=dtype, n=x.shape[0], h=L["h"], w=L["w"], c=L["cin"], co=L["cout"],
+                           k=(L["k"], L["k"]), stride=(L["stride"],) * 2, pad=(L["pad"],) * 4, depthwise=L["depthwise"],
+                           act=1 if L["act"] else 0)
+    case["input"], case["kernel"], case["bias"] = np.ascontiguousarray(x), ops["kernel"], ops["bias"]
+    assert tuple(case["in_shape"]) == tuple(x.shape) and tuple(case["w_shape"]) == tuple(ops["kernel"].shape)
+    if dtype == "int8":
+        case["in_scale"], case["in_zp"] = ops["in_scale"], ops["in_zp"]
+        case["k_scale"] = np.array([ops["k_scale"]], dtype=np.float32)
+        case["b_scale"] = (np.float32(ops["in_scale"]) * case["k_scale"]).astype(np.float32)
+        case["out_scale"], case["out_zp"] = ops["out_scale"], ops["out_zp"]
+    return case
+
+
+def chain_inputs(chain):
+    """the synthetic tensors LayerChain uploaded for layers that do not consume their predecessor"""
+    out = {}
+    for i, e in enumerate(chain.entries):
+        if i == 0 or e["d_in"] != chain.entries[i - 1]["d_out"]:
+            rng = np.random.default_rng(chain_seed(chain) + 1000 + i)
+            out[i] = (rng.integers(-64, 64, e["in_dims"], dtype=np.int8) if chain.dtype == "int8"
+                      else rng.standard_normal(e["in_dims"]).astype(np.float16))
+    return out
+
+
+def chain_seed(chain):
+    return SEED
+
+
+def run_chain(gpu, dtype, layout, fuse):
+    fe, hip, opt, dev = gpu
+    chain = wl.LayerChain(fe, hip, opt, wl.MOBILENETV1, 1, dev.alloc, dev.upload, dtype=dtype, layout=layout, seed=SEED,
+                          chained=True, fuse=fuse)
+    opt.shl_mi355x_set_stream(None)
+    chain.run_eager()
+    ends = {u[-1] for u in chain.units}  # layers whose output reaches HBM (a fused pair keeps its middle tensor on chip)
+    outs = {}
+    for i, e in enumerate(chain.entries):
+        if i in ends:
+            outs[i] = dev.download(e["d_out"], e["out_dims"], np.int8 if dtype == "int8" else np.float16)
+    return chain, outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused_pairs", "one_launch_per_layer"])
+def test_mobilenetv1_int8_nhwc_chain_equals_the_oracle_chain(gpu, fuse):
+    chain, outs = run_chain(gpu, "int8", "NHWC", fuse)
+    assert len(chain.units) == (15 if fuse else 28)
+    feeds = chain_inputs(chain)
+    cur = None
+    checked = 0
+    for i, e in enumerate(chain.entries):
+        x = feeds[i] if i in feeds else cur
+        case = layer_case(e["layer"], dict(e["ops"], in_scale=e["in_scale"], in_zp=e["in_zp"]), "int8", "NHWC", x)
+        cur = cases.oracle_run(case, "ref")              # formulation R: the reference's own arithmetic
+        if i in outs:
+            n, worst = cases.mismatch_report(outs[i], cur)
+            assert n == 0, "layer %d (%s via %s): %d mismatches vs the oracle CHAIN (max %d)" % (
+                i, wl.layer_name(e["layer"]), e["kernel_name"], n, worst)
+            checked += 1
+    assert checked == len(chain.units)
+    chain.release()
+
+
+@pytest.mark.gpu
+def test_mobilenetv1_fp16_nchw_chain_layer_by_layer(gpu):
+    """configs[3]: the c906 example's shapes, dtype and layout.  Layer i of the HIP chain is checked against
+    the oracle fed with the HIP chain's own layer-(i-1) output, so the 1e-3 bar applies to every layer on
+    its own; the free-running oracle chain bounds the accumulated drift."""
+    chain, outs = run_chain(gpu, "f16", "NCHW", False)
+    feeds = chain_inputs(chain)
+    free = None
+    for i, e in enumerate(chain.entries):
+        x_gpu = feeds[i] if i in feeds else outs[i - 1]
+        ops = e["ops"]
+        want = cases.oracle_run(layer_case(e["layer"], ops, "f16", "NCHW", x_gpu), "f16")
+        assert np.isfinite(want.astype(np.float32)).all()
+        golden_util.compare_f16_tol(outs[i], want, "fp16 NCHW layer %d (%s via %s)" % (i, wl.layer_name(e["layer"]), e["kernel_name"]))
+        x_free = feeds[i] if i in feeds else free
+        free = cases.oracle_run(layer_case(e["layer"], ops, "f16", "NCHW", x_free), "f16")
+        g, f = outs[i].astype(np.float64), free.astype(np.float64)
+        drift = np.abs(g - f).max() / max(1e-6, np.abs(f).max())
+        assert drift < 2e-2, "layer %d: end-to-end drift %.3e of the tensor's range" % (i, drift)
+    chain.release()
+
+
+def oracle_whole_model(ms, x, dtype, layout, seed=99):
+    """Replays workloads.ModelSession (27 convs, global_avgpool2d, classifier, softmax) through the oracle."""
+    int8 = dtype == "int8"
+    nhwc = layout == "NHWC"
+    q = (2.0 ** -4, -5) if int8 else (1.0, 0)
+    cur = x
+    layers = wl.MOBILENETV1
+    for i, L in enumerate(layers):
+        if i == len(layers) - 1:
+            qp = (2.0 ** -4, -5) if int8 else (1.0, 0)
+            cur = tail.siso_oracle(dict(kind="pool", x=cur, dtype=dtype, layout=layout, axis=1, in_q=q, out_q=qp))
+            q = qp
+        o = wl.synth_layer_operands(L, seed + i, dtype, layout, q[0] if int8 else None)
+        ops = dict(o, in_scale=q[0], in_zp=q[1])
+        cur = cases.oracle_run(layer_case(L, ops, dtype, layout, cur), "ref" if int8 else "f16")
+        q = (o["out_scale"], o["out_zp"])
+    qs = (1.0 / 256, -128) if int8 else (1.0, 0)
+    return tail.siso_oracle(dict(kind="softmax", x=cur, dtype=dtype, layout=layout, axis=3 if nhwc else 1, in_q=q, out_q=qs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,layout", [("int8", "NHWC"), ("f16", "NCHW")])
+def test_mobilenetv1_session_equals_the_oracle_model(gpu, dtype, layout):
+    """csinn_session_setup + csinn_session_run on CSINN_MI355X (one hipGraph, fused pairs) against the
+    oracle's replay of the 30-layer model."""
+    fe, hip, opt, dev = gpu
+    ms = wl.ModelSession(fe, pkg.API_MI355X, dtype, layout)
+    assert opt.shl_mi355x_session_is_device_resident(ms.sess) == 2
+    for k in range(2):
+        x = ms.synthetic_input(k)
+        got = ms.run(x).reshape(-1)
+        want = oracle_whole_model(ms, x, dtype, layout).reshape(-1)
+        if dtype == "int8":
+            n, worst = cases.mismatch_report(got, want)
+            assert worst <= 1 and n <= 2, "softmax output: %d mismatches (max %d)" % (n, worst)   # device exp vs glibc
+            assert int(np.argmax(got)) == int(np.argmax(want))
+        else:
+            g, w = got.astype(np.float64), want.astype(np.float64)
+            assert np.abs(g - w).max() <= 2e-2 * max(w.max(), 1e-6), "probabilities drift %.3e" % np.abs(g - w).max()
+    ms.close()
