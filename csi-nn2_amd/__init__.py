@@ -187,6 +187,8 @@ def load_hip():
         "shl_mi355x_graph_launch": (C.c_int, [vp, vp]),
         "shl_mi355x_graph_destroy": (C.c_int, [vp]),
         "shl_mi355x_conv_plan_create": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(vp)]),
+        "shl_mi355x_conv_plan_create_dw_channel": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, f32, f32, vp, C.POINTER(vp)]),
+        "shl_mi355x_debug_trace": (C.c_int, [vp, i32]),
         "shl_mi355x_conv_plan_destroy": (C.c_int, [vp]),
         "shl_mi355x_conv_plan_algo": (C.c_int, [vp]),
         "shl_mi355x_conv_plan_kernel_name": (C.c_char_p, [vp]),

@@ -58,6 +58,11 @@ struct ConvArgs {
     int32_t halo_px;      // halo kernel: capacity of one LDS patch buffer in pixels (multiple of 16)
     int32_t halo_pps;     // halo kernel: patch pieces a producer wave requests per K step
     const void *w_frag;   // pointwise int8: weights in MFMA fragment order [group][K/32][64][16 B], or null
+    // CSINN_OP_DEPTHWISE_CONV2D_CHANNEL (dwconv_channel.hip): acc_init = kernel zero points, mult = kernel
+    // scales, bias = RAW int32 bias (bit pattern), out_scale = the output record's float scale (relu step)
+    float ch_in_scale;    // input scale
+    float ch_out_scale;   // output scale from the record's multiplier / shift (shl_ref_get_scale)
+    int32_t ch_has_bias;
 };
 
 // The pad page is 4 KiB so that concurrent readers can be spread over 32 cache lines instead of
@@ -297,7 +302,8 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 bool igemm_supports(const shl_mi355x_conv_desc &d);
 const char *igemm_variant(int64_t M, int64_t Co);  // "tile" | "regs" | "wave"
-bool igemm_fuses_nchw_out(int64_t M, int64_t Co);   // the tile kernel stores NCHW itself
+const char *igemm_pick_name(const ConvArgs &a, int esize);  // + "pp": the kernel family launch_conv_igemm will use
+bool igemm_fuses_nchw_out(const ConvArgs &a, int esize);  // the block-tile kernels store NCHW themselves
 bool dwconv_supports(const shl_mi355x_conv_desc &d);
 bool dwconv_dot4_supports(const shl_mi355x_conv_desc &d);  // int8 3x3: weights packed [C][3 dwords]
 void dwconv_dot4_pack(const shl_mi355x_conv_desc &d, const int8_t *hwo, uint32_t *dst);
@@ -307,6 +313,7 @@ int launch_dwconv_mfma(const ConvArgs &a, hipStream_t s);
 // pointwise int8 NHWC with the weight slice in registers, for bandwidth-bound sizes (conv1x1_stream.hip)
 bool conv1x1_stream_pick(const ConvArgs &a);
 int launch_conv1x1_stream(const ConvArgs &a, hipStream_t s);
+int launch_dwconv_channel(const ConvArgs &a, hipStream_t s);  // dwconv_channel.hip
 bool stem_supports(const shl_mi355x_conv_desc &d);
 void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
 size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);

@@ -954,17 +954,40 @@ static const char *variant_override()
     return v ? v : "";
 }
 
-bool igemm_fuses_nchw_out(int64_t M, int64_t Co)
+// which kernel family runs problem `a`: "wave" | "regs" | "tile" | "pp"; *flavour = ping-pong tile flavour
+const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
+{
+    const char *ov = variant_override();
+    if (flavour) *flavour = -1;
+    const bool forced_pp = !strcmp(ov, "pp");
+    if (forced_pp || !ov[0]) {
+        const int f = pp_flavour(a, esize, forced_pp);
+        if (f >= 0) {
+            if (flavour) *flavour = f;
+            return "pp";
+        }
+        if (forced_pp) return "tile";  // shapes the ping-pong kernel does not take
+    }
+    return igemm_variant(a.M, a.Co);
+}
+
+const char *igemm_pick_name(const ConvArgs &a, int esize) { return igemm_pick(a, esize, nullptr); }
+
+bool igemm_fuses_nchw_out(const ConvArgs &a, int esize)
 {
     static const char *halo_env = getenv("SHL_MI355X_HALO");  // the halo kernel has no NCHW epilogue
     if (halo_env && halo_env[0] == '1') return false;
-    return !strcmp(igemm_variant(M, Co), "tile");
+    ConvArgs t = a;
+    t.out_nchw = 1;
+    const char *v = igemm_pick(t, esize, nullptr);
+    return !strcmp(v, "tile") || !strcmp(v, "pp");
 }
 
 const char *igemm_variant(int64_t M, int64_t Co)
 {
     const char *ov = variant_override();
-    if (ov[0]) return ov;
+    if (ov[0] && strcmp(ov, "pp")) return ov;
+    if (ov[0]) return "tile";
     // LDS tile kernel once there is at least ~one 128x128 tile for every other CU; below that
     // (MobileNetV1 at batch 1: 1-98 tiles) latency dominates and the barrier-free wave kernel wins
     const int64_t blocks128 = ((M + BM - 1) / BM) * ((Co + BN - 1) / BN);
@@ -975,11 +998,13 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
 {
     if (a.M == 0 || a.Co == 0) return SHL_MI355X_OK;
     (void)layout;  // the kernels see NHWC; NCHW callers were re-laid out by the plan
-    const char *v = igemm_variant(a.M, a.Co);
     const bool i8 = dtype == SHL_MI355X_I8;
-    if (i8 && !variant_override()[0] && conv1x1_stream_pick(a)) return launch_conv1x1_stream(a, s);
-    const int epi = i8 ? epi_code(a) : 0;
     const int esize = i8 ? 1 : 2;
+    if (i8 && !variant_override()[0] && conv1x1_stream_pick(a)) return launch_conv1x1_stream(a, s);
+    int ppf = -1;
+    const char *v = igemm_pick(a, esize, &ppf);
+    if (!strcmp(v, "pp")) return launch_conv_igemm_pp(a, dtype, ppf, s);
+    const int epi = i8 ? epi_code(a) : 0;
     dim3 grid;
     size_t lds = 0;
     int threads = 256;

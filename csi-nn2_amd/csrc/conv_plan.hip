@@ -10,7 +10,7 @@
 
 #include <vector>
 
-#include "common.h"
+#include "igemm_common.h"
 
 struct shl_mi355x_conv_plan {
     shl_mi355x_conv_desc desc;
@@ -25,6 +25,8 @@ struct shl_mi355x_conv_plan {
     // NCHW through the NHWC MFMA kernel: scratch images of the input and output, sized for
     // desc.batch at plan time (no allocation may happen inside a captured forward)
     char *scratch_in, *scratch_out;
+    float ch_in_scale, ch_out_scale;  // ALGO_DW_CHANNEL: input scale, output scale from multiplier / shift
+    int32_t ch_has_bias;
     int32_t kstride;   // igemm: packed row bytes
     int32_t kchunks;
     int32_t cchunks;
@@ -191,21 +193,25 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         p->kchunks = Kb / 16;
         p->cchunks = d.in_c * es / 16;
         w_bytes = (size_t)d.out_c * p->kstride;
-        const char *v = igemm_variant((int64_t)d.batch * d.out_h * d.out_w, d.out_c);
         const bool i8 = d.dtype == SHL_MI355X_I8;
+        ConvArgs probe = {};
+        probe.Kh = d.kernel_h, probe.Kw = d.kernel_w, probe.sh = d.stride_h, probe.sw = d.stride_w;
+        probe.pt = d.pad_top, probe.pl = d.pad_left, probe.H = d.in_h, probe.W = d.in_w, probe.Ho = d.out_h, probe.Wo = d.out_w;
+        probe.C = d.in_c, probe.Co = d.out_c, probe.kstride = p->kstride;
+        probe.M = (int32_t)((int64_t)d.batch * d.out_h * d.out_w);
+        probe.N = d.batch;
+        probe.out_nchw = d.layout == SHL_MI355X_NCHW && ((d.out_h * d.out_w * es) & 3) == 0;
+        const char *v = igemm_pick_name(probe, es);
         if (!strcmp(v, "wave"))
             p->kernel_name = i8 ? "conv_igemm_wave_i8_mfma32x32x32" : "conv_igemm_wave_f16_mfma32x32x16";
         else if (!strcmp(v, "regs"))
             p->kernel_name = i8 ? "conv_igemm_regs_i8_mfma32x32x32" : "conv_igemm_regs_f16_mfma32x32x16";
+        else if (!strcmp(v, "pp"))
+            p->kernel_name = i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
         else
             p->kernel_name = i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
         if (i8 && d.layout == SHL_MI355X_NHWC) {  // pointwise at bandwidth-bound sizes (conv1x1_stream.hip)
-            ConvArgs probe = {};
-            probe.Kh = d.kernel_h, probe.Kw = d.kernel_w, probe.sh = d.stride_h, probe.sw = d.stride_w;
-            probe.pt = d.pad_top, probe.pl = d.pad_left, probe.H = d.in_h, probe.W = d.in_w, probe.Ho = d.out_h, probe.Wo = d.out_w;
-            probe.C = d.in_c, probe.Co = d.out_c, probe.kstride = p->kstride;
             probe.w_frag = &probe;  // the copy is made below for exactly these shapes
-            probe.M = (int32_t)((int64_t)d.batch * d.out_h * d.out_w);
             if (conv1x1_stream_pick(probe)) p->kernel_name = "conv1x1_stream_i8_mfma32x32x32";
         }
     } else if (algo == SHL_MI355X_ALGO_STEM) {
@@ -341,6 +347,61 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     return SHL_MI355X_OK;
 }
 
+int shl_mi355x_conv_plan_create_dw_channel(const struct shl_mi355x_conv_desc *desc, const void *kernel_host,
+                                           const float *kernel_scale, const int32_t *kernel_zp,
+                                           const int32_t *bias_i32, float in_scale, float out_scale_ms,
+                                           void *stream, shl_mi355x_conv_plan **plan_out)
+{
+    if (!desc || !plan_out || !kernel_host || !kernel_scale || !kernel_zp) {
+        set_error("conv_plan_create_dw_channel: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    *plan_out = nullptr;
+    const shl_mi355x_conv_desc &d = *desc;
+    int rc = validate(d);
+    if (rc != SHL_MI355X_OK || d.layout != SHL_MI355X_NCHW || d.dtype != SHL_MI355X_I8 || d.group != d.in_c ||
+        !(out_scale_ms > 0.0f)) {
+        set_error("conv_plan_create_dw_channel: int8 NCHW depthwise descriptor with a positive output scale expected");
+        return rc != SHL_MI355X_OK ? rc : SHL_MI355X_EINVAL;
+    }
+    shl_mi355x_conv_plan *p = (shl_mi355x_conv_plan *)calloc(1, sizeof(*p));
+    if (!p) return SHL_MI355X_ENOMEM;
+    p->desc = d;
+    p->algo = SHL_MI355X_ALGO_DW_CHANNEL;
+    p->kernel_name = "dwconv_channel_nchw_i8_int64acc";
+    p->ch_in_scale = in_scale;
+    p->ch_out_scale = out_scale_ms;
+    p->ch_has_bias = bias_i32 != nullptr;
+    p->inv_out_scale = 1.0f / d.out_scale;
+    const size_t w_bytes = (size_t)d.out_c * d.kernel_h * d.kernel_w;
+    const size_t tab_bytes = align_up((size_t)d.out_c, 128) * 4;
+    p->off_w = 0;
+    p->off_acc = align_up(w_bytes, 256);
+    p->off_mult = p->off_acc + tab_bytes;
+    p->off_bias = p->off_mult + tab_bytes;
+    p->off_pad = p->off_bias + tab_bytes;
+    p->block_bytes = p->off_pad + PAD_PAGE_BYTES;
+    hipError_t e = hipMalloc((void **)&p->block, p->block_bytes);
+    if (e != hipSuccess) {
+        free(p);
+        return hip_fail(e, "hipMalloc(plan block)");
+    }
+    std::vector<char> host(p->block_bytes, 0);
+    memcpy(host.data() + p->off_w, kernel_host, w_bytes);
+    memcpy(host.data() + p->off_acc, kernel_zp, (size_t)d.out_c * 4);
+    memcpy(host.data() + p->off_mult, kernel_scale, (size_t)d.out_c * 4);
+    if (bias_i32) memcpy(host.data() + p->off_bias, bias_i32, (size_t)d.out_c * 4);
+    e = hipMemcpyAsync(p->block, host.data(), p->block_bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) {
+        (void)hipFree(p->block);
+        free(p);
+        return hip_fail(e, "upload(plan block)");
+    }
+    *plan_out = p;
+    return SHL_MI355X_OK;
+}
+
 int shl_mi355x_conv_plan_destroy(shl_mi355x_conv_plan *plan)
 {
     if (!plan) return SHL_MI355X_OK;
@@ -424,6 +485,9 @@ static int fill_args(const shl_mi355x_conv_plan *plan, const void *input_dev, vo
     a.clamp_lo = plan->clamp_lo;
     a.clamp_hi = plan->clamp_hi;
     a.pad_page = plan->block + plan->off_pad;
+    a.ch_in_scale = plan->ch_in_scale;
+    a.ch_out_scale = plan->ch_out_scale;
+    a.ch_has_bias = plan->ch_has_bias;
     {
         static const char *dbg = getenv("SHL_MI355X_DEBUG");
         a.debug = dbg ? atoi(dbg) : 0;
@@ -466,7 +530,7 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
             a.in = plan->scratch_in;
             // the tile kernel's epilogue stores NCHW itself; planes whose byte size is not a multiple of
             // 4 (7x7 int8) would fall to element stores there and are cheaper through the re-layout pass
-            if (igemm_fuses_nchw_out(a.M, a.Co) && ((a.Ho * a.Wo * es) & 3) == 0) {
+            if (igemm_fuses_nchw_out(a, es) && ((a.Ho * a.Wo * es) & 3) == 0) {
                 a.out_nchw = 1;
                 return launch_conv_igemm(a, d.dtype, SHL_MI355X_NHWC, s);
             }
@@ -480,10 +544,18 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
             return launch_dwconv(a, d.dtype, d.layout, s);
         case SHL_MI355X_ALGO_STEM:
             return launch_conv_stem(a, s);
+        case SHL_MI355X_ALGO_DW_CHANNEL:
+            return launch_dwconv_channel(a, s);
         default:
             return launch_conv_direct(a, d.dtype, d.layout,
                                       is_depthwise(d) && d.layout == SHL_MI355X_NHWC, s);
     }
+}
+
+int shl_mi355x_debug_trace(uint64_t *host, int32_t count)
+{
+    if (!host || count <= 0) return SHL_MI355X_EINVAL;
+    return pp_read_trace(reinterpret_cast<unsigned long long *>(host), count);
 }
 
 /* depthwise 3x3 + pointwise 1x1 fused into one launch (dwpw_fused.hip); 1 when the pair qualifies */

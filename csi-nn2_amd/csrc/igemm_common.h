@@ -99,6 +99,12 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb)
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
 }
 
+// ping-pong kernel for MFMA-bound layers (conv_igemm_pp.hip): flavour for a problem (-1: does not apply)
+int pp_flavour(const ConvArgs &a, int esize, bool forced);
+int launch_conv_igemm_pp(const ConvArgs &a, int dtype, int flavour, hipStream_t s);
+const char *igemm_pick(const ConvArgs &a, int esize, int *flavour);
+int pp_read_trace(unsigned long long *host, int count);
+
 // launchers of the halo-staged kernel (conv_igemm_halo.hip)
 bool halo_eligible(const ConvArgs &a, int esize);
 // returns SHL_MI355X_ENOTSUP when the patch does not fit the chosen tile (caller falls back)

@@ -357,6 +357,164 @@ int shl_mi355x_conv2d_exec(CSINN_CONV_ARGS)
     return run_plan(&params->base, input, output, input->dim[0], "conv2d");
 }
 
+
+/* ------------------------------------------------------------------------ CSINN_OP_*_CHANNEL op ids
+ * (source/reference/convolution_channel.c, registered at reference/setup.c:786-808).
+ * The reference registers only `exec` for them (no init), so exec builds the plan on first use when
+ * the caller never ran an init callback.  int8, NCHW only -- as the reference.
+ *
+ *  conv2d_channel   shl_ref_conv2d_channel_nchw_quant (:68-86): float path with the kernel dequantised
+ *                   per output channel and the bias as b * s_k[oc] * s_in (the bias tensor's own record
+ *                   is ignored, :58-66) -> the ordinary device plan with tables derived that way.
+ *  depthwise        shl_ref_depthwise_conv2d_channel_nchw_i8 (:172-255): int64 accumulation, raw int32
+ *                   bias, shl_ref_quantize_channel_i8 with the output record's multiplier / shift. */
+static int channel_desc(struct shl_mi355x_conv_desc *d, struct csinn_tensor *input, struct csinn_tensor *output,
+                        struct csinn_tensor *kernel, struct csinn_conv2d_params *params, int act, const char *what)
+{
+    memset(d, 0, sizeof(*d));
+    if (params->base.layout != CSINN_LAYOUT_NCHW) {
+        shl_debug_error("mi355x: %s supports NCHW only (as the reference)\n", what);
+        return CSINN_UNSUPPORT_LAYOUT;
+    }
+    if (input->dtype != CSINN_DTYPE_INT8 || kernel->dtype != CSINN_DTYPE_INT8 || output->dtype != CSINN_DTYPE_INT8) {
+        shl_debug_error("mi355x: %s supports int8 tensors only\n", what);
+        return CSINN_UNSUPPORT_DTYPE;
+    }
+    if (input->qinfo == NULL || output->qinfo == NULL || kernel->qinfo == NULL || input->quant_channel > 1 ||
+        output->quant_channel > 1 || kernel->quant_channel != kernel->dim[0]) {
+        shl_debug_error("mi355x: %s needs one record per activation tensor and one per output channel of the kernel\n", what);
+        return CSINN_UNSUPPORT_DTYPE;
+    }
+    d->layout = SHL_MI355X_NCHW;
+    d->dtype = SHL_MI355X_I8;
+    d->act = act;
+    d->batch = input->dim[0];
+    d->in_c = input->dim[1];
+    d->in_h = input->dim[2];
+    d->in_w = input->dim[3];
+    d->out_c = output->dim[1];
+    d->out_h = output->dim[2];
+    d->out_w = output->dim[3];
+    d->kernel_h = kernel->dim[2];
+    d->kernel_w = kernel->dim[3];
+    d->stride_h = params->stride_height;
+    d->stride_w = params->stride_width;
+    d->pad_top = params->pad_top;
+    d->pad_left = params->pad_left;
+    d->dilation_h = params->dilation_height > 0 ? params->dilation_height : 1;
+    d->dilation_w = params->dilation_width > 0 ? params->dilation_width : 1;
+    d->group = 1;
+    d->in_zp = input->qinfo->zero_point;
+    d->out_zp = output->qinfo->zero_point;
+    d->out_scale = output->qinfo->scale;
+    return CSINN_TRUE;
+}
+
+static int conv2d_channel_init_act(CSINN_CONV_ARGS, int act)
+{
+    struct shl_mi355x_conv_desc d;
+    int rc = channel_desc(&d, input, output, kernel, params, act, "conv2d_channel");
+    if (rc != CSINN_TRUE) return rc;
+    if (params->group != 1 || kernel->dim[1] != d.in_c) {
+        shl_debug_error("mi355x: conv2d_channel: grouped kernels go through GROUP_CONV2D_CHANNEL (not on the device)\n");
+        return CSINN_FALSE;
+    }
+    if (kernel->data == NULL || kernel->mtype == CSINN_MEM_TYPE_DMABUF) return CSINN_FALSE;
+    const int co = d.out_c;
+    for (int oc = 0; oc < co; oc++)
+        if (kernel->qinfo[oc].zero_point != 0) {
+            shl_debug_error("mi355x: conv2d_channel: asymmetric weights (zero point %d) are not supported\n",
+                            kernel->qinfo[oc].zero_point);
+            return CSINN_UNSUPPORT_DTYPE;
+        }
+    float *mult = shl_mem_alloc((int64_t)co * sizeof(float));
+    float *bias_f = shl_mem_alloc((int64_t)co * sizeof(float));
+    const int has_bias = bias != NULL && bias->dim_count != 0 && bias->data != NULL;
+    const float s_in = input->qinfo->scale;
+    for (int oc = 0; oc < co; oc++) {
+        mult[oc] = s_in * kernel->qinfo[oc].scale;
+        bias_f[oc] = 0.0f;
+        if (has_bias) { /* channel_bias_to_common: bias_data[i] * kernel->qinfo[i].scale * input->qinfo->scale */
+            float t = ((const int32_t *)bias->data)[oc] * kernel->qinfo[oc].scale;
+            bias_f[oc] = t * s_in;
+        }
+    }
+    shl_mi355x_conv_plan *plan = NULL;
+    int st = shl_mi355x_conv_plan_create(&d, kernel->data, mult, bias_f,
+                                         shl_mi355x_ctx_stream(shl_mi355x_ctx_of(params->base.sess)), &plan);
+    shl_mem_free(mult);
+    shl_mem_free(bias_f);
+    if (st != SHL_MI355X_OK) {
+        shl_debug_error("mi355x: conv2d_channel plan creation failed (%d): %s\n", st, shl_mi355x_last_error());
+        return CSINN_FALSE;
+    }
+    shl_mi355x_registry_put(params, plan);
+    return CSINN_TRUE;
+}
+
+static int dwconv_channel_init_act(CSINN_CONV_ARGS, int act)
+{
+    struct shl_mi355x_conv_desc d;
+    int rc = channel_desc(&d, input, output, kernel, params, act, "depthwise_conv2d_channel");
+    if (rc != CSINN_TRUE) return rc;
+    if (d.in_c < 1 || d.out_c % d.in_c != 0 || kernel->dim[1] != 1) {
+        shl_debug_error("mi355x: depthwise_conv2d_channel expects an O1HW kernel with Cout a multiple of Cin\n");
+        return CSINN_FALSE;
+    }
+    if (kernel->data == NULL || kernel->mtype == CSINN_MEM_TYPE_DMABUF) return CSINN_FALSE;
+    d.group = d.in_c;
+    const int co = d.out_c;
+    /* shl_ref_get_scale (source/reference/utils.c:132-137) */
+    const float out_scale_ms = (float)(output->qinfo->multiplier / pow(2, 31) * pow(2, output->qinfo->shift));
+    if (!(out_scale_ms > 0.0f)) {
+        shl_debug_error("mi355x: depthwise_conv2d_channel: the output record's multiplier / shift give scale %g\n",
+                        (double)out_scale_ms);
+        return CSINN_FALSE;
+    }
+    float *ks = shl_mem_alloc((int64_t)co * sizeof(float));
+    int32_t *kz = shl_mem_alloc((int64_t)co * sizeof(int32_t));
+    for (int oc = 0; oc < co; oc++) {
+        ks[oc] = kernel->qinfo[oc].scale;
+        kz[oc] = kernel->qinfo[oc].zero_point;
+    }
+    const int has_bias = bias != NULL && bias->dim_count != 0 && bias->data != NULL;
+    shl_mi355x_conv_plan *plan = NULL;
+    int st = shl_mi355x_conv_plan_create_dw_channel(&d, kernel->data, ks, kz, has_bias ? bias->data : NULL,
+                                                    input->qinfo->scale, out_scale_ms,
+                                                    shl_mi355x_ctx_stream(shl_mi355x_ctx_of(params->base.sess)), &plan);
+    shl_mem_free(ks);
+    shl_mem_free(kz);
+    if (st != SHL_MI355X_OK) {
+        shl_debug_error("mi355x: depthwise_conv2d_channel plan creation failed (%d): %s\n", st, shl_mi355x_last_error());
+        return CSINN_FALSE;
+    }
+    shl_mi355x_registry_put(params, plan);
+    return CSINN_TRUE;
+}
+
+static int channel_exec(CSINN_CONV_ARGS, int (*init_act)(CSINN_CONV_ARGS, int), int act, const char *what)
+{
+    if (shl_mi355x_registry_get(params) == NULL) { /* the reference's protocol for these ids has no init */
+        int rc = init_act(input, output, kernel, bias, params, act);
+        if (rc != CSINN_TRUE) return rc;
+    }
+    return run_plan(&params->base, input, output, input->dim[0], what);
+}
+
+#define CHANNEL_OP(stem, init_fn, act, what)                                                               \
+    int shl_mi355x_##stem##_init(CSINN_CONV_ARGS) { return init_fn(input, output, kernel, bias, params, act); } \
+    int shl_mi355x_##stem##_exec(CSINN_CONV_ARGS)                                                          \
+    {                                                                                                      \
+        return channel_exec(input, output, kernel, bias, params, init_fn, act, what);                      \
+    }
+CHANNEL_OP(conv2d_channel, conv2d_channel_init_act, SHL_MI355X_ACT_NONE, "conv2d_channel")
+CHANNEL_OP(conv2d_channel_relu, conv2d_channel_init_act, SHL_MI355X_ACT_RELU, "conv2d_channel_relu")
+CHANNEL_OP(conv2d_channel_relu6, conv2d_channel_init_act, SHL_MI355X_ACT_RELU6, "conv2d_channel_relu6")
+CHANNEL_OP(depthwise_conv2d_channel, dwconv_channel_init_act, SHL_MI355X_ACT_NONE, "depthwise_conv2d_channel")
+CHANNEL_OP(depthwise_conv2d_channel_relu, dwconv_channel_init_act, SHL_MI355X_ACT_RELU, "depthwise_conv2d_channel_relu")
+CHANNEL_OP(depthwise_conv2d_channel_relu6, dwconv_channel_init_act, SHL_MI355X_ACT_RELU6, "depthwise_conv2d_channel_relu6")
+#undef CHANNEL_OP
+
 /* ------------------------------------------------------------------------ fullyconnected
  * out[b, o] = sum_d in[b, d] * w[o, d] + bias[o]  ==  1x1 convolution over a
  * [batches, 1, 1, in_nodes] NHWC tensor (source/reference/fullyconnected.c:21-52). */

@@ -11,7 +11,7 @@
 #include "mi355x_internal.h"
 
 /* ------------------------------------------------------------------------ callback table */
-#define MI355X_CB_MAX 48
+#define MI355X_CB_MAX 64
 static struct {
     int key; /* op * CSINN_DTYPE_SIZE + dtype */
     struct csinn_callback cb;
@@ -422,6 +422,20 @@ void shl_target_init_mi355x(void)
         reg(dt, CSINN_OP_FULLYCONNECTED, shl_mi355x_fullyconnected_init,
             shl_mi355x_fullyconnected_exec, shl_gref_fullyconnected);
     }
+    /* the per-channel op ids exist for int8 only (reference/setup.c:786-808 registers them for every dtype,
+     * convolution_channel.c implements u8 / i8) */
+    reg(CSINN_DTYPE_INT8, CSINN_OP_CONV2D_CHANNEL, shl_mi355x_conv2d_channel_init, shl_mi355x_conv2d_channel_exec,
+        shl_gref_conv2d);
+    reg(CSINN_DTYPE_INT8, CSINN_OP_CONV2D_CHANNEL_RELU, shl_mi355x_conv2d_channel_relu_init,
+        shl_mi355x_conv2d_channel_relu_exec, shl_gref_conv2d_relu);
+    reg(CSINN_DTYPE_INT8, CSINN_OP_CONV2D_CHANNEL_RELU6, shl_mi355x_conv2d_channel_relu6_init,
+        shl_mi355x_conv2d_channel_relu6_exec, shl_gref_conv2d_relu6);
+    reg(CSINN_DTYPE_INT8, CSINN_OP_DEPTHWISE_CONV2D_CHANNEL, shl_mi355x_depthwise_conv2d_channel_init,
+        shl_mi355x_depthwise_conv2d_channel_exec, shl_gref_depthwise_conv2d);
+    reg(CSINN_DTYPE_INT8, CSINN_OP_DEPTHWISE_CONV2D_CHANNEL_RELU, shl_mi355x_depthwise_conv2d_channel_relu_init,
+        shl_mi355x_depthwise_conv2d_channel_relu_exec, shl_gref_depthwise_conv2d_relu);
+    reg(CSINN_DTYPE_INT8, CSINN_OP_DEPTHWISE_CONV2D_CHANNEL_RELU6, shl_mi355x_depthwise_conv2d_channel_relu6_init,
+        shl_mi355x_depthwise_conv2d_channel_relu6_exec, shl_gref_depthwise_conv2d_relu6);
     for (int i = 0; i < 2; i++) {
         reg(dts[i], CSINN_OP_RELU, NULL, shl_mi355x_relu_exec, shl_gref_relu);
         reg(dts[i], CSINN_OP_RELU6, NULL, shl_mi355x_relu6_exec, shl_gref_relu6);

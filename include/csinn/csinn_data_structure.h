@@ -123,9 +123,13 @@ enum csinn_op_enum {
     CSINN_OP_DEPTHWISE_CONV2D_RELU = 36,
     CSINN_OP_DEPTHWISE_CONV2D_RELU6 = 37,
     CSINN_OP_DEPTHWISE_CONV2D_CHANNEL = 38,
+    CSINN_OP_DEPTHWISE_CONV2D_CHANNEL_RELU = 39,
+    CSINN_OP_DEPTHWISE_CONV2D_CHANNEL_RELU6 = 40,
     CSINN_OP_GROUP_CONV2D = 42,
     CSINN_OP_GROUP_CONV2D_RELU = 43,
     CSINN_OP_GROUP_CONV2D_RELU6 = 44,
+    CSINN_OP_GROUP_CONV2D_CHANNEL = 45,
+    CSINN_OP_GROUP_CONV2D_CHANNEL_RELU = 46,
     CSINN_OP_FULLYCONNECTED = 71,
     CSINN_OP_GLOBAL_AVGPOOL2D = 74,
     CSINN_OP_RELU = 127,

@@ -62,7 +62,8 @@ enum shl_mi355x_algo {
     SHL_MI355X_ALGO_IGEMM = 2,  /* LDS-staged implicit GEMM on MFMA */
     SHL_MI355X_ALGO_DW = 3,     /* bandwidth-tuned depthwise kernel */
     SHL_MI355X_ALGO_GEMV = 4,   /* fullyconnected, small batch (reserved) */
-    SHL_MI355X_ALGO_STEM = 5    /* 3x3 conv with 3 input channels (image stem), v_dot4 */
+    SHL_MI355X_ALGO_STEM = 5,   /* 3x3 conv with 3 input channels (image stem), v_dot4 */
+    SHL_MI355X_ALGO_DW_CHANNEL = 6 /* CSINN_OP_DEPTHWISE_CONV2D_CHANNEL: int64 accumulation (plan_create_dw_channel) */
 };
 
 /* ------------------------------------------------------------------------------------
@@ -157,6 +158,29 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc,
                                 const void *kernel_host, const float *mult_host,
                                 const float *bias_host, void *stream,
                                 shl_mi355x_conv_plan **plan_out);
+/* Diagnostics: with SHL_MI355X_DEBUG bit 128 set, workgroup 0 of the ping-pong implicit-GEMM kernel
+ * (conv_igemm_pp.hip) records s_memtime at its phase boundaries; copies up to 1024 stamps to `host`
+ * (slots 0..511 wave 0, 512..1023 wave 4).  tools/pp_trace.py prints them. */
+int shl_mi355x_debug_trace(uint64_t *host, int32_t count);
+
+/*
+ * Plan for CSINN_OP_DEPTHWISE_CONV2D_CHANNEL{,_RELU,_RELU6} (int8, NCHW, kernel O1HW): the reference's one
+ * integer-accumulating convolution, shl_ref_depthwise_conv2d_channel_nchw_i8
+ * (source/reference/convolution_channel.c:172-255) + shl_ref_quantize_channel_i8
+ * (source/reference/utils.c:175-180, 205-210).
+ *   kernel_scale / kernel_zp   out_c per-channel records of the kernel tensor
+ *   bias_i32                   RAW int32 bias (added to the 64-bit accumulator unscaled), or NULL
+ *   in_scale                   the input record's float scale
+ *   out_scale_ms               the output scale the reference derives from the record's multiplier /
+ *                              shift (shl_ref_get_scale, utils.c:132-137); desc->out_scale stays the
+ *                              record's float scale, which the fused relu / relu6 step uses
+ * The plan runs through shl_mi355x_conv_forward / _destroy like any other.
+ */
+int shl_mi355x_conv_plan_create_dw_channel(const struct shl_mi355x_conv_desc *desc, const void *kernel_host,
+                                           const float *kernel_scale, const int32_t *kernel_zp,
+                                           const int32_t *bias_i32, float in_scale, float out_scale_ms,
+                                           void *stream, shl_mi355x_conv_plan **plan_out);
+
 int shl_mi355x_conv_plan_destroy(shl_mi355x_conv_plan *plan);
 /* the algorithm the plan resolved to (enum shl_mi355x_algo) and its kernel name */
 int shl_mi355x_conv_plan_algo(const shl_mi355x_conv_plan *plan);

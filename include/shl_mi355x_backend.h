@@ -51,6 +51,20 @@ const char *shl_mi355x_params_kernel_name(void *params);
 int shl_mi355x_conv2d_init(CSINN_CONV_ARGS);
 int shl_mi355x_conv2d_exec(CSINN_CONV_ARGS);
 int shl_mi355x_group_conv2d_exec(CSINN_CONV_ARGS);  /* selected by init when 1 < group < Cin */
+/* CSINN_OP_CONV2D_CHANNEL* / CSINN_OP_DEPTHWISE_CONV2D_CHANNEL* (int8 NCHW; source/reference/
+ * convolution_channel.c).  The reference registers no init for these ids: exec plans on first use. */
+int shl_mi355x_conv2d_channel_init(CSINN_CONV_ARGS);
+int shl_mi355x_conv2d_channel_exec(CSINN_CONV_ARGS);
+int shl_mi355x_conv2d_channel_relu_init(CSINN_CONV_ARGS);
+int shl_mi355x_conv2d_channel_relu_exec(CSINN_CONV_ARGS);
+int shl_mi355x_conv2d_channel_relu6_init(CSINN_CONV_ARGS);
+int shl_mi355x_conv2d_channel_relu6_exec(CSINN_CONV_ARGS);
+int shl_mi355x_depthwise_conv2d_channel_init(CSINN_CONV_ARGS);
+int shl_mi355x_depthwise_conv2d_channel_exec(CSINN_CONV_ARGS);
+int shl_mi355x_depthwise_conv2d_channel_relu_init(CSINN_CONV_ARGS);
+int shl_mi355x_depthwise_conv2d_channel_relu_exec(CSINN_CONV_ARGS);
+int shl_mi355x_depthwise_conv2d_channel_relu6_init(CSINN_CONV_ARGS);
+int shl_mi355x_depthwise_conv2d_channel_relu6_exec(CSINN_CONV_ARGS);
 int shl_mi355x_fullyconnected_init(struct csinn_tensor *input, struct csinn_tensor *output,
                                    struct csinn_tensor *weights, struct csinn_tensor *bias,
                                    struct csinn_fc_params *params);

@@ -467,6 +467,109 @@ int oracle_conv2d_i8_exact(const struct oracle_conv *c, const int8_t *input,
     return 0;
 }
 
+
+/* ------------------------------------------------------------------ CSINN_OP_*_CHANNEL ops
+ * Registered under their own op ids (source/reference/setup.c:786-808); NCHW only.
+ *
+ * oracle_conv2d_channel_i8 -- shl_ref_conv2d_channel_nchw_quant (convolution_channel.c:68-86): float path
+ *   with the kernel dequantised per OUTPUT CHANNEL, ((float)w - zp_k[oc]) * s_k[oc] (:31-56), the bias as
+ *   b * s_k[oc] * s_in (:58-66: the bias tensor's own record is ignored), shl_ref_conv2d_f32, then the ordinary
+ *   csinn_tensor_data_convert requantisation with the output's scale / zero point; the _RELU / _RELU6 ids run
+ *   csinn_relu / csinn_relu6 on the stored output in place (:315-337).  kernel_channels must be out_c. */
+int oracle_conv2d_channel_i8(const struct oracle_conv *c, const int8_t *input, const int8_t *kernel,
+                             const int32_t *bias, int8_t *output)
+{
+    if (c->layout != ORACLE_NCHW) return -4; /* CSINN_UNSUPPORT_LAYOUT */
+    if (c->group != 1 || c->kernel_channels != c->out_c) return -2;
+    const int64_t ni = in_elems(c), nw = kernel_elems(c), no = out_elems(c);
+    float *fi = malloc(sizeof(float) * (size_t)(ni > 0 ? ni : 1));
+    float *fw = malloc(sizeof(float) * (size_t)(nw > 0 ? nw : 1));
+    float *fo = malloc(sizeof(float) * (size_t)(no > 0 ? no : 1));
+    float *fb = c->has_bias ? malloc(sizeof(float) * (size_t)c->out_c) : NULL;
+    if (!fi || !fw || !fo || (c->has_bias && !fb)) return -3;
+    for (int64_t i = 0; i < ni; ++i) fi[i] = oracle_int8_to_float(input[i], c->in_zp, c->in_scale);
+    const int64_t per = nw / c->out_c;
+    for (int oc = 0; oc < c->out_c; ++oc)
+        for (int64_t j = 0; j < per; ++j)
+            fw[oc * per + j] = ((float)kernel[oc * per + j] - c->kernel_zp[oc]) * c->kernel_scale[oc];
+    if (c->has_bias)
+        for (int oc = 0; oc < c->out_c; ++oc) {
+            float t = bias[oc] * c->kernel_scale[oc];
+            fb[oc] = t * c->in_scale;
+        }
+    oracle_conv2d_f32(c, fi, fw, fb, fo);
+    for (int64_t i = 0; i < no; ++i) output[i] = oracle_float_to_int8(fo[i], c->out_scale, c->out_zp);
+    if (c->act != ORACLE_ACT_NONE)
+        oracle_relu_i8(output, output, no, c->out_scale, c->out_zp, c->out_scale, c->out_zp,
+                       c->act == ORACLE_ACT_RELU6);
+    free(fi); free(fw); free(fo); free(fb);
+    return 0;
+}
+
+/* shl_ref_get_scale (source/reference/utils.c:132-137) */
+static float get_scale_ms(int32_t multiplier, int32_t shift)
+{
+    float scale = multiplier / pow(2, 31) * pow(2, shift);
+    return scale;
+}
+
+/* shl_ref_quantize_channel_i8 + shl_ref_quantize_f32_to_i8 (source/reference/utils.c:175-180, 205-210):
+ * the 64-bit accumulator is passed as int32_t; out = data * s_in * s_k; the OUTPUT scale comes from the
+ * record's multiplier / shift, not from its float scale */
+static int8_t quantize_channel_i8(int32_t data, float in_scale, float wscale, int32_t multiplier, int32_t shift,
+                                  int32_t out_zp)
+{
+    float out = data * in_scale * wscale;
+    float scale = get_scale_ms(multiplier, shift);
+    float r = nearbyint(out / scale + out_zp);
+    return fmin(127, fmax(-128, r));
+}
+
+/* oracle_depthwise_conv2d_channel_i8 -- shl_ref_depthwise_conv2d_channel_nchw_i8 (convolution_channel.c:172-255):
+ *   the only integer-accumulating convolution of source/reference.  acc (int64) = sum over in-bounds taps of
+ *   (w - zp_k[oc]) * (q - zp_in), + the RAW int32 bias, then quantize_channel_i8.  The kernel is indexed as
+ *   the reference does after its O1HW -> "NHWC" transposition: element ((ic*Kh + ky)*Kw + kx) + m with
+ *   m = oc % multiplier, ic = oc / multiplier -- for depth multipliers > 1 that is NOT filter oc (restated
+ *   literally: identical results are the contract).  The _RELU / _RELU6 ids apply csinn_relu(6) on the stored
+ *   output with the record's FLOAT scale (:381-407). */
+int oracle_depthwise_conv2d_channel_i8(const struct oracle_conv *c, const int8_t *input, const int8_t *kernel,
+                                       const int32_t *bias, int32_t out_multiplier, int32_t out_shift,
+                                       int8_t *output)
+{
+    if (c->layout != ORACLE_NCHW) return -4;
+    if (c->in_c < 1 || c->out_c % c->in_c || c->kernel_channels != c->out_c) return -2;
+    const int mult = c->out_c / c->in_c;
+    for (int b = 0; b < c->batch; ++b)
+        for (int oy = 0; oy < c->out_h; ++oy)
+            for (int ox = 0; ox < c->out_w; ++ox)
+                for (int ic = 0; ic < c->in_c; ++ic)
+                    for (int m = 0; m < mult; ++m) {
+                        const int oc = m + ic * mult;
+                        const int x0 = ox * c->stride_w - c->pad_left;
+                        const int y0 = oy * c->stride_h - c->pad_top;
+                        int64_t acc = 0;
+                        for (int ky = 0; ky < c->kernel_h; ++ky)
+                            for (int kx = 0; kx < c->kernel_w; ++kx) {
+                                const int x = x0 + c->dilation_w * kx;
+                                const int y = y0 + c->dilation_h * ky;
+                                if (x < 0 || x >= c->in_w || y < 0 || y >= c->in_h) continue;
+                                int32_t input_val = input[idx_in(c, b, y, x, ic)];
+                                int32_t filter_val = kernel[((int64_t)ic * c->kernel_h + ky) * c->kernel_w + kx + m];
+                                acc += (filter_val - c->kernel_zp[oc]) * (input_val - c->in_zp);
+                            }
+                        if (c->has_bias) acc += bias[oc];
+                        output[idx_out(c, b, oy, ox, oc)] =
+                            quantize_channel_i8((int32_t)acc, c->in_scale, c->kernel_scale[oc], out_multiplier,
+                                                out_shift, c->out_zp);
+                    }
+    if (c->act != ORACLE_ACT_NONE) {
+        const int64_t no = out_elems(c);
+        oracle_relu_i8(output, output, no, c->out_scale, c->out_zp, c->out_scale, c->out_zp,
+                       c->act == ORACLE_ACT_RELU6);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ fp16 */
 
 static int differs_from_one(float s) { return fabsf(s - 1.0f) > 1.1920929e-07f; }

@@ -90,6 +90,16 @@ int oracle_conv2d_f16_ref(const struct oracle_conv *c, const int16_t *input,
 int oracle_conv2d_f32(const struct oracle_conv *c, const float *input, const float *kernel,
                       const float *bias, float *output);
 
+/* The CSINN_OP_*_CHANNEL op ids (source/reference/convolution_channel.c, registered at
+ * reference/setup.c:786-808; NCHW, kernel_channels == out_c): conv2d = float path with the kernel
+ * dequantised per output channel and the bias scaled by s_k[oc] * s_in; depthwise = int64 accumulation +
+ * shl_ref_quantize_channel_i8 with the output record's multiplier / shift. */
+int oracle_conv2d_channel_i8(const struct oracle_conv *c, const int8_t *input, const int8_t *kernel,
+                             const int32_t *bias, int8_t *output);
+int oracle_depthwise_conv2d_channel_i8(const struct oracle_conv *c, const int8_t *input, const int8_t *kernel,
+                                       const int32_t *bias, int32_t out_multiplier, int32_t out_shift,
+                                       int8_t *output);
+
 /* fullyconnected == conv over [batch,1,1,in]; provided for readability of the tests:
  * shl_ref_fullyconnected_quant (source/reference/fullyconnected.c:21-87) */
 int oracle_fullyconnected_i8_ref(int32_t batch, int32_t in_nodes, int32_t units,

@@ -351,3 +351,109 @@ def mismatch_report(a, b):
     b = np.asarray(b).astype(np.int32)
     diff = np.abs(a - b)
     return int((diff != 0).sum()), int(diff.max()) if diff.size else 0
+
+
+# ---------------------------------------------------------------------------------- CSINN_OP_*_CHANNEL ops
+# (source/reference/convolution_channel.c).  No csinn_* entry point exists for these op ids: a
+# caller maps the callback itself (shl_op_callback_map) and calls cb->exec, which is what these helpers do.
+OP_CONV2D_CHANNEL, OP_DEPTHWISE_CONV2D_CHANNEL = 31, 38   # + 1 relu, + 2 relu6
+
+
+def make_channel_case(seed, kind="conv", n=1, h=8, w=8, c=16, co=16, k=(3, 3), stride=(1, 1), pad=(1, 1, 1, 1),
+                      dilation=(1, 1), multiplier=1, act=0, exact=True, has_bias=True, kernel_zp=False):
+    """int8 NCHW problem with one kernel record per output channel.  kind: "conv" | "dw"."""
+    rng = np.random.default_rng(seed)
+    dw = kind == "dw"
+    if dw:
+        co = c * multiplier
+    case = make_case(seed, layout=NCHW, n=n, h=h, w=w, c=c, co=co, k=k, stride=stride, pad=pad, dilation=dilation,
+                     depthwise=dw, multiplier=multiplier, act=act, per_channel=True, exact=exact, has_bias=has_bias)
+    case["chan_kind"] = kind
+    case["k_zp"] = (rng.integers(-6, 7, co).astype(np.int32) if kernel_zp else np.zeros(co, dtype=np.int32))
+    if dw:
+        # raw int32 bias added to the accumulator (|acc| of a 3x3 depthwise tap sum is a few 10^4)
+        case["bias"] = rng.integers(-3000, 3001, (co,), dtype=np.int32)
+        # the OUTPUT scale of the depthwise op comes from the record's multiplier / shift
+        target = 3.0 * np.sqrt(case["kh"] * case["kw"]) * 37.0 * 18.5 * case["in_scale"] * float(case["k_scale"].mean()) / 127.0
+        if exact:
+            shift = int(np.ceil(np.log2(target))) + 1
+            mult = 1 << 30                                     # 0.5 * 2^shift: a power of two
+        else:
+            shift = int(np.floor(np.log2(target))) + 1
+            mult = int(rng.integers(1 << 30, (1 << 31) - 1))  # [0.5, 1) * 2^shift
+        case["out_multiplier"], case["out_shift"] = mult, shift
+        case["out_scale"] = float(np.float32(mult / 2.0 ** 31 * 2.0 ** shift))   # what a converter would store
+    return case
+
+
+def oracle_channel_run(case):
+    lib = oracle_lib()
+    keep = []
+    d = oracle_desc(case, keep)
+    inp, ker, bias = (np.ascontiguousarray(case[k]) for k in ("input", "kernel", "bias"))
+    out = np.zeros(case["out_shape"], dtype=np.int8)
+    if case["chan_kind"] == "conv":
+        rc = lib.oracle_conv2d_channel_i8(C.byref(d), C.c_void_p(inp.ctypes.data), C.c_void_p(ker.ctypes.data),
+                                          C.c_void_p(bias.ctypes.data), C.c_void_p(out.ctypes.data))
+    else:
+        rc = lib.oracle_depthwise_conv2d_channel_i8(C.byref(d), C.c_void_p(inp.ctypes.data), C.c_void_p(ker.ctypes.data),
+                                                    C.c_void_p(bias.ctypes.data), C.c_int32(case["out_multiplier"]),
+                                                    C.c_int32(case["out_shift"]), C.c_void_p(out.ctypes.data))
+    assert rc == 0, "oracle returned %d" % rc
+    return out
+
+
+def csinn_channel_run(fe, api, case, device=None, call_init=True, keep_params=None):
+    """shl_op_callback_map(CSINN_OP_*_CHANNEL*) + cb->init (if any) + cb->exec through front-end `fe`."""
+    keep = pkg.Keep()
+    sess = pkg.layer_session(fe, api, keep)
+    dw = case["chan_kind"] == "dw"
+    out = np.zeros(case["out_shape"], dtype=np.int8)
+    dev_in = dev_out = None
+    if device is not None:
+        dev_in = device.alloc(case["input"].nbytes)
+        device.upload(dev_in, case["input"])
+        dev_out = device.alloc(out.nbytes)
+    t_in = pkg.make_tensor(fe, keep, case["in_shape"], pkg.DTYPE_INT8, pkg.LAYOUT_NCHW, data=case["input"],
+                           scales=(case["in_scale"],), zps=(case["in_zp"],), name=b"input", sess=sess, device_ptr=dev_in)
+    t_out = pkg.make_tensor(fe, keep, case["out_shape"], pkg.DTYPE_INT8, pkg.LAYOUT_NCHW, data=out,
+                            scales=(case["out_scale"],), zps=(case["out_zp"],), name=b"output", sess=sess,
+                            device_ptr=dev_out)
+    if dw:
+        t_out.contents.qinfo[0].multiplier = case["out_multiplier"]
+        t_out.contents.qinfo[0].shift = case["out_shift"]
+    t_w = pkg.make_tensor(fe, keep, case["w_shape"], pkg.DTYPE_INT8, pkg.LAYOUT_O1HW if dw else pkg.LAYOUT_OIHW,
+                          data=case["kernel"], scales=tuple(case["k_scale"]), zps=tuple(int(z) for z in case["k_zp"]),
+                          is_const=1, name=b"kernel", sess=sess)
+    if case["has_bias"]:
+        t_b = pkg.make_tensor(fe, keep, (case["co"],), pkg.DTYPE_INT32, pkg.LAYOUT_O, data=case["bias"],
+                              scales=tuple(case["b_scale"]), zps=(0,), is_const=1, name=b"bias", sess=sess)
+    else:
+        t_b = pkg.make_tensor(fe, keep, (), pkg.DTYPE_INT32, pkg.LAYOUT_O, name=b"bias", sess=sess)
+    params = pkg.conv_params(fe, keep, api, pkg.LAYOUT_NCHW, case["stride"], case["pad"], case["dilation"],
+                             case["c"] if dw else 1, 0, sess)
+    op = (OP_DEPTHWISE_CONV2D_CHANNEL if dw else OP_CONV2D_CHANNEL) + case["act"]
+    fe.shl_op_callback_map.restype = C.c_int
+    fe.shl_op_callback_map.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    rc = fe.shl_op_callback_map(params, op, pkg.DTYPE_INT8)
+    if rc != pkg.CSINN_TRUE:
+        raise pkg.MI355XError("shl_op_callback_map(op %d) returned %d" % (op, rc))
+    cb = C.cast(params, C.POINTER(pkg.Conv2dParams)).contents.base.cb.contents
+    tp = C.POINTER(pkg.Tensor)
+    fn_t = C.CFUNCTYPE(C.c_int, tp, tp, tp, tp, C.c_void_p)
+    if call_init and cb.init:
+        rc = fn_t(cb.init)(t_in, t_out, t_w, t_b, params)
+        if rc != pkg.CSINN_TRUE:
+            raise pkg.MI355XError("init of op %d returned %d" % (op, rc))
+    if not cb.exec:
+        raise pkg.MI355XError("op %d has no exec callback" % op)
+    rc = fn_t(cb.exec)(t_in, t_out, t_w, t_b, params)
+    if rc != pkg.CSINN_TRUE:
+        raise pkg.MI355XError("exec of op %d returned %d" % (op, rc))
+    if device is not None:
+        out = device.download(dev_out, out.shape, out.dtype)
+        device.free(dev_in)
+        device.free(dev_out)
+    if keep_params is not None:
+        keep_params.append((params, keep))
+    return out

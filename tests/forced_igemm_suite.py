@@ -41,7 +41,20 @@ SHAPES = [
 ]
 F16_IDX = [0, 3, 4, 7, 10, 14, 16]
 
-EXPECT = os.environ.get("SHL_EXPECT_KERNEL", "")
+EXPECT = os.environ.get("SHL_EXPECT_KERNEL", "")          # the forced kernel family ...
+FALLBACK = os.environ.get("SHL_EXPECT_FALLBACK", "")      # ... or, for shapes it does not take, this one
+EXPECT_MIN = int(os.environ.get("SHL_EXPECT_MIN", "1"))   # cases that must have run on the forced family
+SEEN = {"expected": 0, "fallback": 0}
+
+
+def _note(kname):
+    if not EXPECT:
+        return
+    if EXPECT in kname:
+        SEEN["expected"] += 1
+    else:
+        assert FALLBACK and FALLBACK in kname, "expected a %s kernel, the plan chose %s" % (EXPECT, kname)
+        SEEN["fallback"] += 1
 
 
 @pytest.fixture(scope="module")
@@ -68,8 +81,7 @@ def _run(gpu, case):
 def test_forced_variant_int8_equals_formulation_x(gpu, idx, exact, layout):
     case = cases.make_case(8000 + idx, exact=exact, layout=layout, **SHAPES[idx])
     got, kname = _run(gpu, case)
-    if EXPECT:
-        assert EXPECT in kname, "expected a %s kernel, the plan chose %s" % (EXPECT, kname)
+    _note(kname)
     want = cases.oracle_run(case, "exact")
     count, worst = cases.mismatch_report(got, want)
     assert count == 0, "shape %d %s via %s: %d mismatches vs formulation X (max %d)" % (idx, layout, kname, count, worst)
@@ -85,6 +97,11 @@ def test_forced_variant_fp16_within_tolerance(gpu, idx, layout):
         kw["act"] = 1
     case = cases.make_case(8500 + idx, dtype="f16", layout=layout, **kw)
     got, kname = _run(gpu, case)
-    if EXPECT:
-        assert EXPECT in kname, "expected a %s kernel, the plan chose %s" % (EXPECT, kname)
+    _note(kname)
     golden_util.compare_f16_tol(got, cases.oracle_run(case, "f16"), "fp16 shape %d %s via %s" % (idx, layout, kname))
+
+
+def test_zz_the_forced_family_was_exercised():
+    """runs last (file order): the forced kernel family must have taken its share of the cases"""
+    if EXPECT:
+        assert SEEN["expected"] >= EXPECT_MIN, SEEN

@@ -42,6 +42,13 @@ VARIANTS = [
     (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x128", SHL_MI355X_HALO="1"), "tile"),
     (dict(SHL_MI355X_IGEMM="tile"), "tile"),                      # the tile kernel's own automatic flavour choice
     (dict(SHL_MI355X_IGEMM="regs"), "regs"),
+    # ping-pong kernel (conv_igemm_pp.hip): automatic flavour and every flavour forced; shapes it does not take
+    # (K tiles straddling taps, Cout * esize % 16 != 0) fall back to the tile kernel
+    (dict(SHL_MI355X_IGEMM="pp"), "pp"),
+    (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x256"), "pp"),
+    (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x128"), "pp"),
+    (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x128k64"), "pp"),
+    (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x128x2"), "pp"),
 ]
 
 
@@ -56,6 +63,8 @@ def test_forced_igemm_variant_is_bit_exact(variant):
     env = {k: v for k, v in os.environ.items() if not k.startswith("SHL_MI355X_")}
     env.update(extra)
     env["SHL_EXPECT_KERNEL"] = expect
+    if expect == "pp":
+        env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "30"
     res = subprocess.run([sys.executable, "-m", "pytest", SUITE, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
                          capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-2000:]

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Phase timeline of the ping-pong implicit-GEMM kernel (conv_igemm_pp.hip) on ONE layer.
+
+    SHL_MI355X_DEBUG=128 [SHL_MI355X_IGEMM=pp SHL_MI355X_PP=256x128] python tools/pp_trace.py --layer 4 --batch 128
+Workgroup 0 stamps s_memtime at its phase boundaries (wave 0 = group 0, wave 4 = group 1); this prints the
+deltas in shader cycles: prologue, first-DMA wait, then per period [fragment reads issued | LDS wait | barrier |
+MFMA section with its DMA pieces | DMA certify | barrier] (group 1 certifies before its first barrier), and the epilogue.
+"""
+import argparse
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layer", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--periods", type=int, default=6)
+    a = ap.parse_args()
+    import cases
+    pkg = cases.pkg
+    wl = importlib.import_module("csi-nn2_amd.workloads")
+    fe = pkg.load_frontend("standalone")
+    hip, opt = pkg.load_backend(fe)
+    dev = cases.HipDevice(hip)
+    chain = wl.LayerChain(fe, hip, opt, [wl.RESNET50_3X3[a.layer]], a.batch, dev.alloc, dev.upload, chained=False)
+    for _ in range(3):
+        chain.run_layer(0)
+    hip.shl_mi355x_stream_sync(None)
+    buf = (C.c_uint64 * 1024)()
+    pkg.check(hip.shl_mi355x_debug_trace(buf, 1024), hip, "debug_trace")
+    t = np.array(buf[:], dtype=np.uint64).astype(np.int64)
+    print(wl.layer_name(chain.entries[0]["layer"]), chain.entries[0]["kernel_name"])
+    for g, base in ((0, 0), (1, 512)):
+        s = t[base:base + 512]
+        n = int((s != 0).sum())
+        if n < 6:
+            print("group %d: no trace (is SHL_MI355X_DEBUG=128 set and the layer on the pp kernel?)" % g)
+            continue
+        d = np.diff(s[:n])
+        per = 6
+        print("group %d: %d stamps, total %d cycles" % (g, n, s[n - 1] - s[0]))
+        print("  address setup %d | ring fill + tables %d | wait tile 0 + barrier %d" % (d[0], d[1], d[2]))
+        body = d[3:]
+        names = (["reads", "ldswait", "barrier", "mfma+dma", "certify", "barrier"] if g == 0 else
+                 ["reads", "ldswait", "certify", "barrier", "mfma+dma", "barrier"])
+        nper = (len(body) - 1) // per
+        for p in list(range(min(a.periods, nper))) + ([nper - 1] if nper > a.periods else []):
+            row = body[p * per:(p + 1) * per]
+            print("  period %2d: " % p + "  ".join("%s %5d" % (nm, v) for nm, v in zip(names, row)) + "   = %d" % row.sum())
+        allp = body[:nper * per].reshape(nper, per)
+        print("  mean     : " + "  ".join("%s %5d" % (nm, v) for nm, v in zip(names, allp.mean(axis=0))) +
+              "   = %d per period, %d periods" % (allp.sum(axis=1).mean(), nper))
+        print("  tail (epilogue etc.): %s" % list(body[nper * per:]))
+
+
+if __name__ == "__main__":
+    main()
