@@ -13,6 +13,11 @@ one hipGraph so that the timed region contains no host work.  Batch-1 inference 
 with N GPUs every rank runs its own replica on its own image ("replicas only", weak scaling); the
 only communication is the one-time RCCL broadcast of rank 0's packed weights.
 
+Timing: W untimed warm-up steps, then WINDOWS (default 7) windows of exactly K steps each, every window
+bracketed by barrier + synchronisation on both sides and reduced with MAX over ranks; `ms_per_step` /
+`value` are the MEDIAN window (one 20-step window of a 75 us step is 1.5 ms: a single sample of that
+length is at the mercy of one scheduler hiccup), all windows are listed in `windows_ms`.
+
 The JSON line also carries
   roofline     -- the dominant kernel function of the step (largest share of GPU time), its
                   algorithmic bytes per launch over its average launch duration measured with HIP
@@ -21,8 +26,13 @@ The JSON line also carries
   cpu_baseline -- the reference C backend (kind "reference": the genuine library built by
                   oracle/Makefile.ref, or kind "port": this repo's oracle) timed on the host cores
                   on a bounded sample of the same network;
-  extra        -- the ResNet-50 3x3 set at batch 128 (BASELINE configs[2], MFMA-bound) when
-                  --extra is given.
+  configs      -- (N = 1 runs) the other single-GPU configurations of BASELINE.json, each with its own
+                  roofline: configs[2] ResNet-50 3x3 set int8 batch 128 in NCHW (as BASELINE names it)
+                  and in NHWC, against the int8 MFMA peak; configs[3] MobileNetV1 binary16 NCHW batch 1
+                  (c906_mobilenetv1_f16 shapes).  --no-configs skips them; --extra adds serving views.
+
+--workload resnet50_3x3 --total-batch 1024 is BASELINE configs[4]: the batch is SHARDED over the ranks
+(sharding.shard_batch: 128 images per GPU at N = 8), weights broadcast once from rank 0.
 """
 import argparse
 import ctypes as C
@@ -52,7 +62,11 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 1 mobilenetv1, 128 resnet50_3x3)")
     ap.add_argument("--dtype", default="int8", choices=["int8", "f16"])
     ap.add_argument("--layout", default="", choices=["", "NHWC", "NCHW"])
-    ap.add_argument("--extra", action="store_true", help="also time the ResNet-50 3x3 set at batch 128")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="total batch sharded over the ranks (BASELINE configs[4]: resnet50_3x3 --total-batch 1024)")
+    ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each (median reported)")
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip the configs[2] / configs[3] entries")
+    ap.add_argument("--extra", action="store_true", help="serving views: concurrent streams, csinn_session_run end to end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true", help="every layer its own launch (no pointwise+depthwise fusion)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -252,6 +266,12 @@ def main():
     else:
         layers, batch, chained, bound = wl.RESNET50_3X3, args.batch or 128, False, "mfma"
         layout = args.layout or "NHWC"
+    sharded = args.total_batch > 0
+    if sharded:  # BASELINE configs[4]: one batch cut into contiguous per-rank slices (no data-path collective)
+        lo, hi = par.shard_batch(args.total_batch, world, rank)
+        batch = hi - lo
+        if batch == 0:
+            raise SystemExit("rank %d owns no image of a total batch of %d" % (rank, args.total_batch))
     # the graph-level rewrite csinn_session_setup applies on this backend (session.c plan_fusion):
     # pointwise + the depthwise layer that consumes it = one launch
     fuse = chained and args.dtype == "int8" and layout == "NHWC" and not args.no_fuse
@@ -259,8 +279,9 @@ def main():
     # receive rank 0's packed blocks over RCCL before they can agree with it
     chain = wl.LayerChain(fe, hip, opt, layers, batch, hbm.alloc, hbm.upload, dtype=args.dtype, layout=layout,
                           seed=1234 if rank == 0 else 999 + rank, chained=chained, fuse=fuse)
+    bcast = None
     if world > 1:
-        par.broadcast_plan_blocks(chain, torch, dist, hip, src=0)
+        bcast = par.broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c=not single_dev)
         par.assert_replicas_agree(chain, torch, dist, hip)
 
     stream = hip.shl_mi355x_stream_create()
@@ -268,37 +289,49 @@ def main():
     for _ in range(args.warmup):
         chain.replay()
     hip.shl_mi355x_stream_sync(stream)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        chain.replay()
-    hip.shl_mi355x_stream_sync(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    windows = []
+    for _ in range(max(1, args.windows)):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            chain.replay()
+        hip.shl_mi355x_stream_sync(stream)
+        torch.cuda.synchronize()
+        w = time.perf_counter() - t0
+        if dist:
+            dist.barrier()
+            t = torch.tensor([w], dtype=torch.float64, device="cpu" if single_dev else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+        windows.append(w)
+    elapsed = float(np.median(windows))
 
-    images = world * batch * args.steps
-    ops_per_step = chain.total_ops() * world
+    total_images = (args.total_batch if sharded else world * batch) * args.steps
+    ops_per_image = chain.total_ops() // batch
+    ops_total = ops_per_image * total_images
     result = {
         "metric": "mobilenetv1_int8_images_per_sec" if args.workload == "mobilenetv1" else "resnet50_3x3_int8_conv_gops",
-        "value": images / elapsed if args.workload == "mobilenetv1" else ops_per_step * args.steps / elapsed / 1e9,
+        "value": total_images / elapsed if args.workload == "mobilenetv1" else ops_total / elapsed / 1e9,
         "unit": "img/s" if args.workload == "mobilenetv1" else "GOPS",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8" if args.dtype == "int8" else "f16", "data": "synthetic",
-        "conv_gops": ops_per_step * args.steps / elapsed / 1e9,
-        "images_per_sec": images / elapsed,
-        "config": {"workload": "%s %s %s, %d conv layers in %d launches%s, batch %d per GPU, hipGraph replay via csinn_* C API"
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if sharded else "weak",
+        "vs_baseline": None, "dtype": "i8" if args.dtype == "int8" else "f16", "data": "synthetic",
+        "conv_gops": ops_total / elapsed / 1e9,
+        "images_per_sec": total_images / elapsed,
+        "windows_ms": [w * 1e3 for w in windows],
+        "timing": "median of %d windows of %d steps, each bracketed by barrier + synchronise, MAX over ranks" % (
+            len(windows), args.steps),
+        "config": {"workload": "%s %s %s, %d conv layers in %d launches%s, batch %d per GPU%s, hipGraph replay via csinn_* C API"
                                % (args.workload, args.dtype, layout, len(layers), len(chain.units),
-                                  " (pointwise+depthwise pairs fused as csinn_session_setup does)" if len(chain.units) < len(layers) else "", batch),
-                   "per_gpu_batch": batch, "parallelism": "replicas x%d (batch shard, RCCL weight bcast)" % world,
-                   "ops_per_image": chain.total_ops() // batch, "algorithmic_bytes_per_image": chain.total_bytes() // batch,
+                                  " (pointwise+depthwise pairs fused as csinn_session_setup does)" if len(chain.units) < len(layers) else "",
+                                  batch, " (total batch %d sharded)" % args.total_batch if sharded else ""),
+                   "per_gpu_batch": batch,
+                   "parallelism": ("batch shard x%d" % world if sharded else "replicas x%d" % world) +
+                                  (" (weights broadcast once: %s)" % bcast if bcast else ""),
+                   "ops_per_image": ops_per_image, "algorithmic_bytes_per_image": chain.total_bytes() // batch,
                    "device": arch.value.decode(), "compute_units": cus.value},
     }
 
@@ -328,25 +361,45 @@ def main():
                 sys.stderr.write("%-52s %-32s %8.2f us %8.1f GB/s %8.2f TOP/s\n" % (
                     chain.unit_name(u), chain.unit_kernel_name(u), t * 1e6,
                     chain.unit_bytes(u) / t / 1e9, chain.unit_ops(u) / t / 1e12))
-        if args.extra and args.workload == "mobilenetv1":
-            # the other single-GPU configurations of BASELINE.json, per-layer graph timing (no chaining)
-            extras = [
-                ("resnet50 3x3 set int8 NHWC batch 128 (BASELINE configs[2] shapes, NHWC)", wl.RESNET50_3X3, 128, "int8", "NHWC", "mfma", 3),
-                ("resnet50 3x3 set int8 NCHW batch 128 (BASELINE configs[2])", wl.RESNET50_3X3, 128, "int8", "NCHW", "mfma", 3),
-                ("mobilenetv1 fp16 NCHW batch 1 (BASELINE configs[3], c906_mobilenetv1_f16 shapes)", wl.MOBILENETV1, 1, "f16", "NCHW", "hbm", 20),
-                ("mobilenetv1 int8 NHWC batch 128 (throughput view of configs[1]; every layer its own launch)", wl.MOBILENETV1, 128, "int8", "NHWC", "hbm", 3),
+        if world == 1 and args.workload == "mobilenetv1" and not args.no_configs:
+            # the other single-GPU configurations of BASELINE.json: per-layer graph timing (independent layers,
+            # every layer its own launch), each with the roofline of its dominant kernel
+            others = [
+                ("configs[2]", "resnet50 3x3 set int8 NCHW batch 128", wl.RESNET50_3X3, 128, "int8", "NCHW", "mfma", 3),
+                ("configs[2] (NHWC view)", "resnet50 3x3 set int8 NHWC batch 128", wl.RESNET50_3X3, 128, "int8", "NHWC", "mfma", 3),
+                ("configs[3]", "mobilenetv1 fp16 NCHW batch 1 (c906_mobilenetv1_f16 shapes)", wl.MOBILENETV1, 1, "f16", "NCHW", "hbm", 20),
             ]
-            result["extra"] = []
-            for name, layers_x, batch_x, dtype_x, layout_x, bound_x, reps_x in extras:
+            if args.extra:
+                others.append(("configs[1] (throughput view)", "mobilenetv1 int8 NHWC batch 128, every layer its own launch",
+                               wl.MOBILENETV1, 128, "int8", "NHWC", "hbm", 3))
+            result["configs"] = []
+            prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            for tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, reps_x in others:
                 hbm2 = TorchHBM(torch, torch.device("cuda", local_rank))
                 rc = wl.LayerChain(fe, hip, opt, layers_x, batch_x, hbm2.alloc, hbm2.upload, dtype=dtype_x,
                                    layout=layout_x, seed=4321, chained=False)
                 rt = time_groups(rc, hip, opt, stream, reps=reps_x)
-                rroof, _ = summarise_kernels(rc, wl, rt, bound_x)
+                rroof, rgroups = summarise_kernels(rc, wl, rt, bound_x)
+                wname = "resnet50_3x3" if layers_x is wl.RESNET50_3X3 else "mobilenetv1"
+                attach_traffic(rroof, os.path.join(prof, "traffic_%s_%s_%s_b%d.json" % (wname, dtype_x, layout_x, batch_x)))
                 unit = "GOPS" if dtype_x == "int8" else "GFLOPS"
-                result["extra"].append({"workload": name, unit.lower(): rc.total_ops() / sum(rt) / 1e9,
-                                        "images_per_sec": batch_x / sum(rt), "ms_per_pass": sum(rt) * 1e3,
-                                        "dtype": "u8" if dtype_x == "int8" else "f16", "roofline": rroof})
+                peak = I8_MFMA_PEAK_TOPS if dtype_x == "int8" else F16_MFMA_PEAK_TFLOPS
+                entry = {"baseline_config": tag, "workload": name, "metric": "conv_" + unit.lower(),
+                         "value": rc.total_ops() / sum(rt) / 1e9, "unit": unit,
+                         "images_per_sec": batch_x / sum(rt), "ms_per_pass": sum(rt) * 1e3,
+                         "dtype": "i8" if dtype_x == "int8" else "f16", "layers": len(layers_x),
+                         "mfma_frac_whole_set": rc.total_ops() / sum(rt) / 1e12 / peak,
+                         "roofline": rroof,
+                         "kernels": {k: {"launches": v["launches"], "us_total": v["time"] * 1e6,
+                                         "TOPs": v["ops"] / v["time"] / 1e12, "GBps": v["bytes"] / v["time"] / 1e9}
+                                     for k, v in rgroups.items()}}
+                result["configs"].append(entry)
+                if args.detail:
+                    sys.stderr.write("---- %s\n" % name)
+                    for u, t in enumerate(rt):
+                        sys.stderr.write("%-52s %-32s %8.2f us %8.1f GB/s %8.2f TOP/s\n" % (
+                            rc.unit_name(u), rc.unit_kernel_name(u), t * 1e6, rc.unit_bytes(u) / t / 1e9,
+                            rc.unit_ops(u) / t / 1e12))
                 rc.release()
                 del hbm2
         if args.extra and args.workload == "mobilenetv1":

@@ -189,6 +189,11 @@ def load_hip():
         "shl_mi355x_conv_plan_create": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(vp)]),
         "shl_mi355x_conv_plan_create_dw_channel": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, f32, f32, vp, C.POINTER(vp)]),
         "shl_mi355x_debug_trace": (C.c_int, [vp, i32]),
+        "shl_mi355x_comm_available": (C.c_int, []),
+        "shl_mi355x_comm_unique_id": (C.c_int, [vp]),
+        "shl_mi355x_comm_create": (C.c_int, [vp, i32, i32, C.POINTER(vp)]),
+        "shl_mi355x_comm_destroy": (C.c_int, [vp]),
+        "shl_mi355x_comm_bcast": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), i32, i32, vp]),
         "shl_mi355x_conv_plan_destroy": (C.c_int, [vp]),
         "shl_mi355x_conv_plan_algo": (C.c_int, [vp]),
         "shl_mi355x_conv_plan_kernel_name": (C.c_char_p, [vp]),
@@ -301,6 +306,8 @@ def load_backend(frontend):
         opt.shl_mi355x_session_stream.restype = C.c_void_p
         opt.shl_mi355x_session_set_stream.argtypes = [C.POINTER(Session), C.c_void_p]
         opt.shl_mi355x_session_set_stream.restype = None
+        opt.shl_mi355x_bcast_const_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
+                                                      C.POINTER(Session)]
         opt._typed = True
     # the dispatch tables exist after the first csinn_alloc_session (source/nn2/setup.c:77-84)
     s = frontend.csinn_alloc_session()

@@ -536,10 +536,12 @@ int pp_flavour(const ConvArgs &a, int esize, bool forced)
     if (want >= 0) return want;
     const int64_t m256 = ((int64_t)a.M + 255) / 256;
     if (forced) return a.Co > 128 && esize == 1 ? 0 : (cb % 128 == 0 ? 1 : 2);
-    // automatic: MFMA-bound shapes only (deep K), and enough 256-wide tiles to occupy the chip
+    // automatic (measured on the ResNet-50 3x3 set at batch 128, profiles/r02_notes.md): with at least ~1.2
+    // tiles of 256 x 128 per CU the two-workgroups-per-CU flavour wins (each workgroup's prologue, first DMA
+    // wait and epilogue -- 40-45 % of a tile's time -- overlap the other's K loop: 128->128 @28 33.0 -> 27.8 us);
+    // with one tile per CU or fewer the round-1 kernels are level or ahead and keep the layer
     if (a.kstride < 1024) return -1;
-    if (a.Co > 128 && esize == 1 && m256 * ((a.Co + 255) / 256) >= 192) return 0;
-    if (m256 * ((a.Co + 127) / 128) >= 160) return cb % 128 == 0 ? 1 : 2;
+    if (m256 * ((a.Co + 127) / 128) >= 300) return 3;
     return -1;
 }
 

@@ -94,6 +94,45 @@ def broadcast_plan_blocks(chain, torch, dist, hip, src=0):
     return n
 
 
+def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c=True):
+    """The one-time weight broadcast of `chain`.  Preferred: RCCL behind the C boundary -- rank `src` draws an
+    ncclUniqueId through the C-ABI, the 128 bytes travel over the process group that already exists (bootstrap
+    only), every rank creates the communicator and calls shl_mi355x_bcast_const_blocks (host code stays C, as
+    BASELINE north_star asks).  All ranks agree first on whether that path is usable; otherwise (no librccl,
+    or a gloo group on one device in the tests) the same bytes go through torch.distributed.  Returns a
+    description of the path taken."""
+    import ctypes as C
+    why = "disabled"
+    if prefer_c:
+        ok = torch.tensor([int(hip.shl_mi355x_comm_available())], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        why = "librccl not found on every rank"
+        if int(ok.item()) == 1:
+            uid = (C.c_ubyte * 128)()
+            if rank == src and hip.shl_mi355x_comm_unique_id(uid) != 0:
+                raise RuntimeError("ncclGetUniqueId failed: " + hip.shl_mi355x_last_error().decode())
+            t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+            dist.broadcast(t, src=src)
+            uid = (C.c_ubyte * 128)(*t.cpu().tolist())
+            comm = C.c_void_p()
+            rc = hip.shl_mi355x_comm_create(uid, rank, world, C.byref(comm))
+            good = torch.tensor([int(rc == 0)], dtype=torch.int32, device="cuda")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if int(good.item()) == 1:
+                n = len(chain.entries)
+                params = (C.c_void_p * n)(*[C.cast(e["params"], C.c_void_p) for e in chain.entries])
+                rc = opt.shl_mi355x_bcast_const_blocks(comm, params, n, src, chain.sess)
+                hip.shl_mi355x_comm_destroy(comm)
+                if rc != 1:
+                    raise RuntimeError("shl_mi355x_bcast_const_blocks failed: " + hip.shl_mi355x_last_error().decode())
+                return "RCCL ncclBroadcast behind the C-ABI (shl_mi355x_bcast_const_blocks), %d blocks in one group" % n
+            if comm:
+                hip.shl_mi355x_comm_destroy(comm)
+            why = "ncclCommInitRank failed on some rank: " + hip.shl_mi355x_last_error().decode()
+    n = broadcast_plan_blocks(chain, torch, dist, hip, src=src)
+    return "torch.distributed broadcast, %d buckets (%s)" % (n, why)
+
+
 def checksum_bytes(arr):
     return zlib.crc32(np.ascontiguousarray(arr).view(np.uint8).tobytes())
 

@@ -307,6 +307,34 @@ const char *shl_mi355x_params_kernel_name(void *params)
     return p ? shl_mi355x_conv_plan_kernel_name(p) : "";
 }
 
+/* One-time weight broadcast of a set of layers: the constant blocks of the plans attached to
+ * `params[0..n)` travel from rank `root` to every rank of `comm` (shl_mi355x_comm_create) as one RCCL
+ * group on the session's stream; returns once they have landed.  Every rank must have initialised the
+ * same layers (same shapes -> same block sizes); only the root's weights matter. */
+int shl_mi355x_bcast_const_blocks(void *comm, void **params, int32_t n, int32_t root, struct csinn_session *sess)
+{
+    if (n <= 0) return CSINN_TRUE;
+    void **blocks = calloc((size_t)n, sizeof(void *));
+    size_t *bytes = calloc((size_t)n, sizeof(size_t));
+    int rc = CSINN_TRUE;
+    for (int i = 0; i < n && rc == CSINN_TRUE; i++) {
+        blocks[i] = shl_mi355x_params_const_block(params[i], &bytes[i]);
+        if (blocks[i] == NULL) {
+            shl_debug_error("mi355x: bcast_const_blocks: layer %d has no device plan\n", i);
+            rc = CSINN_FALSE;
+        }
+    }
+    void *stream = shl_mi355x_session_stream(sess);
+    if (rc == CSINN_TRUE && (shl_mi355x_comm_bcast(comm, blocks, bytes, n, root, stream) != SHL_MI355X_OK ||
+                             shl_mi355x_stream_sync(stream) != SHL_MI355X_OK)) {
+        shl_debug_error("mi355x: weight broadcast failed: %s\n", shl_mi355x_last_error());
+        rc = CSINN_FALSE;
+    }
+    free(blocks);
+    free(bytes);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------ staging */
 static void *stage_buffer(struct shl_mi355x_ctx *c, int slot, size_t bytes)
 {

@@ -158,6 +158,24 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc,
                                 const void *kernel_host, const float *mult_host,
                                 const float *bias_host, void *stream,
                                 shl_mi355x_conv_plan **plan_out);
+/* ---- multi-GPU: the one collective of the path ---------------------------------
+ * The batch shards over the GPUs of a node with no collective on the data path; the only exchange is the
+ * one-time broadcast of the plans' constant blocks from the rank that packed the weights.  RCCL
+ * (ncclBroadcast over xGMI) behind the C-ABI; librccl.so is opened on first use, so single-GPU
+ * processes never load it.
+ *   comm_available   1 when librccl.so and its entry points were found
+ *   comm_unique_id   rank `root`: 128 opaque bytes (ncclUniqueId) to hand to every peer out of band
+ *   comm_create      collective over all ranks with the same 128 bytes -> opaque communicator
+ *   comm_bcast       blocks_dev[i] (bytes[i] bytes, same sizes on every rank) from `root` to all, enqueued on
+ *                    `stream` as ONE ncclGroup (a few large messages, not one collective per layer)
+ */
+int shl_mi355x_comm_available(void);
+int shl_mi355x_comm_unique_id(void *id128);
+int shl_mi355x_comm_create(const void *id128, int32_t rank, int32_t world, void **comm_out);
+int shl_mi355x_comm_destroy(void *comm);
+int shl_mi355x_comm_bcast(void *comm, void *const *blocks_dev, const size_t *bytes, int32_t count, int32_t root,
+                          void *stream);
+
 /* Diagnostics: with SHL_MI355X_DEBUG bit 128 set, workgroup 0 of the ping-pong implicit-GEMM kernel
  * (conv_igemm_pp.hip) records s_memtime at its phase boundaries; copies up to 1024 stamps to `host`
  * (slots 0..511 wave 0, 512..1023 wave 4).  tools/pp_trace.py prints them. */

@@ -44,6 +44,9 @@ int shl_mi355x_release_params(void *params);
 int shl_mi355x_live_plans(int64_t *hbm_bytes);
 /* device block of the plan attached to `params` (for the RCCL weight broadcast) */
 void *shl_mi355x_params_const_block(void *params, size_t *bytes);
+/* multi-GPU setup: RCCL broadcast of the layers' constant blocks from rank `root` over the
+ * communicator of shl_mi355x_comm_create (include/shl_mi355x.h); CSINN_TRUE once they have landed */
+int shl_mi355x_bcast_const_blocks(void *comm, void **params, int32_t n, int32_t root, struct csinn_session *sess);
 /* name of the HIP kernel the plan attached to `params` launches ("" if none) */
 const char *shl_mi355x_params_kernel_name(void *params);
 

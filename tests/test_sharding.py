@@ -79,3 +79,53 @@ def test_weight_broadcast_under_gloo_world_size_2(tmp_path):
     line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0]
     # 5 blocks, 8 KiB buckets: [300, 4096, 17, 1000] share one bucket, 70000 gets its own -> 2 collectives
     assert line == "RESULT ok=1 collectives=2 covered=1024", line
+
+
+def test_rccl_entry_points_without_a_gpu(built):
+    """The C-ABI side of the weight broadcast (csrc/comm_rccl.hip): librccl is opened on first use; bad
+    arguments and the absence of a device are reported, never a crash."""
+    import ctypes as C
+    from cases import pkg
+    hip = pkg.load_hip()
+    avail = hip.shl_mi355x_comm_available()
+    assert avail in (0, 1)
+    comm = C.c_void_p()
+    assert hip.shl_mi355x_comm_create(None, 0, 1, C.byref(comm)) in (-2, -3)       # EINVAL / ENOTSUP (no librccl)
+    if avail and hip.shl_mi355x_device_count() == 0:
+        uid = (C.c_ubyte * 128)()
+        assert hip.shl_mi355x_comm_create(uid, 0, 1, C.byref(comm)) != 0           # no device: refused loudly
+        assert b"device" in hip.shl_mi355x_last_error().lower()
+    assert hip.shl_mi355x_comm_destroy(None) == 0
+
+
+@pytest.mark.gpu
+def test_rccl_broadcast_behind_the_c_abi_single_rank():
+    """What one GPU can exercise of the N > 1 path: ncclGetUniqueId -> ncclCommInitRank(world 1) ->
+    shl_mi355x_bcast_const_blocks over the plans of two real layers -> destroy; the blocks must survive
+    bit for bit (a one-rank broadcast is the identity) and the layers must still compute correctly."""
+    import ctypes as C
+    import importlib
+    import numpy as np
+    from cases import pkg
+    wl = importlib.import_module("csi-nn2_amd.workloads")
+    fe = pkg.load_frontend("standalone")
+    hip, opt = pkg.load_backend(fe)
+    assert hip.shl_mi355x_comm_available() == 1, hip.shl_mi355x_last_error()
+    dev = cases.HipDevice(hip)
+    chain = wl.LayerChain(fe, hip, opt, wl.MOBILENETV1[1:3], 1, dev.alloc, dev.upload, chained=True)
+    before = []
+    for p, n in chain.const_blocks():
+        before.append(dev.download(p, (n,), np.uint8))
+    uid = (C.c_ubyte * 128)()
+    pkg.check(hip.shl_mi355x_comm_unique_id(uid), hip, "comm_unique_id")
+    comm = C.c_void_p()
+    pkg.check(hip.shl_mi355x_comm_create(uid, 0, 1, C.byref(comm)), hip, "comm_create")
+    n = len(chain.entries)
+    params = (C.c_void_p * n)(*[C.cast(e["params"], C.c_void_p) for e in chain.entries])
+    assert opt.shl_mi355x_bcast_const_blocks(comm, params, n, 0, chain.sess) == pkg.CSINN_TRUE, hip.shl_mi355x_last_error()
+    pkg.check(hip.shl_mi355x_comm_destroy(comm), hip, "comm_destroy")
+    for (p, nb), b in zip(chain.const_blocks(), before):
+        assert np.array_equal(dev.download(p, (nb,), np.uint8), b)
+    chain.run_eager()
+    hip.shl_mi355x_stream_sync(None)
+    chain.release()
