@@ -314,6 +314,8 @@ int launch_dwconv_mfma(const ConvArgs &a, hipStream_t s);
 bool conv1x1_stream_pick(const ConvArgs &a);
 int launch_conv1x1_stream(const ConvArgs &a, hipStream_t s);
 int launch_dwconv_channel(const ConvArgs &a, hipStream_t s);  // dwconv_channel.hip
+bool conv_gemv_pick(const ConvArgs &a, int esize);             // conv_gemv.hip: 1x1 on <= 8 pixels
+int launch_conv_gemv(const ConvArgs &a, int dtype, hipStream_t s);
 bool stem_supports(const shl_mi355x_conv_desc &d);
 void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
 size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);

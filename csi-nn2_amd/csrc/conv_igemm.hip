@@ -959,6 +959,7 @@ const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
 {
     const char *ov = variant_override();
     if (flavour) *flavour = -1;
+    if (!ov[0] && conv_gemv_pick(a, esize)) return "gemv";
     const bool forced_pp = !strcmp(ov, "pp");
     if (forced_pp || !ov[0]) {
         const int f = pp_flavour(a, esize, forced_pp);
@@ -975,8 +976,6 @@ const char *igemm_pick_name(const ConvArgs &a, int esize) { return igemm_pick(a,
 
 bool igemm_fuses_nchw_out(const ConvArgs &a, int esize)
 {
-    static const char *halo_env = getenv("SHL_MI355X_HALO");  // the halo kernel has no NCHW epilogue
-    if (halo_env && halo_env[0] == '1') return false;
     ConvArgs t = a;
     t.out_nchw = 1;
     const char *v = igemm_pick(t, esize, nullptr);
@@ -1001,6 +1000,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     const bool i8 = dtype == SHL_MI355X_I8;
     const int esize = i8 ? 1 : 2;
     if (i8 && !variant_override()[0] && conv1x1_stream_pick(a)) return launch_conv1x1_stream(a, s);
+    if (!variant_override()[0] && conv_gemv_pick(a, esize)) return launch_conv_gemv(a, dtype, s);
     int ppf = -1;
     const char *v = igemm_pick(a, esize, &ppf);
     if (!strcmp(v, "pp")) return launch_conv_igemm_pp(a, dtype, ppf, s);
@@ -1067,7 +1067,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         bool want_halo = halo_env && halo_env[0] == '1';
         // ... except its "resident" mode: Cout <= 64 with a K short enough for the whole weight tensor
         // to sit in the ring (ResNet-50 64->64 @56: 45 -> see notes), on unless SHL_MI355X_HALO=0
-        if (!halo_env && tile == T256x64 && a.Kh * a.Kw * (a.C * esize / BKB) <= 10 && !a.out_nchw) want_halo = true;
+        if (!halo_env && tile == T256x64 && a.Kh * a.Kw * (a.C * esize / BKB) <= 10) want_halo = true;
         const int halo_tile = tile == T128 ? 0 : tile == T256x64 ? 1 : tile == T256x128 ? 2 : -1;
         if (want_halo && halo_tile >= 0 && halo_eligible(a, esize)) {
             const int rc = launch_conv_igemm_halo(a, dtype, halo_tile, s);

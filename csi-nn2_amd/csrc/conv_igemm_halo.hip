@@ -87,7 +87,9 @@ struct HaloGeom {
     static constexpr int stage_bytes(int esize) { return NWAVES * 64 * (64 * esize + 16); }
 };
 
-template <bool kI8, int EPI, int MI, int WR, int WC, int NSTV>
+// kNchwOut: the output tensor is NCHW (the input is still NHWC scratch): its own instantiation, because the
+// transposing epilogue needs 35 registers more than the NHWC one and this kernel lives on occupancy
+template <bool kI8, int EPI, int MI, int WR, int WC, int NSTV, bool kNchwOut = false>
 __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvArgs a)
 {
     using G = HaloGeom<MI, WR, WC, NSTV>;
@@ -379,6 +381,15 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
     const int srow = lane / CPR, schunk = lane % CPR;
     const bool vec16 = ((a.Co * ESIZE) & 15) == 0;
     char *out = static_cast<char *>(a.out);
+    if constexpr (kNchwOut) {  // the shared staged epilogue, NCHW planes (igemm_common.h)
+#pragma unroll
+        for (int ih = 0; ih < MI / 2; ++ih)
+            igemm_store_block64_impl<kI8, EPI, true>(a, acc[2 * ih][0], acc[2 * ih][1], acc[2 * ih + 1][0], acc[2 * ih + 1][1], ws,
+                                                     pix0 + wc * 64, co0 + wr * 32 * MI + ih * 64,
+                                                     tab_acc + wr * 32 * MI + ih * 64, tab_mult + wr * 32 * MI + ih * 64,
+                                                     tab_bias + wr * 32 * MI + ih * 64, lane);
+        return;
+    }
 #pragma unroll
     for (int ih = 0; ih < MI / 2; ++ih) {  // 64 channels at a time; the region is wave-private
 #pragma unroll
@@ -531,7 +542,19 @@ int launch_conv_igemm_halo(const ConvArgs &a_in, int dtype, int tile, hipStream_
     }
 #define SHL_HALO_RING(MI, WRV, WCV) \
     if (nst == 4) { SHL_HALO_EPI(MI, WRV, WCV, 4) } else { SHL_HALO_EPI(MI, WRV, WCV, 6) }
-    if (tile == 1 && nst == 10) {
+    if (a.out_nchw && !(tile == 1 && nst == 10)) return SHL_MI355X_ENOTSUP;  // NCHW epilogue: resident geometry only
+    if (tile == 1 && nst == 10 && a.out_nchw) {
+        if (!i8) {
+            launch_halo<conv_igemm_halo_kernel<false, 0, 2, 1, 4, 10, true>>(grid, 512, lds, s, a);
+        } else switch (epi) {
+            case 0: launch_halo<conv_igemm_halo_kernel<true, 0, 2, 1, 4, 10, true>>(grid, 512, lds, s, a); break;
+            case 1: launch_halo<conv_igemm_halo_kernel<true, 1, 2, 1, 4, 10, true>>(grid, 512, lds, s, a); break;
+            case 2: launch_halo<conv_igemm_halo_kernel<true, 2, 2, 1, 4, 10, true>>(grid, 512, lds, s, a); break;
+            case 3: launch_halo<conv_igemm_halo_kernel<true, 3, 2, 1, 4, 10, true>>(grid, 512, lds, s, a); break;
+            case 4: launch_halo<conv_igemm_halo_kernel<true, 4, 2, 1, 4, 10, true>>(grid, 512, lds, s, a); break;
+            default: launch_halo<conv_igemm_halo_kernel<true, 5, 2, 1, 4, 10, true>>(grid, 512, lds, s, a); break;
+        }
+    } else if (tile == 1 && nst == 10) {
         SHL_HALO_EPI(2, 1, 4, 10)
     } else if (tile == 1) {
         SHL_HALO_RING(2, 1, 4)

@@ -206,6 +206,8 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             p->kernel_name = i8 ? "conv_igemm_wave_i8_mfma32x32x32" : "conv_igemm_wave_f16_mfma32x32x16";
         else if (!strcmp(v, "regs"))
             p->kernel_name = i8 ? "conv_igemm_regs_i8_mfma32x32x32" : "conv_igemm_regs_f16_mfma32x32x16";
+        else if (!strcmp(v, "gemv"))
+            p->kernel_name = i8 ? "conv_gemv_i8_dot4" : "conv_gemv_f16_fma";
         else if (!strcmp(v, "pp"))
             p->kernel_name = i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
         else

@@ -99,6 +99,127 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb)
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
 }
 
+// ---- epilogue of one 64-pixel x 64-channel block held by a wave as 2 x 2 MFMA tiles -----------------
+// acc[i][j]: i = 32-channel tile, j = 32-pixel tile; C/D layout: column (pixel) = lane & 31, row (channel)
+// = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// Staged through a wave-private LDS block so that every lane stores 16 contiguous bytes.
+template <bool kI8, int EPI, bool kNchw, typename Acc>
+__device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, const Acc &a00, const Acc &a01, const Acc &a10,
+                                               const Acc &a11, char *ws, int pix_first, int co_first,
+                                               const int32_t *tab_acc, const float *tab_mult, const float *tab_bias, int lane)
+{
+    constexpr int ESIZE = kI8 ? 1 : 2;
+    constexpr int ROW_B = 64 * ESIZE;
+    constexpr int PITCH = ROW_B + 16;
+    constexpr int CPR = ROW_B / 16;  // 16-byte chunks per staged row
+    constexpr int RPI = 64 / CPR;    // rows per store instruction
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int srow = lane / CPR, schunk = lane % CPR;
+    char *out = static_cast<char *>(a.out);
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const Acc &acc = i2 == 0 ? (j == 0 ? a00 : a01) : (j == 0 ? a10 : a11);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = i2 * 32 + 8 * g + 4 * fhalf;  // first of this lane's 4 channels within the 64
+                const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + c);
+                char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
+                char *dst_t = ws + c * PITCH + (j * 32 + frow) * ESIZE;  // NCHW output: [channel][pixel]
+                if constexpr (kI8) {
+                    const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + c);
+                    const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + c);
+                    const uint32_t pk = requant4_i8_t<EPI>(acc[4 * g + 0] + ai.x, acc[4 * g + 1] + ai.y, acc[4 * g + 2] + ai.z,
+                                                           acc[4 * g + 3] + ai.w, mu, bi, a);
+                    if constexpr (kNchw) {
+                        // 4 x 4 byte transposition across the four lanes of a quad (= four consecutive pixels):
+                        // lane k ends up with channel c + k of pixels 4q .. 4q+3 -- one dword store instead of
+                        // four byte stores (the staged NCHW epilogue was LDS-store-issue bound)
+                        const int k = lane & 3;
+                        const uint32_t v0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x00, 0xf, 0xf, true);
+                        const uint32_t v1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x55, 0xf, 0xf, true);
+                        const uint32_t v2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xaa, 0xf, 0xf, true);
+                        const uint32_t v3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xff, 0xf, 0xf, true);
+                        const uint32_t sel = 0x0c0c0000u | ((uint32_t)(4 + k) << 8) | (uint32_t)k;
+                        const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, sel);
+                        const uint32_t t23 = __builtin_amdgcn_perm(v3, v2, sel);
+                        *reinterpret_cast<uint32_t *>(ws + (c + k) * PITCH + j * 32 + (frow & ~3)) =
+                            __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+                    } else {
+                        *reinterpret_cast<uint32_t *>(dst) = pk;
+                    }
+                } else {
+                    const uint32_t h0 = finish_f16(acc[4 * g + 0], bi.x, a);
+                    const uint32_t h1 = finish_f16(acc[4 * g + 1], bi.y, a);
+                    const uint32_t h2 = finish_f16(acc[4 * g + 2], bi.z, a);
+                    const uint32_t h3 = finish_f16(acc[4 * g + 3], bi.w, a);
+                    if constexpr (kNchw) {
+                        *reinterpret_cast<uint16_t *>(dst_t) = (uint16_t)h0;
+                        *reinterpret_cast<uint16_t *>(dst_t + PITCH) = (uint16_t)h1;
+                        *reinterpret_cast<uint16_t *>(dst_t + 2 * PITCH) = (uint16_t)h2;
+                        *reinterpret_cast<uint16_t *>(dst_t + 3 * PITCH) = (uint16_t)h3;
+                    } else {
+                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                    }
+                }
+            }
+        }
+    // wave-local hand-over: the same wave wrote and reads; LDS operations complete in order
+    if constexpr (kNchw) {
+        // rows of the staging block are channels: a lane owns 16 bytes = 16 / ESIZE consecutive flat
+        // (n, oy, ox) pixels of one channel.  Widest store that can neither straddle an image nor be
+        // misaligned: 16 B when Ho*Wo*ESIZE % 16 == 0, else 4 B (the caller guarantees % 4 == 0)
+        constexpr int EPC = 16 / ESIZE;
+        const int hw = a.Ho * a.Wo;
+        const bool wide = ((hw * ESIZE) & 15) == 0;
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = it * RPI + srow;  // channel within the 64
+            const int oc = co_first + row;
+            const int p0 = pix_first + schunk * EPC;
+            const uint4 v = *reinterpret_cast<const uint4 *>(ws + row * PITCH + schunk * 16);
+            if (oc >= a.Co || p0 >= a.M) continue;
+            if (wide) {
+                const int n = p0 / hw, q = p0 - n * hw;
+                *reinterpret_cast<uint4 *>(out + (((int64_t)n * a.Co + oc) * hw + q) * ESIZE) = v;
+            } else {
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pk = p0 + k * (4 / ESIZE);
+                    if (pk >= a.M) break;
+                    const int n = pk / hw, q = pk - n * hw;
+                    *reinterpret_cast<uint32_t *>(out + (((int64_t)n * a.Co + oc) * hw + q) * ESIZE) = w4[k];
+                }
+            }
+        }
+    } else {
+        const int oc = co_first + schunk * (16 / ESIZE);
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = it * RPI + srow;
+            const int p = pix_first + row;
+            const uint4 v = *reinterpret_cast<const uint4 *>(ws + row * PITCH + schunk * 16);
+            if (p < a.M && oc < a.Co) *reinterpret_cast<uint4 *>(out + ((int64_t)p * a.Co + oc) * ESIZE) = v;
+        }
+    }
+}
+
+// the output layout is a launch constant: one wave-uniform branch, two straight-line bodies (a run-time test
+// per staged group cost the 64 -> 64 @56 layer 6 us of its 35)
+template <bool kI8, int EPI, typename Acc>
+__device__ __forceinline__ void igemm_store_block64(const ConvArgs &a, const Acc &a00, const Acc &a01, const Acc &a10,
+                                                    const Acc &a11, char *ws, int pix_first, int co_first,
+                                                    const int32_t *tab_acc, const float *tab_mult, const float *tab_bias,
+                                                    int lane)
+{
+    if (a.out_nchw)
+        igemm_store_block64_impl<kI8, EPI, true>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
+    else
+        igemm_store_block64_impl<kI8, EPI, false>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
+}
+
 // ping-pong kernel for MFMA-bound layers (conv_igemm_pp.hip): flavour for a problem (-1: does not apply)
 int pp_flavour(const ConvArgs &a, int esize, bool forced);
 int launch_conv_igemm_pp(const ConvArgs &a, int dtype, int flavour, hipStream_t s);

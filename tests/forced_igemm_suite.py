@@ -1,6 +1,6 @@
 """Parity suite for ONE forced implicit-GEMM variant (run by tests/test_igemm_variants.py in a sub-process).
 
-The variant switches (SHL_MI355X_IGEMM / _TILE / _PIPE / _HALO / _P8) are read once per process, so every
+The variant switches (SHL_MI355X_IGEMM / _TILE / _PIPE / _HALO / _PP) are read once per process, so every
 combination gets its own interpreter: `python -m pytest tests/forced_igemm_suite.py -m gpu` with the
 switches in the environment.  Every shape runs int8 in the exact regime AND with general scales (both must
 equal oracle formulation X bit for bit), in NHWC and in NCHW (NCHW planes of 64 / 196 / 784 elements take

@@ -37,7 +37,7 @@ def gpu(standalone):
 def _check(case, got, expected, what, kernel_name=""):
     if case["dtype"] == "int8":
         golden_util.compare(case, got, expected, what)
-    elif "igemm" in kernel_name:
+    elif "igemm" in kernel_name or "gemv" in kernel_name:
         golden_util.compare_f16_tol(got, expected, what)          # different summation order
     else:
         golden_util.compare(case, got, expected, what)            # reference order: bit-exact
@@ -143,6 +143,30 @@ def test_fp16_output_scale_with_fused_activation(gpu, kw, scale):
     want = cases.oracle_run(case, "f16")
     assert float(want.astype(np.float32).max()) > 0
     _check(case, got, want, "fp16 out_scale %g via %s" % (scale, kname), kname)
+
+
+GEMV_SHAPES = [dict(fc=True, n=1, c=1024, co=1000), dict(fc=True, n=8, c=2048, co=1000), dict(fc=True, n=3, c=48, co=7),
+               dict(c=1024, co=1000, k=(1, 1), pad=(0, 0, 0, 0), h=1, w=1), dict(c=64, co=130, k=(1, 1), pad=(0, 0, 0, 0), h=2, w=2, act=1),
+               dict(layout=NCHW, c=1024, co=1000, k=(1, 1), pad=(0, 0, 0, 0), h=1, w=1, n=2, per_channel=True), dict(fc=True, n=5, c=1040, co=33, act=0)]
+
+
+@pytest.mark.parametrize("idx", range(len(GEMV_SHAPES)))
+@pytest.mark.parametrize("dtype", ["int8", "f16"])
+def test_gemv_kernel_on_a_handful_of_pixels(gpu, idx, dtype):
+    """1x1 / fullyconnected on <= 8 pixels (csrc/conv_gemv.hip: MobileNetV1's classifier): int8 bit-exact vs the
+    oracle in both regimes, binary16 within 1e-3."""
+    kw = dict(GEMV_SHAPES[idx])
+    if dtype == "f16":
+        kw.pop("per_channel", None)
+    for exact in ((True, False) if dtype == "int8" else (True,)):
+        case = cases.make_case(5600 + idx, dtype=dtype, exact=exact, **kw)
+        got, kname = _run(gpu, case, device_tensors=True)
+        assert "gemv" in kname, kname
+        if dtype == "int8":
+            n, worst = cases.mismatch_report(got, cases.oracle_run(case, "exact"))
+            assert n == 0, "%s: %d mismatches (max %d)" % (kname, n, worst)
+        else:
+            golden_util.compare_f16_tol(got, cases.oracle_run(case, "f16"), "gemv f16 shape %d" % idx)
 
 
 def _plan_forward(hip, dev, case, algo):

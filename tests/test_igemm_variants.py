@@ -76,7 +76,7 @@ RESNET_3X3 = [dict(c=64, co=64, h=56, w=56), dict(c=128, co=128, h=56, w=56, str
               dict(c=128, co=128, h=28, w=28), dict(c=256, co=256, h=28, w=28, stride=(2, 2)),
               dict(c=256, co=256, h=14, w=14), dict(c=512, co=512, h=14, w=14, stride=(2, 2)),
               dict(c=512, co=512, h=7, w=7)]
-BLOCK_TILE_KERNELS = ("tile", "p8", "halo")
+BLOCK_TILE_KERNELS = ("tile", "pp", "halo")
 
 
 @pytest.fixture(scope="module")

@@ -129,3 +129,22 @@ def test_rccl_broadcast_behind_the_c_abi_single_rank():
     chain.run_eager()
     hip.shl_mi355x_stream_sync(None)
     chain.release()
+
+
+@pytest.mark.gpu
+def test_bench_shards_a_total_batch_over_two_ranks_on_one_device():
+    """BASELINE configs[4] in miniature: `bench.py --workload resnet50_3x3 --total-batch 10` under
+    torch.distributed.run with two ranks that share the box's single GPU (SHL_BENCH_SINGLE_DEVICE: gloo group,
+    torch broadcast).  Exercises shard_batch (5 + 5 images), the weight broadcast from rank 0 to a rank whose
+    plans were built from different weights, assert_replicas_agree, the barriers and the MAX-over-ranks timing."""
+    import json
+    env = dict(os.environ, SHL_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", "--workload", "resnet50_3x3",
+           "--total-batch", "10", "--steps", "2", "--warmup", "1", "--windows", "2", "--no-cpu-baseline", "--no-configs"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=cases.ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["per_gpu_batch"] == 5
+    assert "batch shard x2" in line["config"]["parallelism"] and "broadcast" in line["config"]["parallelism"]
+    assert line["value"] > 0 and len(line["windows_ms"]) == 2

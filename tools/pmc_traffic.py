@@ -20,6 +20,8 @@ import sys
 FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kernel name)
     ("conv_igemm_wave_kernel<true", "conv_igemm_wave_i8_mfma32x32x32"),
     ("conv_igemm_wave_kernel<false", "conv_igemm_wave_f16_mfma32x32x16"),
+    ("conv_igemm_pp_kernel<true", "conv_igemm_pp_i8_mfma32x32x32"),
+    ("conv_igemm_pp_kernel<false", "conv_igemm_pp_f16_mfma32x32x16"),
     ("conv_igemm_tile_kernel<true", "conv_igemm_tile_i8_mfma32x32x32"),
     ("conv_igemm_halo_kernel<true", "conv_igemm_tile_i8_mfma32x32x32"),
     ("conv_igemm_halo_kernel<false", "conv_igemm_tile_f16_mfma32x32x16"),
