@@ -54,6 +54,11 @@ struct ConvArgs {
     float clamp_hi;       //   r = rint(f / s_out) + zp_out before the conversion to int8
     int32_t debug;        // ablation switches for tools/kbench.py (SHL_MI355X_DEBUG): 1 skip K loop, 2 skip stores
     const void *pad_page; // PAD_PAGE_BYTES of HBM filled with the padding value (zp_in / 0)
+    // conv_igemm_pc.hip: per OUTPUT PIXEL p = (n, oy, ox), built once per plan (conv_plan.hip): .x = byte offset of
+    // input pixel (n, oy*sh - pt, ox*sw - pl) in the NHWC input (tap (0, 0); may lie outside the tensor),
+    // .y = valid ky bits | valid kx bits << 16.  Replaces ~1 000 cycles of index arithmetic per DMA piece in a
+    // prologue that nothing overlaps.
+    const int2 *pix_tab;
     int32_t out_nchw;     // igemm tile kernel: write the output tensor as NCHW (input is still NHWC)
     int32_t halo_px;      // halo kernel: capacity of one LDS patch buffer in pixels (multiple of 16)
     int32_t halo_pps;     // halo kernel: patch pieces a producer wave requests per K step

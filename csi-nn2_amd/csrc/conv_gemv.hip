@@ -47,12 +47,12 @@ __global__ __launch_bounds__(256) void conv_gemv_kernel(ConvArgs a)
                 if constexpr (kI8) {
                     acc_i[o] = __builtin_amdgcn_sdot4(x[d], wv[o][d], acc_i[o], false);
                 } else {
-                    // plain fp32 multiply-adds of the exactly widened halves (v_dot2c_f32_f16 returned sums that
-                    // were off by whole terms on gfx950 in this accumulate-chain form; 16 VALU per chunk is nothing here)
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    const h2 xa = __builtin_bit_cast(h2, x[d]), wa = __builtin_bit_cast(h2, wv[o][d]);
-                    acc_f[o] += (float)xa[0] * (float)wa[0];
-                    acc_f[o] += (float)xa[1] * (float)wa[1];
+                    // fp32 multiply-adds of the exactly widened halves.  The dwords go through scalar copies:
+                    // __builtin_bit_cast applied directly to a vector ELEMENT (x[d]) made hipcc 7.2 read element
+                    // 0 for every d (the loads even got overlapping destination registers)
+                    const uint32_t xu = (uint32_t)x[d], wu = (uint32_t)wv[o][d];
+                    acc_f[o] += f16_bits_to_float((uint16_t)(xu & 0xffffu)) * f16_bits_to_float((uint16_t)(wu & 0xffffu));
+                    acc_f[o] += f16_bits_to_float((uint16_t)(xu >> 16)) * f16_bits_to_float((uint16_t)(wu >> 16));
                 }
             }
     }

@@ -954,12 +954,21 @@ static const char *variant_override()
     return v ? v : "";
 }
 
-// which kernel family runs problem `a`: "wave" | "regs" | "tile" | "pp"; *flavour = ping-pong tile flavour
+// which kernel family runs problem `a`: "wave" | "regs" | "tile" | "pp" | "pc"; *flavour = tile flavour of pp / pc
 const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
 {
     const char *ov = variant_override();
     if (flavour) *flavour = -1;
     if (!ov[0] && conv_gemv_pick(a, esize)) return "gemv";
+    const bool forced_pc = !strcmp(ov, "pc");
+    if (forced_pc || !ov[0]) {
+        const int f = pc_flavour(a, esize, forced_pc);
+        if (f >= 0) {
+            if (flavour) *flavour = f;
+            return "pc";
+        }
+        if (forced_pc) return "tile";  // shapes the producer / consumer kernel does not take
+    }
     const bool forced_pp = !strcmp(ov, "pp");
     if (forced_pp || !ov[0]) {
         const int f = pp_flavour(a, esize, forced_pp);
@@ -979,13 +988,13 @@ bool igemm_fuses_nchw_out(const ConvArgs &a, int esize)
     ConvArgs t = a;
     t.out_nchw = 1;
     const char *v = igemm_pick(t, esize, nullptr);
-    return !strcmp(v, "tile") || !strcmp(v, "pp");
+    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc");
 }
 
 const char *igemm_variant(int64_t M, int64_t Co)
 {
     const char *ov = variant_override();
-    if (ov[0] && strcmp(ov, "pp")) return ov;
+    if (ov[0] && strcmp(ov, "pp") && strcmp(ov, "pc")) return ov;
     if (ov[0]) return "tile";
     // LDS tile kernel once there is at least ~one 128x128 tile for every other CU; below that
     // (MobileNetV1 at batch 1: 1-98 tiles) latency dominates and the barrier-free wave kernel wins
@@ -1004,6 +1013,11 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     int ppf = -1;
     const char *v = igemm_pick(a, esize, &ppf);
     if (!strcmp(v, "pp")) return launch_conv_igemm_pp(a, dtype, ppf, s);
+    if (!strcmp(v, "pc")) {
+        static const char *pcx_env = getenv("SHL_MI355X_PCX");  // "0": plain producer / consumer kernel (A/B)
+        if (pcx_applies(a) && !(pcx_env && pcx_env[0] == '0')) return launch_conv_igemm_pcx(a, dtype, ppf, s);
+        return launch_conv_igemm_pc(a, dtype, ppf, s);
+    }
     const int epi = i8 ? epi_code(a) : 0;
     dim3 grid;
     size_t lds = 0;
@@ -1050,13 +1064,13 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         // at most one block per CU anyway: spend the LDS on an 8-deep ring (512->512 @14 s2: 31 -> 27 us;
         // with more tiles the second block per CU is worth more than the deeper ring)
         if (tile == T128 && utap && (int64_t)((a.M + 127) / 128) * ((a.Co + 127) / 128) <= 256) pipe = 8;
-        if (pipe_env) pipe = pipe_env[0] == '8' ? 8 : (pipe_env[0] == '0' ? 0 : 4);
+        if (pipe_env) pipe = pipe_env[0] == '8' ? 8 : pipe_env[0] == '6' ? 6 : (pipe_env[0] == '0' ? 0 : 4);
         int tbm = 128, tbn = 128;
         switch (tile) {
             case T256x64: tbm = 256; tbn = 64; if (pipe) pipe = 4; lds = pipe ? TileGeom<2, 1, 4, 4>::LDS_B : TileGeom<2, 1, 4, 0>::LDS_B; break;
-            case T256x128: tbm = 256; tbn = 128; lds = TileGeom<4, 1, 4, 0>::LDS_B; pipe = 0; break;
+            case T256x128: tbm = 256; tbn = 128; pipe = pipe == 6 ? 6 : 0; lds = pipe ? TileGeom<4, 1, 4, 6>::LDS_B : TileGeom<4, 1, 4, 0>::LDS_B; break;
             case T256x256: tbm = 256; tbn = 256; lds = TileGeom<4, 2, 4, 0>::LDS_B; threads = 512; pipe = 0; break;
-            default: lds = pipe == 8 ? TileGeom<2, 2, 2, 8>::LDS_B : pipe ? TileGeom<2, 2, 2, 4>::LDS_B : TileGeom<2, 2, 2, 0>::LDS_B; break;
+            default: if (pipe == 6) pipe = 4; lds = pipe == 8 ? TileGeom<2, 2, 2, 8>::LDS_B : pipe ? TileGeom<2, 2, 2, 4>::LDS_B : TileGeom<2, 2, 2, 0>::LDS_B; break;
         }
         grid = dim3((unsigned)(((a.M + tbm - 1) / tbm) * ((a.Co + tbn - 1) / tbn)));
         if (pipe) threads *= 2;  // as many DMA waves as MFMA waves
@@ -1101,7 +1115,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     } else if (tile == T256x256) {
         SHL_TILE_P(4, 2, 4, true, 0)
     } else if (tile == T256x128) {
-        SHL_TILE_P(4, 1, 4, true, 0)
+        if (pipe == 6) { SHL_TILE_P(4, 1, 4, true, 6) } else { SHL_TILE_P(4, 1, 4, true, 0) }
     } else if (tile == T256x64) {
         if (utap) { SHL_TILE(2, 1, 4, true) } else { SHL_TILE(2, 1, 4, false) }
     } else if (pipe == 8 && utap) {

@@ -25,6 +25,7 @@ struct shl_mi355x_conv_plan {
     // NCHW through the NHWC MFMA kernel: scratch images of the input and output, sized for
     // desc.batch at plan time (no allocation may happen inside a captured forward)
     char *scratch_in, *scratch_out;
+    int2 *pix_tab;  // per output pixel: tap-(0,0) byte offset and tap validity masks (ConvArgs::pix_tab), or NULL
     float ch_in_scale, ch_out_scale;  // ALGO_DW_CHANNEL: input scale, output scale from multiplier / shift
     int32_t ch_has_bias;
     int32_t kstride;   // igemm: packed row bytes
@@ -187,6 +188,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     const int cpg = d.in_c / d.group;
     const size_t raw_w = (size_t)d.out_c * cpg * d.kernel_h * d.kernel_w * es;
     size_t w_bytes = raw_w;
+    bool want_pix_tab = false;
     if (algo == SHL_MI355X_ALGO_IGEMM) {
         const int Kb = d.kernel_h * d.kernel_w * d.in_c * es;
         p->kstride = (int32_t)align_up((size_t)Kb, 64);
@@ -195,6 +197,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         w_bytes = (size_t)d.out_c * p->kstride;
         const bool i8 = d.dtype == SHL_MI355X_I8;
         ConvArgs probe = {};
+        probe.pix_tab = reinterpret_cast<const int2 *>(&probe);  // "will exist": built below when the pick needs it
         probe.Kh = d.kernel_h, probe.Kw = d.kernel_w, probe.sh = d.stride_h, probe.sw = d.stride_w;
         probe.pt = d.pad_top, probe.pl = d.pad_left, probe.H = d.in_h, probe.W = d.in_w, probe.Ho = d.out_h, probe.Wo = d.out_w;
         probe.C = d.in_c, probe.Co = d.out_c, probe.kstride = p->kstride;
@@ -210,6 +213,10 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             p->kernel_name = i8 ? "conv_gemv_i8_dot4" : "conv_gemv_f16_fma";
         else if (!strcmp(v, "pp"))
             p->kernel_name = i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
+        else if (!strcmp(v, "pc")) {
+            p->kernel_name = i8 ? "conv_igemm_pc_i8_mfma32x32x32" : "conv_igemm_pc_f16_mfma32x32x16";
+            want_pix_tab = true;
+        }
         else
             p->kernel_name = i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
         if (i8 && d.layout == SHL_MI355X_NHWC) {  // pointwise at bandwidth-bound sizes (conv1x1_stream.hip)
@@ -345,6 +352,35 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         free(p);
         return hip_fail(e, "upload(plan block)");
     }
+    if (want_pix_tab) {
+        const int64_t M = (int64_t)d.batch * d.out_h * d.out_w;
+        std::vector<int2> tab((size_t)M);
+        const int pix_bytes = d.in_c * es;
+        size_t k = 0;
+        for (int n = 0; n < d.batch; ++n)
+            for (int oy = 0; oy < d.out_h; ++oy)
+                for (int ox = 0; ox < d.out_w; ++ox, ++k) {
+                    const int y0 = oy * d.stride_h - d.pad_top, x0 = ox * d.stride_w - d.pad_left;
+                    uint32_t my = 0, mx = 0;
+                    for (int ky = 0; ky < d.kernel_h && ky < 16; ++ky)
+                        if ((unsigned)(y0 + ky * d.dilation_h) < (unsigned)d.in_h) my |= 1u << ky;
+                    for (int kx = 0; kx < d.kernel_w && kx < 16; ++kx)
+                        if ((unsigned)(x0 + kx * d.dilation_w) < (unsigned)d.in_w) mx |= 1u << kx;
+                    tab[k].x = (int)((((int64_t)n * d.in_h + y0) * d.in_w + x0) * pix_bytes);
+                    tab[k].y = (int)(my | (mx << 16));
+                }
+        e = M ? hipMalloc((void **)&p->pix_tab, (size_t)M * sizeof(int2)) : hipSuccess;
+        if (e == hipSuccess && M) e = hipMemcpyAsync(p->pix_tab, tab.data(), (size_t)M * sizeof(int2), hipMemcpyHostToDevice, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) {
+            (void)hipFree(p->pix_tab);
+            (void)hipFree(p->scratch_in);
+            (void)hipFree(p->scratch_out);
+            (void)hipFree(p->block);
+            free(p);
+            return hip_fail(e, "upload(pixel address table)");
+        }
+    }
     *plan_out = p;
     return SHL_MI355X_OK;
 }
@@ -409,6 +445,7 @@ int shl_mi355x_conv_plan_destroy(shl_mi355x_conv_plan *plan)
     if (!plan) return SHL_MI355X_OK;
     (void)hipFree(plan->scratch_in);
     (void)hipFree(plan->scratch_out);
+    (void)hipFree(plan->pix_tab);
     hipError_t e = hipFree(plan->block);
     free(plan);
     if (e != hipSuccess) return hip_fail(e, "hipFree(plan block)");
@@ -426,6 +463,7 @@ size_t shl_mi355x_conv_plan_bytes(const shl_mi355x_conv_plan *plan)
 {
     if (!plan) return 0;
     size_t n = plan->block_bytes;
+    if (plan->pix_tab) n += (size_t)plan->desc.batch * plan->desc.out_h * plan->desc.out_w * sizeof(int2);
     if (plan->scratch_in) {
         const shl_mi355x_conv_desc &d = plan->desc;
         const size_t es = d.dtype == SHL_MI355X_I8 ? 1 : 2;
@@ -487,6 +525,7 @@ static int fill_args(const shl_mi355x_conv_plan *plan, const void *input_dev, vo
     a.clamp_lo = plan->clamp_lo;
     a.clamp_hi = plan->clamp_hi;
     a.pad_page = plan->block + plan->off_pad;
+    a.pix_tab = plan->pix_tab;
     a.ch_in_scale = plan->ch_in_scale;
     a.ch_out_scale = plan->ch_out_scale;
     a.ch_has_bias = plan->ch_has_bias;
@@ -557,6 +596,8 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
 int shl_mi355x_debug_trace(uint64_t *host, int32_t count)
 {
     if (!host || count <= 0) return SHL_MI355X_EINVAL;
+    const char *v = getenv("SHL_MI355X_IGEMM");  // which kernel's stamps: the producer / consumer kernel when it is forced
+    if (v && !strcmp(v, "pc")) return pc_read_trace(reinterpret_cast<unsigned long long *>(host), count);
     return pp_read_trace(reinterpret_cast<unsigned long long *>(host), count);
 }
 

@@ -223,6 +223,11 @@ __device__ __forceinline__ void igemm_store_block64(const ConvArgs &a, const Acc
 // ping-pong kernel for MFMA-bound layers (conv_igemm_pp.hip): flavour for a problem (-1: does not apply)
 int pp_flavour(const ConvArgs &a, int esize, bool forced);
 int launch_conv_igemm_pp(const ConvArgs &a, int dtype, int flavour, hipStream_t s);
+int pc_flavour(const ConvArgs &a, int esize, bool forced);  // conv_igemm_pc.hip
+int launch_conv_igemm_pc(const ConvArgs &a, int dtype, int flavour, hipStream_t s);
+int pc_read_trace(unsigned long long *host, int count);
+bool pcx_applies(const ConvArgs &a);  // conv_igemm_pcx.hip: the pc kernel with one pixel staging per filter row
+int launch_conv_igemm_pcx(const ConvArgs &a, int dtype, int flavour, hipStream_t s);
 const char *igemm_pick(const ConvArgs &a, int esize, int *flavour);
 int pp_read_trace(unsigned long long *host, int count);
 

@@ -15,6 +15,8 @@ the C-ABI so that a replay contains no host work.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import (ACT_NONE, ACT_RELU, API_MI355X, CSINN_TRUE, DTYPE_FLOAT16, DTYPE_INT8, DTYPE_INT32,
@@ -133,6 +135,8 @@ class LayerChain:
                     host = rng.integers(-64, 64, in_dims, dtype=np.int8)
                 else:
                     host = rng.standard_normal(in_dims).astype(np.float16)
+                if os.environ.get("SHL_BENCH_ZERO_INPUT") == "1":  # power probe: all-zero activations toggle no multiplier bits
+                    host = np.zeros_like(host)
                 upload(d_in, host)
                 in_scale, in_zp = ops["in_scale"], ops["in_zp"]
             d_out = alloc(out_bytes)

@@ -1,6 +1,6 @@
 """Parity suite for ONE forced implicit-GEMM variant (run by tests/test_igemm_variants.py in a sub-process).
 
-The variant switches (SHL_MI355X_IGEMM / _TILE / _PIPE / _HALO / _PP) are read once per process, so every
+The variant switches (SHL_MI355X_IGEMM / _TILE / _PIPE / _HALO / _PP / _PC) are read once per process, so every
 combination gets its own interpreter: `python -m pytest tests/forced_igemm_suite.py -m gpu` with the
 switches in the environment.  Every shape runs int8 in the exact regime AND with general scales (both must
 equal oracle formulation X bit for bit), in NHWC and in NCHW (NCHW planes of 64 / 196 / 784 elements take
@@ -38,8 +38,11 @@ SHAPES = [
     dict(c=64, co=128, h=16, w=16, act=2, per_channel=True),
     dict(c=64, co=72, h=56, w=9, n=1),                               # tall image: halo patches spanning rows
     dict(c=128, co=256, h=12, w=12, n=4, act=1),                     # 256-wide channel tile exactly
+    dict(c=128, co=40, k=(1, 1), pad=(0, 0, 0, 0), h=9, w=9, n=3),   # ONE 128-byte K tile (shorter than any ring)
+    dict(c=256, co=96, k=(1, 1), pad=(0, 0, 0, 0), h=5, w=7, n=2),   # two
+    dict(c=384, co=128, h=10, w=10, n=3, act=1),                     # 27 K tiles of 128 bytes, M = 300
 ]
-F16_IDX = [0, 3, 4, 7, 10, 14, 16]
+F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19]
 
 EXPECT = os.environ.get("SHL_EXPECT_KERNEL", "")          # the forced kernel family ...
 FALLBACK = os.environ.get("SHL_EXPECT_FALLBACK", "")      # ... or, for shapes it does not take, this one

@@ -36,6 +36,7 @@ VARIANTS = [
     (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x64", SHL_MI355X_PIPE="0", SHL_MI355X_HALO="0"), "tile"),
     (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x64", SHL_MI355X_PIPE="4", SHL_MI355X_HALO="0"), "tile"),
     (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x128"), "tile"),
+    (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x128", SHL_MI355X_PIPE="6"), "tile"),
     (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x256"), "tile"),
     (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="128", SHL_MI355X_HALO="1"), "tile"),
     (dict(SHL_MI355X_IGEMM="tile", SHL_MI355X_TILE="256x64", SHL_MI355X_HALO="1"), "tile"),
@@ -49,6 +50,10 @@ VARIANTS = [
     (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x128"), "pp"),
     (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x128k64"), "pp"),
     (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x128x2"), "pp"),
+    # producer / consumer kernel with 128-byte K tiles (conv_igemm_pc.hip); takes C * esize % 128 == 0
+    (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="256x128"), "pc"),
+    (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="128x128"), "pc"),
+    (dict(SHL_MI355X_IGEMM="pc"), "pc"),
 ]
 
 
@@ -63,7 +68,7 @@ def test_forced_igemm_variant_is_bit_exact(variant):
     env = {k: v for k, v in os.environ.items() if not k.startswith("SHL_MI355X_")}
     env.update(extra)
     env["SHL_EXPECT_KERNEL"] = expect
-    if expect == "pp":
+    if expect in ("pp", "pc"):
         env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "30"
     res = subprocess.run([sys.executable, "-m", "pytest", SUITE, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
                          capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
@@ -76,7 +81,7 @@ RESNET_3X3 = [dict(c=64, co=64, h=56, w=56), dict(c=128, co=128, h=56, w=56, str
               dict(c=128, co=128, h=28, w=28), dict(c=256, co=256, h=28, w=28, stride=(2, 2)),
               dict(c=256, co=256, h=14, w=14), dict(c=512, co=512, h=14, w=14, stride=(2, 2)),
               dict(c=512, co=512, h=7, w=7)]
-BLOCK_TILE_KERNELS = ("tile", "pp", "halo")
+BLOCK_TILE_KERNELS = ("tile", "pp", "pc", "halo")
 
 
 @pytest.fixture(scope="module")

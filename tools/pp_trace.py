@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--layer", type=int, default=4)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--periods", type=int, default=6)
+    ap.add_argument("--pc", action="store_true", help="producer / consumer kernel (SHL_MI355X_IGEMM=pc SHL_MI355X_DEBUG=32)")
     a = ap.parse_args()
     import cases
     pkg = cases.pkg
@@ -39,6 +40,29 @@ def main():
     pkg.check(hip.shl_mi355x_debug_trace(buf, 1024), hip, "debug_trace")
     t = np.array(buf[:], dtype=np.uint64).astype(np.int64)
     print(wl.layer_name(chain.entries[0]["layer"]), chain.entries[0]["kernel_name"])
+    if a.pc:
+        for role, base, head, names in (("consumer wave 0", 0, ["tables", "barrier P"], ["3 substeps", "lds wait", "barrier", "last substep"]),
+                                        ("producer wave 4", 512, ["address setup", "ring fill", "certify 0", "barrier P"],
+                                         ["certify", "barrier", "issue"])):
+            s = t[base:base + 512]
+            n = int((s != 0).sum())
+            if n < 6:
+                print(role + ": no trace")
+                continue
+            d = np.diff(s[:n])
+            print("%s: %d stamps, total %d cycles" % (role, n, s[n - 1] - s[0]))
+            print("  " + " | ".join("%s %d" % (nm, v) for nm, v in zip(head, d[:len(head)])))
+            body = d[len(head):]
+            per = len(names)
+            nper = len(body) // per
+            for p in list(range(min(a.periods, nper))) + ([nper - 1] if nper > a.periods else []):
+                row = body[p * per:(p + 1) * per]
+                print("  K tile %2d: " % p + "  ".join("%s %5d" % (nm, v) for nm, v in zip(names, row)) + "   = %d" % row.sum())
+            allp = body[:nper * per].reshape(nper, per)
+            print("  mean      : " + "  ".join("%s %5d" % (nm, v) for nm, v in zip(names, allp.mean(axis=0))) +
+                  "   = %d per K tile, %d K tiles" % (allp.sum(axis=1).mean(), nper))
+            print("  tail: %s" % list(body[nper * per:]))
+        return
     for g, base in ((0, 0), (1, 512)):
         s = t[base:base + 512]
         n = int((s != 0).sum())

@@ -3,6 +3,9 @@
 //   mode 1  global_load_dwordx4 -> VGPR (data xor-reduced, never stored)
 //   mode 2  global_load_dwordx4 -> VGPR -> ds_write_b128
 //   mode 3  half of the pieces by LDS-DMA, half through VGPR + ds_write_b128 (same wave)
+//   HALF    pieces shaped like a 64-byte K step of the igemm kernels: 16 rows x 64 B, rows 128 B apart (half lines)
+//   mode 5/6/7  four LDS-DMA waves next to four consumer-like waves (ds_read_b128 stream / + MFMAs / MFMAs only):
+//           the DMA rate printed is what the producers of conv_igemm_pc.hip can expect
 //   mode 4  as 3, but waves alternate: even waves LDS-DMA only, odd waves VGPR + ds_write only
 // The igemm kernels' K loop is paced by this path (profiles/r02_notes.md); the question is whether the
 // ~40 B/clk/CU seen with LDS-DMA is the texture-address path (then nothing helps) or the DMA's LDS side.
@@ -27,13 +30,14 @@ __device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
 // -- under a counted vmcnt(BATCH): everything but this half's requests has landed -- put the previous half's
 // register-staged pieces into LDS (MODE 1: xor them away).  Loads, waits and LDS stores are opaque asm so that
 // the schedule is the one written here whatever shares the wave.
-template <int MODE, int ROLE, int NWAVES, int BATCH>
+template <int MODE, int ROLE, int NWAVES, int BATCH, bool HALF>
 __device__ __forceinline__ void half_iter(const char *base, int pieces, int &pc, int lane, char *slot, uint32_t slot_lds, int par,
                                           v4i (&vload)[BATCH], v4i (&vstore)[BATCH], v4i &acc)
 {
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
-        const char *src = base + (size_t)pc * 1024 + lane * 16;
+        const char *src = HALF ? base + (size_t)(pc >> 1) * 2048 + (lane >> 2) * 128 + (pc & 1) * 64 + (lane & 3) * 16
+                               : base + (size_t)pc * 1024 + lane * 16;
         pc += NWAVES;
         if (pc >= pieces) pc -= pieces;
         if (ROLE == 0 || (ROLE == 2 && (j & 1) == 0)) {
@@ -47,6 +51,7 @@ __device__ __forceinline__ void half_iter(const char *base, int pieces, int &pc,
     for (int j = 0; j < BATCH; ++j) {
         if (ROLE == 0 || (ROLE == 2 && (j & 1) == 0)) continue;
         if (MODE == 1) {
+            asm volatile("" : "+v"(vstore[j]));  // the value exists only after the wait above (volatile asm keeps its order)
             acc ^= vstore[j];
         } else {
             const uint32_t dst = slot_lds + ((par ^ 1) * BATCH + j) * 1024;
@@ -55,7 +60,7 @@ __device__ __forceinline__ void half_iter(const char *base, int pieces, int &pc,
     }
 }
 
-template <int MODE, int NWAVES, int BATCH>
+template <int MODE, int NWAVES, int BATCH, bool HALF = false>
 __global__ __launch_bounds__(64 * NWAVES) void k(const char *buf, int region, int iters, int *out, unsigned long long *cyc)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,20 +76,44 @@ __global__ __launch_bounds__(64 * NWAVES) void k(const char *buf, int region, in
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) va[j] = vb[j] = v4i{0, 0, 0, 0};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (MODE == 0 || (MODE == 4 && (wave & 1) == 0)) {
+    if ((MODE == 5 || MODE == 6 || MODE == 7) && wave >= NWAVES / 2) {
+        // consumer-like wave: 6 ds_read_b128 (1 KiB each) per 8 MFMAs (mode 6) / reads only (mode 5) / MFMAs only (mode 7)
+        typedef int v16i __attribute__((ext_vector_type(16)));
+        v16i c[8];
+        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 16; ++r) c[i][r] = 0;
+        v4i f[6];
+        for (int i = 0; i < 6; ++i) f[i] = v4i{lane, 1, 2, 3};
+        const uint32_t rd = (uint32_t)(uintptr_t)smem + lane * 16;
+        for (int it = 0; it < iters * 3; ++it) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (MODE != 5) c[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[m % 6], f[(m + 1) % 6], c[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE != 7 && m < 6) {
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(f[m]) : "v"(rd + ((it * 6 + m) & 15) * 1024));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]));
+        }
+        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 16; ++r) acc[0] ^= c[i][r];
+        for (int i = 0; i < 6; ++i) acc ^= f[i];
+    } else if (MODE == 0 || MODE == 5 || MODE == 6 || MODE == 7 || (MODE == 4 && (wave & 1) == 0)) {
         for (int it = 0; it < iters; it += 2) {
-            half_iter<MODE, 0, NWAVES, BATCH>(base, pieces, pc, lane, slot, slot_lds, 0, va, vb, acc);
-            half_iter<MODE, 0, NWAVES, BATCH>(base, pieces, pc, lane, slot, slot_lds, 1, vb, va, acc);
+            half_iter<MODE, 0, NWAVES, BATCH, HALF>(base, pieces, pc, lane, slot, slot_lds, 0, va, vb, acc);
+            half_iter<MODE, 0, NWAVES, BATCH, HALF>(base, pieces, pc, lane, slot, slot_lds, 1, vb, va, acc);
         }
     } else if (MODE == 3) {
         for (int it = 0; it < iters; it += 2) {
-            half_iter<MODE, 2, NWAVES, BATCH>(base, pieces, pc, lane, slot, slot_lds, 0, va, vb, acc);
-            half_iter<MODE, 2, NWAVES, BATCH>(base, pieces, pc, lane, slot, slot_lds, 1, vb, va, acc);
+            half_iter<MODE, 2, NWAVES, BATCH, HALF>(base, pieces, pc, lane, slot, slot_lds, 0, va, vb, acc);
+            half_iter<MODE, 2, NWAVES, BATCH, HALF>(base, pieces, pc, lane, slot, slot_lds, 1, vb, va, acc);
         }
     } else {
         for (int it = 0; it < iters; it += 2) {
-            half_iter<MODE, 1, NWAVES, BATCH>(base, pieces, pc, lane, slot, slot_lds, 0, va, vb, acc);
-            half_iter<MODE, 1, NWAVES, BATCH>(base, pieces, pc, lane, slot, slot_lds, 1, vb, va, acc);
+            half_iter<MODE, 1, NWAVES, BATCH, HALF>(base, pieces, pc, lane, slot, slot_lds, 0, va, vb, acc);
+            half_iter<MODE, 1, NWAVES, BATCH, HALF>(base, pieces, pc, lane, slot, slot_lds, 1, vb, va, acc);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -94,19 +123,20 @@ __global__ __launch_bounds__(64 * NWAVES) void k(const char *buf, int region, in
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int MODE, int NWAVES, int BATCH>
+template <int MODE, int NWAVES, int BATCH, bool HALF = false>
 void run(const char *name, int blocks, const char *buf, int region, int *out, unsigned long long *cyc)
 {
     const int iters = 2000;
     const size_t lds = (size_t)NWAVES * 2 * BATCH * 1024;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE, NWAVES, BATCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE, NWAVES, BATCH, HALF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<MODE, NWAVES, BATCH>), dim3(blocks), dim3(64 * NWAVES), lds, 0, buf, region, 20, out, cyc);
-    hipDeviceSynchronize();
+    printf("%-34s waves %2d batch %2d blocks %4d: ", name, NWAVES, BATCH, blocks);
+    hipLaunchKernelGGL((k<MODE, NWAVES, BATCH, HALF>), dim3(blocks), dim3(64 * NWAVES), lds, 0, buf, region, 20, out, cyc);
+    if (hipDeviceSynchronize() != hipSuccess) printf("warm-up failed: %s\n", hipGetErrorString(hipGetLastError()));
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<MODE, NWAVES, BATCH>), dim3(blocks), dim3(64 * NWAVES), lds, 0, buf, region, iters, out, cyc);
+    hipLaunchKernelGGL((k<MODE, NWAVES, BATCH, HALF>), dim3(blocks), dim3(64 * NWAVES), lds, 0, buf, region, iters, out, cyc);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms = 0;
@@ -116,9 +146,8 @@ void run(const char *name, int blocks, const char *buf, int region, int *out, un
     double mean = 0;
     for (int i = 0; i < blocks; ++i) mean += (double)h[i];
     mean /= blocks;
-    const double bytes_per_block = (double)iters * NWAVES * BATCH * 1024;
-    printf("%-34s waves %2d batch %2d blocks %4d: %7.1f us  %6.2f TB/s chip  %6.1f GB/s per block  %5.1f B per s_memtime tick per block\n", name,
-           NWAVES, BATCH, blocks, ms * 1e3, bytes_per_block * blocks / (ms * 1e-3) / 1e12, bytes_per_block / (ms * 1e-3) / 1e9,
+    const double bytes_per_block = (double)iters * (MODE >= 5 ? NWAVES / 2 : NWAVES) * BATCH * 1024;
+    printf("%7.1f us  %6.2f TB/s chip  %6.1f GB/s per block  %5.1f B per s_memtime tick per block\n", ms * 1e3, bytes_per_block * blocks / (ms * 1e-3) / 1e12, bytes_per_block / (ms * 1e-3) / 1e9,
            bytes_per_block / mean);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) printf("  error: %s\n", hipGetErrorString(err));
@@ -126,6 +155,7 @@ void run(const char *name, int blocks, const char *buf, int region, int *out, un
 
 int main()
 {
+    setvbuf(stdout, NULL, _IONBF, 0);
     const int region = 96 * 1024;  // 32 workgroups per XCD x 96 KiB = 3 MiB of its 4 MiB L2
     char *buf;
     int *out;
@@ -137,9 +167,15 @@ int main()
     for (int blocks : {256, 512}) {
         printf("---- %d workgroups, region %d KiB each\n", blocks, region / 1024);
         run<0, 4, 8>("LDS-DMA", blocks, buf, region, out, cyc);
+        run<0, 4, 8, true>("LDS-DMA, 16 rows x 64 B per piece", blocks, buf, region, out, cyc);
+        run<0, 8, 8, true>("LDS-DMA, 16 rows x 64 B per piece", blocks, buf, region, out, cyc);
+        run<0, 2, 8, true>("LDS-DMA, 16 rows x 64 B per piece", blocks, buf, region, out, cyc);
         run<0, 8, 8>("LDS-DMA", blocks, buf, region, out, cyc);
         run<0, 1, 8>("LDS-DMA", blocks, buf, region, out, cyc);
         run<0, 2, 8>("LDS-DMA", blocks, buf, region, out, cyc);
+        run<5, 8, 8>("4 DMA waves + 4 waves ds_read_b128", blocks, buf, region, out, cyc);
+        run<6, 8, 8>("4 DMA waves + 4 waves read + MFMA", blocks, buf, region, out, cyc);
+        run<7, 8, 8>("4 DMA waves + 4 waves MFMA only", blocks, buf, region, out, cyc);
         run<1, 4, 8>("global_load -> VGPR", blocks, buf, region, out, cyc);
         run<1, 8, 8>("global_load -> VGPR", blocks, buf, region, out, cyc);
         run<1, 1, 8>("global_load -> VGPR", blocks, buf, region, out, cyc);
