@@ -954,12 +954,14 @@ static const char *variant_override()
     return v ? v : "";
 }
 
-// which kernel family runs problem `a`: "wave" | "regs" | "tile" | "pp" | "pc"; *flavour = tile flavour of pp / pc
+// which kernel family runs problem `a`: "wave" | "regs" | "tile" | "pp" | "pc" | "res"; *flavour = tile flavour of pp / pc
 const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
 {
     const char *ov = variant_override();
     if (flavour) *flavour = -1;
     if (!ov[0] && conv_gemv_pick(a, esize)) return "gemv";
+    if ((!ov[0] || !strcmp(ov, "res")) && res_applies(a, esize)) return "res";
+    if (!strcmp(ov, "res")) return "tile";  // shapes the resident-weights kernel does not take
     const bool forced_pc = !strcmp(ov, "pc");
     if (forced_pc || !ov[0]) {
         const int f = pc_flavour(a, esize, forced_pc);
@@ -988,13 +990,13 @@ bool igemm_fuses_nchw_out(const ConvArgs &a, int esize)
     ConvArgs t = a;
     t.out_nchw = 1;
     const char *v = igemm_pick(t, esize, nullptr);
-    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc");
+    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc") || !strcmp(v, "res");
 }
 
 const char *igemm_variant(int64_t M, int64_t Co)
 {
     const char *ov = variant_override();
-    if (ov[0] && strcmp(ov, "pp") && strcmp(ov, "pc")) return ov;
+    if (ov[0] && strcmp(ov, "pp") && strcmp(ov, "pc") && strcmp(ov, "res")) return ov;
     if (ov[0]) return "tile";
     // LDS tile kernel once there is at least ~one 128x128 tile for every other CU; below that
     // (MobileNetV1 at batch 1: 1-98 tiles) latency dominates and the barrier-free wave kernel wins
@@ -1013,9 +1015,12 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     int ppf = -1;
     const char *v = igemm_pick(a, esize, &ppf);
     if (!strcmp(v, "pp")) return launch_conv_igemm_pp(a, dtype, ppf, s);
+    if (!strcmp(v, "res")) return launch_conv_igemm_res(a, s);
     if (!strcmp(v, "pc")) {
-        static const char *pcx_env = getenv("SHL_MI355X_PCX");  // "0": plain producer / consumer kernel (A/B)
-        if (pcx_applies(a) && !(pcx_env && pcx_env[0] == '0')) return launch_conv_igemm_pcx(a, dtype, ppf, s);
+        // opt-in: the shifted-row form moves 1.8x fewer bytes but is no faster (the loop is not paced by the byte
+        // count: profiles/r02_notes.md)
+        static const char *pcx_env = getenv("SHL_MI355X_PCX");
+        if (pcx_env && pcx_env[0] == '1' && pcx_applies(a)) return launch_conv_igemm_pcx(a, dtype, ppf, s);
         return launch_conv_igemm_pc(a, dtype, ppf, s);
     }
     const int epi = i8 ? epi_code(a) : 0;

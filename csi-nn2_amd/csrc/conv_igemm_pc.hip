@@ -336,7 +336,8 @@ __global__ __launch_bounds__(512) void conv_igemm_pc_kernel(ConvArgs a)
     char *ws = smem + wave * WS_B;
 #pragma unroll
     for (int jh = 0; jh < TP / 2; ++jh)
-        igemm_store_block64<kI8, EPI>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], ws,
+        // kBulk: a consumer runs the epilogue alone on its SIMD (igemm_common.h)
+        igemm_store_block64<kI8, EPI, acc_t, true>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], ws,
                                       pix0 + wp * (G::BM / 2) + jh * 64, co0 + wc * 64, tab_acc, tab_mult, tab_bias, lane);
     mark();
 }

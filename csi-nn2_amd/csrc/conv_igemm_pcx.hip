@@ -101,9 +101,19 @@ __device__ __forceinline__ void pcx_wait_vmcnt(int n)
 #undef SHL_W
 }
 
-template <bool kI8, int EPI, typename G>
+// SHL_MI355X_DEBUG=32: phase stamps as in conv_igemm_pc.hip (tools/pp_trace.py --pc)
+__device__ unsigned long long g_pcx_trace[1024];
+
+template <bool kI8, int EPI, typename G, bool kTrace = false>
 __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
 {
+    int trace_k = (threadIdx.x >> 8) * 512;
+    auto mark = [&]() {
+        if constexpr (kTrace) {
+            if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (trace_k & 511) < 500) g_pcx_trace[trace_k++] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    mark();
     constexpr int ESIZE = kI8 ? 1 : 2;
     constexpr int BKBT = G::BKBT, NWB = G::NWB, TC = G::TC, TP = G::TP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -219,6 +229,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
         };
 
         // ---- pipeline fill: stage 0, the weight ring, part A of stage 1
+        mark();
         issue_pixels(I0{}, IS{});
         next_stage();
         for (int t = 0; t < NWB; ++t)
@@ -227,13 +238,18 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
         // barrier P needs stage 0 and the weights of tile 0: everything but the younger weights and part A
         {
             int allowed = ((nk < NWB ? nk : NWB) - 1) * G::NWT + (1 < nstage ? G::PA : 0);
+            mark();
             pcx_wait_vmcnt(allowed);
         }
+        mark();
         pcx_barrier();  // barrier P
+        mark();
         int r = 0;      // t mod 3
         for (int t = 0; t < nk; ++t) {
             certify(t, r);
+            mark();
             pcx_barrier();  // barrier t: tile t+1 complete; weight slot of tile t (and, r == 2, its pixel stage) free
+            mark();
             if (wt < nk) issue_weights();
             if (r == 0) {  // part B of the stage whose part A went out one slot earlier
                 if (pg < nstage) {
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
                 if (pg < nstage) issue_pixels(I0{}, IA{});
             }
             r = r == 2 ? 0 : r + 1;
+            mark();
         }
         return;
     }
@@ -334,10 +351,14 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
         substep(C{}, C{}, fa0, fb0, wcur, pcur, 1, fa1, fb1);
         substep(C{}, C{}, fa1, fb1, wcur, pcur, 2, fa0, fb0);
         substep(C{}, C{}, fa0, fb0, wcur, pcur, 3, fa1, fb1);
+        mark();
         pcx_wait_all<TP>(fa1, fb1);  // the last reads of this tile have landed
+        mark();
         pcx_barrier();               // barrier t
+        mark();
         // unconditional: after the last tile these reads fetch stale slots that nobody consumes
         substep(C{}, N{}, fa1, fb1, wn, pn, 0, fa0, fb0);
+        mark();
     };
 
     if (tid < G::BN) {
@@ -346,7 +367,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
         reinterpret_cast<float *>(smem + G::TAB_OFF)[2 * G::BN + tid] = t_bias;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mark();
     pcx_barrier();  // barrier P: pixel stage 0 and the weights of tile 0 are complete
+    mark();
     {
         const uint32_t oa = baseA + swa[0], ob = baseB + swb[0][0];
         lds_read128_async<0>(fa0[0], oa);
@@ -384,8 +407,10 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
     char *wsb = smem + wave * WS_B;
 #pragma unroll
     for (int jh = 0; jh < TP / 2; ++jh)
-        igemm_store_block64<kI8, EPI>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], wsb,
+        // kBulk: a consumer runs the epilogue alone on its SIMD (igemm_common.h)
+        igemm_store_block64<kI8, EPI, acc_t, true>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], wsb,
                                       pix0 + wp * (G::BM / 2) + jh * 64, co0 + wc * 64, tab_acc, tab_mult, tab_bias, lane);
+    mark();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -416,6 +441,10 @@ static void pcx_launch(const ConvArgs &a, bool i8, int epi, hipStream_t s)
         SHL_PCX((conv_igemm_pcx_kernel<false, 0, G>));
         return;
     }
+    if (a.debug == 32) {  // traced build, literal epilogue only
+        SHL_PCX((conv_igemm_pcx_kernel<true, 2, G, true>));
+        return;
+    }
     switch (epi) {
         case 0: SHL_PCX((conv_igemm_pcx_kernel<true, 0, G>)); break;
         case 1: SHL_PCX((conv_igemm_pcx_kernel<true, 1, G>)); break;
@@ -425,6 +454,13 @@ static void pcx_launch(const ConvArgs &a, bool i8, int epi, hipStream_t s)
         default: SHL_PCX((conv_igemm_pcx_kernel<true, 5, G>)); break;
     }
 #undef SHL_PCX
+}
+
+int pcx_read_trace(unsigned long long *host, int count)
+{
+    if (count > 1024) count = 1024;
+    SHL_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pcx_trace), (size_t)count * 8));
+    return SHL_MI355X_OK;
 }
 
 // flavour as conv_igemm_pc.hip's (0: 256 x 128, 1: 128 x 128)

@@ -199,6 +199,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         ConvArgs probe = {};
         probe.pix_tab = reinterpret_cast<const int2 *>(&probe);  // "will exist": built below when the pick needs it
         probe.Kh = d.kernel_h, probe.Kw = d.kernel_w, probe.sh = d.stride_h, probe.sw = d.stride_w;
+        probe.dh = d.dilation_h, probe.dw = d.dilation_w;
         probe.pt = d.pad_top, probe.pl = d.pad_left, probe.H = d.in_h, probe.W = d.in_w, probe.Ho = d.out_h, probe.Wo = d.out_w;
         probe.C = d.in_c, probe.Co = d.out_c, probe.kstride = p->kstride;
         probe.M = (int32_t)((int64_t)d.batch * d.out_h * d.out_w);
@@ -213,7 +214,10 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             p->kernel_name = i8 ? "conv_gemv_i8_dot4" : "conv_gemv_f16_fma";
         else if (!strcmp(v, "pp"))
             p->kernel_name = i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
-        else if (!strcmp(v, "pc")) {
+        else if (!strcmp(v, "res")) {
+            p->kernel_name = "conv_igemm_res_i8_mfma32x32x32";
+            want_pix_tab = true;
+        } else if (!strcmp(v, "pc")) {
             p->kernel_name = i8 ? "conv_igemm_pc_i8_mfma32x32x32" : "conv_igemm_pc_f16_mfma32x32x16";
             want_pix_tab = true;
         }
@@ -597,6 +601,9 @@ int shl_mi355x_debug_trace(uint64_t *host, int32_t count)
 {
     if (!host || count <= 0) return SHL_MI355X_EINVAL;
     const char *v = getenv("SHL_MI355X_IGEMM");  // which kernel's stamps: the producer / consumer kernel when it is forced
+    if (v && !strcmp(v, "res")) return res_read_trace(reinterpret_cast<unsigned long long *>(host), count);
+    const char *x = getenv("SHL_MI355X_PCX");
+    if (v && !strcmp(v, "pc") && x && x[0] == '1') return pcx_read_trace(reinterpret_cast<unsigned long long *>(host), count);
     if (v && !strcmp(v, "pc")) return pc_read_trace(reinterpret_cast<unsigned long long *>(host), count);
     return pp_read_trace(reinterpret_cast<unsigned long long *>(host), count);
 }

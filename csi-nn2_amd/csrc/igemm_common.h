@@ -103,7 +103,11 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb)
 // acc[i][j]: i = 32-channel tile, j = 32-pixel tile; C/D layout: column (pixel) = lane & 31, row (channel)
 // = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // Staged through a wave-private LDS block so that every lane stores 16 contiguous bytes.
-template <bool kI8, int EPI, bool kNchw, typename Acc>
+// kBulk: the per-channel tables of a 32-channel half are read in one go (12 ds_read_b128, 48 registers) in front of
+// its eight independent requantisation chains, instead of three reads in front of every chain: a wave that runs the
+// epilogue alone on its SIMD (conv_igemm_res.hip, conv_igemm_pc.hip) otherwise pays one LDS round trip plus one
+// fully dependent ~30-instruction chain sixteen times in a row (measured ~10 000 ticks per 64 x 64 block).
+template <bool kI8, int EPI, bool kNchw, typename Acc, bool kBulk = false>
 __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, const Acc &a00, const Acc &a01, const Acc &a10,
                                                const Acc &a11, char *ws, int pix_first, int co_first,
                                                const int32_t *tab_acc, const float *tab_mult, const float *tab_bias, int lane)
@@ -116,55 +120,109 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
     const int frow = lane & 31, fhalf = lane >> 5;
     const int srow = lane / CPR, schunk = lane % CPR;
     char *out = static_cast<char *>(a.out);
+    // requantise and stage channels c .. c+3 (c = i2 * 32 + 8 g + 4 fhalf) of pixel j * 32 + frow
+    auto emit = [&](const Acc &acc, int j, int g, int c, const float4 &bi, const float4 &mu, const int4 &ai) {
+        char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
+        char *dst_t = ws + c * PITCH + (j * 32 + frow) * ESIZE;  // NCHW output: [channel][pixel]
+        if constexpr (kI8) {
+            const uint32_t pk = requant4_i8_t<EPI>(acc[4 * g + 0] + ai.x, acc[4 * g + 1] + ai.y, acc[4 * g + 2] + ai.z,
+                                                   acc[4 * g + 3] + ai.w, mu, bi, a);
+            if constexpr (kNchw) {
+                // 4 x 4 byte transposition across the four lanes of a quad (= four consecutive pixels):
+                // lane k ends up with channel c + k of pixels 4q .. 4q+3 -- one dword store instead of
+                // four byte stores (the staged NCHW epilogue was LDS-store-issue bound)
+                const int k = lane & 3;
+                const uint32_t v0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x00, 0xf, 0xf, true);
+                const uint32_t v1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x55, 0xf, 0xf, true);
+                const uint32_t v2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xaa, 0xf, 0xf, true);
+                const uint32_t v3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xff, 0xf, 0xf, true);
+                const uint32_t sel = 0x0c0c0000u | ((uint32_t)(4 + k) << 8) | (uint32_t)k;
+                const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, sel);
+                const uint32_t t23 = __builtin_amdgcn_perm(v3, v2, sel);
+                *reinterpret_cast<uint32_t *>(ws + (c + k) * PITCH + j * 32 + (frow & ~3)) =
+                    __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+            } else {
+                *reinterpret_cast<uint32_t *>(dst) = pk;
+            }
+        } else {
+            const uint32_t h0 = finish_f16(acc[4 * g + 0], bi.x, a);
+            const uint32_t h1 = finish_f16(acc[4 * g + 1], bi.y, a);
+            const uint32_t h2 = finish_f16(acc[4 * g + 2], bi.z, a);
+            const uint32_t h3 = finish_f16(acc[4 * g + 3], bi.w, a);
+            if constexpr (kNchw) {
+                *reinterpret_cast<uint16_t *>(dst_t) = (uint16_t)h0;
+                *reinterpret_cast<uint16_t *>(dst_t + PITCH) = (uint16_t)h1;
+                *reinterpret_cast<uint16_t *>(dst_t + 2 * PITCH) = (uint16_t)h2;
+                *reinterpret_cast<uint16_t *>(dst_t + 3 * PITCH) = (uint16_t)h3;
+            } else {
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+            }
+        }
+    };
+    if constexpr (kBulk && kI8) {
 #pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const Acc &acc = i2 == 0 ? (j == 0 ? a00 : a01) : (j == 0 ? a10 : a11);
+        for (int i2 = 0; i2 < 2; ++i2) {
+            float4 bi[4], mu[4];
+            int4 ai[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = i2 * 32 + 8 * g + 4 * fhalf;  // first of this lane's 4 channels within the 64
-                const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + c);
-                char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
-                char *dst_t = ws + c * PITCH + (j * 32 + frow) * ESIZE;  // NCHW output: [channel][pixel]
-                if constexpr (kI8) {
-                    const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + c);
-                    const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + c);
-                    const uint32_t pk = requant4_i8_t<EPI>(acc[4 * g + 0] + ai.x, acc[4 * g + 1] + ai.y, acc[4 * g + 2] + ai.z,
-                                                           acc[4 * g + 3] + ai.w, mu, bi, a);
+                const int c = i2 * 32 + 8 * g + 4 * fhalf;
+                bi[g] = *reinterpret_cast<const float4 *>(tab_bias + c);
+                mu[g] = *reinterpret_cast<const float4 *>(tab_mult + c);
+                ai[g] = *reinterpret_cast<const int4 *>(tab_acc + c);
+            }
+            // all eight requantisations of the half first (independent chains the scheduler can interleave: nothing
+            // between them touches LDS, which it could not tell apart from the staging stores), then the eight stores
+            uint32_t pk[2][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const Acc &acc = i2 == 0 ? (j == 0 ? a00 : a01) : (j == 0 ? a10 : a11);
+                    pk[j][g] = requant4_i8_t<EPI>(acc[4 * g + 0] + ai[g].x, acc[4 * g + 1] + ai[g].y, acc[4 * g + 2] + ai[g].z,
+                                                  acc[4 * g + 3] + ai[g].w, mu[g], bi[g], a);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = i2 * 32 + 8 * g + 4 * fhalf;
                     if constexpr (kNchw) {
-                        // 4 x 4 byte transposition across the four lanes of a quad (= four consecutive pixels):
-                        // lane k ends up with channel c + k of pixels 4q .. 4q+3 -- one dword store instead of
-                        // four byte stores (the staged NCHW epilogue was LDS-store-issue bound)
                         const int k = lane & 3;
-                        const uint32_t v0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x00, 0xf, 0xf, true);
-                        const uint32_t v1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0x55, 0xf, 0xf, true);
-                        const uint32_t v2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xaa, 0xf, 0xf, true);
-                        const uint32_t v3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xff, 0xf, 0xf, true);
+                        const uint32_t v0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk[j][g], 0x00, 0xf, 0xf, true);
+                        const uint32_t v1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk[j][g], 0x55, 0xf, 0xf, true);
+                        const uint32_t v2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk[j][g], 0xaa, 0xf, 0xf, true);
+                        const uint32_t v3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk[j][g], 0xff, 0xf, 0xf, true);
                         const uint32_t sel = 0x0c0c0000u | ((uint32_t)(4 + k) << 8) | (uint32_t)k;
                         const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, sel);
                         const uint32_t t23 = __builtin_amdgcn_perm(v3, v2, sel);
                         *reinterpret_cast<uint32_t *>(ws + (c + k) * PITCH + j * 32 + (frow & ~3)) =
                             __builtin_amdgcn_perm(t23, t01, 0x05040100u);
                     } else {
-                        *reinterpret_cast<uint32_t *>(dst) = pk;
-                    }
-                } else {
-                    const uint32_t h0 = finish_f16(acc[4 * g + 0], bi.x, a);
-                    const uint32_t h1 = finish_f16(acc[4 * g + 1], bi.y, a);
-                    const uint32_t h2 = finish_f16(acc[4 * g + 2], bi.z, a);
-                    const uint32_t h3 = finish_f16(acc[4 * g + 3], bi.w, a);
-                    if constexpr (kNchw) {
-                        *reinterpret_cast<uint16_t *>(dst_t) = (uint16_t)h0;
-                        *reinterpret_cast<uint16_t *>(dst_t + PITCH) = (uint16_t)h1;
-                        *reinterpret_cast<uint16_t *>(dst_t + 2 * PITCH) = (uint16_t)h2;
-                        *reinterpret_cast<uint16_t *>(dst_t + 3 * PITCH) = (uint16_t)h3;
-                    } else {
-                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                        *reinterpret_cast<uint32_t *>(ws + (j * 32 + frow) * PITCH + c) = pk[j][g];
                     }
                 }
-            }
         }
+    } else {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const Acc &acc = i2 == 0 ? (j == 0 ? a00 : a01) : (j == 0 ? a10 : a11);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = i2 * 32 + 8 * g + 4 * fhalf;  // first of this lane's 4 channels within the 64
+                    const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + c);
+                    float4 mu = {0.f, 0.f, 0.f, 0.f};
+                    int4 ai = {0, 0, 0, 0};
+                    if constexpr (kI8) {
+                        mu = *reinterpret_cast<const float4 *>(tab_mult + c);
+                        ai = *reinterpret_cast<const int4 *>(tab_acc + c);
+                    }
+                    emit(acc, j, g, c, bi, mu, ai);
+                }
+            }
+    }
     // wave-local hand-over: the same wave wrote and reads; LDS operations complete in order
     if constexpr (kNchw) {
         // rows of the staging block are channels: a lane owns 16 bytes = 16 / ESIZE consecutive flat
@@ -208,16 +266,16 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
 
 // the output layout is a launch constant: one wave-uniform branch, two straight-line bodies (a run-time test
 // per staged group cost the 64 -> 64 @56 layer 6 us of its 35)
-template <bool kI8, int EPI, typename Acc>
+template <bool kI8, int EPI, typename Acc, bool kBulk = false>
 __device__ __forceinline__ void igemm_store_block64(const ConvArgs &a, const Acc &a00, const Acc &a01, const Acc &a10,
                                                     const Acc &a11, char *ws, int pix_first, int co_first,
                                                     const int32_t *tab_acc, const float *tab_mult, const float *tab_bias,
                                                     int lane)
 {
     if (a.out_nchw)
-        igemm_store_block64_impl<kI8, EPI, true>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
+        igemm_store_block64_impl<kI8, EPI, true, Acc, kBulk>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
     else
-        igemm_store_block64_impl<kI8, EPI, false>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
+        igemm_store_block64_impl<kI8, EPI, false, Acc, kBulk>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
 }
 
 // ping-pong kernel for MFMA-bound layers (conv_igemm_pp.hip): flavour for a problem (-1: does not apply)
@@ -228,6 +286,10 @@ int launch_conv_igemm_pc(const ConvArgs &a, int dtype, int flavour, hipStream_t 
 int pc_read_trace(unsigned long long *host, int count);
 bool pcx_applies(const ConvArgs &a);  // conv_igemm_pcx.hip: the pc kernel with one pixel staging per filter row
 int launch_conv_igemm_pcx(const ConvArgs &a, int dtype, int flavour, hipStream_t s);
+int pcx_read_trace(unsigned long long *host, int count);
+bool res_applies(const ConvArgs &a, int esize);  // conv_igemm_res.hip: persistent workgroups, resident weights (64-byte pixels)
+int launch_conv_igemm_res(const ConvArgs &a, hipStream_t s);
+int res_read_trace(unsigned long long *host, int count);
 const char *igemm_pick(const ConvArgs &a, int esize, int *flavour);
 int pp_read_trace(unsigned long long *host, int count);
 

@@ -1,6 +1,6 @@
 """Parity suite for ONE forced implicit-GEMM variant (run by tests/test_igemm_variants.py in a sub-process).
 
-The variant switches (SHL_MI355X_IGEMM / _TILE / _PIPE / _HALO / _PP / _PC) are read once per process, so every
+The variant switches (SHL_MI355X_IGEMM / _TILE / _PIPE / _HALO / _PP / _PC / _PCX / _RES) are read once per process, so every
 combination gets its own interpreter: `python -m pytest tests/forced_igemm_suite.py -m gpu` with the
 switches in the environment.  Every shape runs int8 in the exact regime AND with general scales (both must
 equal oracle formulation X bit for bit), in NHWC and in NCHW (NCHW planes of 64 / 196 / 784 elements take
@@ -41,6 +41,9 @@ SHAPES = [
     dict(c=128, co=40, k=(1, 1), pad=(0, 0, 0, 0), h=9, w=9, n=3),   # ONE 128-byte K tile (shorter than any ring)
     dict(c=256, co=96, k=(1, 1), pad=(0, 0, 0, 0), h=5, w=7, n=2),   # two
     dict(c=384, co=128, h=10, w=10, n=3, act=1),                     # 27 K tiles of 128 bytes, M = 300
+    dict(c=64, co=48, h=9, w=13, n=5),                               # 64-byte pixels, Cout = 48: images inside one 512-pixel tile
+    dict(c=64, co=64, h=17, w=19, n=4, pad=(1, 0, 1, 2), act=1),     # asymmetric padding, M = 1292 (ragged against 512)
+    dict(c=64, co=16, k=(2, 2), pad=(0, 0, 1, 1), h=12, w=12, n=3),  # four taps
 ]
 F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19]
 

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--layer", type=int, default=4)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--periods", type=int, default=6)
+    ap.add_argument("--res", action="store_true", help="resident-weights kernel (SHL_MI355X_IGEMM=res SHL_MI355X_DEBUG=32)")
     ap.add_argument("--pc", action="store_true", help="producer / consumer kernel (SHL_MI355X_IGEMM=pc SHL_MI355X_DEBUG=32)")
     a = ap.parse_args()
     import cases
@@ -40,6 +41,16 @@ def main():
     pkg.check(hip.shl_mi355x_debug_trace(buf, 1024), hip, "debug_trace")
     t = np.array(buf[:], dtype=np.uint64).astype(np.int64)
     print(wl.layer_name(chain.entries[0]["layer"]), chain.entries[0]["kernel_name"])
+    if a.res:
+        # stamps: start | prologue requests | first wait | then per period: barrier passed, and either
+        # (K-loop role) next-patch requests, K loop, DMA wait  or  (epilogue role) epilogue
+        for role, base in (("group 0 (wave 0)", 0), ("group 1 (wave 4)", 512)):
+            s = t[base:base + 512]
+            n = int((s != 0).sum())
+            d = np.diff(s[:n])
+            print("%s: %d stamps, total %d ticks" % (role, n, s[n - 1] - s[0]))
+            print("  deltas: " + " ".join(str(int(v)) for v in d))
+        return
     if a.pc:
         for role, base, head, names in (("consumer wave 0", 0, ["tables", "barrier P"], ["3 substeps", "lds wait", "barrier", "last substep"]),
                                         ("producer wave 4", 512, ["address setup", "ring fill", "certify 0", "barrier P"],
