@@ -20,6 +20,14 @@ import sys
 FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kernel name)
     ("conv_igemm_wave_kernel<true", "conv_igemm_wave_i8_mfma32x32x32"),
     ("conv_igemm_wave_kernel<false", "conv_igemm_wave_f16_mfma32x32x16"),
+    ("conv_igemm_pc_kernel<true", "conv_igemm_pc_i8_mfma32x32x32"),
+    ("conv_igemm_pc_kernel<false", "conv_igemm_pc_f16_mfma32x32x16"),
+    ("conv_igemm_pcx_kernel<true", "conv_igemm_pc_i8_mfma32x32x32"),
+    ("conv_igemm_pcx_kernel<false", "conv_igemm_pc_f16_mfma32x32x16"),
+    ("conv_igemm_res_kernel", "conv_igemm_res_i8_mfma32x32x32"),
+    ("conv_gemv_kernel<true", "conv_gemv_i8_dot4"),
+    ("conv_gemv_kernel<false", "conv_gemv_f16_fma"),
+    ("dwconv_channel_nchw_i8_kernel", "dwconv_channel_nchw_i8"),
     ("conv_igemm_pp_kernel<true", "conv_igemm_pp_i8_mfma32x32x32"),
     ("conv_igemm_pp_kernel<false", "conv_igemm_pp_f16_mfma32x32x16"),
     ("conv_igemm_tile_kernel<true", "conv_igemm_tile_i8_mfma32x32x32"),
