@@ -226,11 +226,13 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
     // wave-local hand-over: the same wave wrote and reads; LDS operations complete in order
     if constexpr (kNchw) {
         // rows of the staging block are channels: a lane owns 16 bytes = 16 / ESIZE consecutive flat
-        // (n, oy, ox) pixels of one channel.  Widest store that can neither straddle an image nor be
-        // misaligned: 16 B when Ho*Wo*ESIZE % 16 == 0, else 4 B (the caller guarantees % 4 == 0)
+        // (n, oy, ox) pixels of one channel.  One 16-byte store when the chunk lies inside one image plane (always the
+        // case when Ho*Wo*ESIZE % 16 == 0; planes of 196 bytes -- ResNet-50's 14 x 14 maps -- start on 4-byte
+        // boundaries only, which a dwordx4 store accepts: that is 15 of 16 chunks instead of none), else dword stores
+        // (the caller guarantees Ho*Wo*ESIZE % 4 == 0)
         constexpr int EPC = 16 / ESIZE;
+        typedef uint32_t u4_a4 __attribute__((ext_vector_type(4), aligned(4)));
         const int hw = a.Ho * a.Wo;
-        const bool wide = ((hw * ESIZE) & 15) == 0;
 #pragma unroll
         for (int it = 0; it < 64 / RPI; ++it) {
             const int row = it * RPI + srow;  // channel within the 64
@@ -238,17 +240,18 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
             const int p0 = pix_first + schunk * EPC;
             const uint4 v = *reinterpret_cast<const uint4 *>(ws + row * PITCH + schunk * 16);
             if (oc >= a.Co || p0 >= a.M) continue;
-            if (wide) {
-                const int n = p0 / hw, q = p0 - n * hw;
-                *reinterpret_cast<uint4 *>(out + (((int64_t)n * a.Co + oc) * hw + q) * ESIZE) = v;
+            const int n = p0 / hw, q = p0 - n * hw;
+            if (q + EPC <= hw) {
+                u4_a4 t = {v.x, v.y, v.z, v.w};
+                *reinterpret_cast<u4_a4 *>(out + (((int64_t)n * a.Co + oc) * hw + q) * ESIZE) = t;
             } else {
                 const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int pk = p0 + k * (4 / ESIZE);
                     if (pk >= a.M) break;
-                    const int n = pk / hw, q = pk - n * hw;
-                    *reinterpret_cast<uint32_t *>(out + (((int64_t)n * a.Co + oc) * hw + q) * ESIZE) = w4[k];
+                    const int nk = pk / hw, qk = pk - nk * hw;
+                    *reinterpret_cast<uint32_t *>(out + (((int64_t)nk * a.Co + oc) * hw + qk) * ESIZE) = w4[k];
                 }
             }
         }
