@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k(const char *buf, int region, in
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) va[j] = vb[j] = v4i{0, 0, 0, 0};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if ((MODE == 5 || MODE == 6 || MODE == 7) && wave >= NWAVES / 2) {
+    if ((MODE == 5 || MODE == 6 || MODE == 7) && wave >= NWAVES - 4) {  // the last four waves (one per SIMD)
         // consumer-like wave: 6 ds_read_b128 (1 KiB each) per 8 MFMAs (mode 6) / reads only (mode 5) / MFMAs only (mode 7)
         typedef int v16i __attribute__((ext_vector_type(16)));
         v16i c[8];
@@ -146,7 +146,7 @@ void run(const char *name, int blocks, const char *buf, int region, int *out, un
     double mean = 0;
     for (int i = 0; i < blocks; ++i) mean += (double)h[i];
     mean /= blocks;
-    const double bytes_per_block = (double)iters * (MODE >= 5 ? NWAVES / 2 : NWAVES) * BATCH * 1024;
+    const double bytes_per_block = (double)iters * (MODE >= 5 ? NWAVES - 4 : NWAVES) * BATCH * 1024;
     printf("%7.1f us  %6.2f TB/s chip  %6.1f GB/s per block  %5.1f B per s_memtime tick per block\n", ms * 1e3, bytes_per_block * blocks / (ms * 1e-3) / 1e12, bytes_per_block / (ms * 1e-3) / 1e9,
            bytes_per_block / mean);
     const hipError_t err = hipGetLastError();
@@ -176,6 +176,9 @@ int main()
         run<5, 8, 8>("4 DMA waves + 4 waves ds_read_b128", blocks, buf, region, out, cyc);
         run<6, 8, 8>("4 DMA waves + 4 waves read + MFMA", blocks, buf, region, out, cyc);
         run<7, 8, 8>("4 DMA waves + 4 waves MFMA only", blocks, buf, region, out, cyc);
+        run<6, 12, 4>("8 DMA waves + 4 waves read + MFMA", blocks, buf, region, out, cyc);
+        run<7, 12, 4>("8 DMA waves + 4 waves MFMA only", blocks, buf, region, out, cyc);
+        run<6, 6, 8>("2 DMA waves + 4 waves read + MFMA", blocks, buf, region, out, cyc);
         run<1, 4, 8>("global_load -> VGPR", blocks, buf, region, out, cyc);
         run<1, 8, 8>("global_load -> VGPR", blocks, buf, region, out, cyc);
         run<1, 1, 8>("global_load -> VGPR", blocks, buf, region, out, cyc);
