@@ -39,6 +39,24 @@ def _glob(d, exts):
     return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
 
 
+# sources whose kernels read LDS fragments through asynchronous inline asm (lds_read128_async): no spills allowed
+NO_SPILL_SOURCES = ("conv_igemm.hip", "conv_igemm_pp.hip", "conv_igemm_pc.hip", "conv_igemm_pcx.hip", "conv_igemm_res.hip",
+                    "conv_igemm_halo.hip")
+
+
+def spilled_kernels(usage_file):
+    """kernel names with 'VGPRs Spill: N > 0' in a -Rpass-analysis=kernel-resource-usage report"""
+    bad, name = [], "?"
+    with open(usage_file) as f:
+        for ln in f:
+            if "Function Name:" in ln:
+                name = ln.split("Function Name:")[1].split("[")[0].strip()
+            elif "VGPRs Spill:" in ln:
+                if int(ln.split("VGPRs Spill:")[1].split("[")[0].strip() or 0) > 0:
+                    bad.append(name)
+    return bad
+
+
 def build_hip(force=False):
     """One object per .hip file (compiled in parallel, rebuilt only when stale), then one link."""
     from concurrent.futures import ThreadPoolExecutor
@@ -57,8 +75,27 @@ def build_hip(force=False):
         if force or _newer(o, [f] + hdrs):
             stale.append((f, o))
     if stale:
+        def compile_one(fo):
+            # the register allocator's report goes next to the object (<name>.usage.txt): kernels whose fragment reads
+            # are asynchronous inline asm must not spill -- a register stored to scratch before its ds_read has landed
+            # is a wrong result, not a slow one (checked here, and by tests/test_cabi.py on the files)
+            cmd = [hipcc] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", fo[0], "-o", fo[1]]
+            print("+ " + " ".join(cmd), flush=True)
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            usage = [ln for ln in res.stderr.splitlines() if "kernel-resource-usage" in ln]
+            other = [ln for ln in res.stderr.splitlines() if "kernel-resource-usage" not in ln]
+            if other:
+                sys.stderr.write("\n".join(other) + "\n")
+            if res.returncode != 0:
+                raise subprocess.CalledProcessError(res.returncode, cmd)
+            with open(fo[1][:-2] + ".usage.txt", "w") as f:
+                f.write("\n".join(usage) + "\n")
+            bad = spilled_kernels(fo[1][:-2] + ".usage.txt") if os.path.basename(fo[0]) in NO_SPILL_SOURCES else []
+            if bad:
+                os.remove(fo[1])
+                raise RuntimeError("%s: register spills in kernels with asynchronous asm reads: %s" % (fo[0], ", ".join(bad)))
         with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 4)) as pool:
-            list(pool.map(lambda fo: _run([hipcc] + flags + ["-c", fo[0], "-o", fo[1]]), stale))
+            list(pool.map(compile_one, stale))
     if stale or force or _newer(out, objs):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", out])
     return out

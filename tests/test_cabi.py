@@ -107,3 +107,24 @@ def test_invalid_descriptors_are_rejected_before_touching_the_device(standalone)
     assert hip.shl_mi355x_conv_plan_create(None, None, None, None, None, C.byref(plan)) == -2
     assert hip.shl_mi355x_conv_forward(None, None, None, 0, None) == -2
     assert hip.shl_mi355x_relu_i8(None, None, 10, 1.0, 0, 1.0, 0, 0, None) == -2
+
+
+def test_kernels_with_asynchronous_fragment_reads_do_not_spill(built):
+    """The block-tile implicit-GEMM kernels read their MFMA fragments with asynchronous inline asm
+    (igemm_common.h:lds_read128_async).  A register the compiler spills before such a read has landed is stored as
+    garbage -- a wrong result, not a slow one (seen with a 12-wave producer / consumer flavour, profiles/r02_notes.md).
+    build.py keeps the register allocator's report of every object and refuses these sources when one spills; this
+    checks the reports of the library that is actually loaded."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("shl_build", os.path.join(pkg.HERE, "build.py"))
+    build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build)
+    objdir = os.path.join(pkg.HERE, "lib", "obj")
+    checked = 0
+    for src in build.NO_SPILL_SOURCES:
+        report = os.path.join(objdir, src[:-4] + ".usage.txt")
+        assert os.path.exists(report), "no register report for %s (rebuild with csi-nn2_amd/build.py)" % src
+        assert build.spilled_kernels(report) == [], src
+        with open(report) as f:
+            checked += sum("Function Name:" in ln for ln in f)
+    assert checked >= 50, checked
