@@ -152,28 +152,48 @@ __global__ __launch_bounds__(512) void conv_igemm_pc_kernel(ConvArgs a)
         }
         const char *const in_base = static_cast<const char *>(a.in);
         const char *const w_base = static_cast<const char *>(a.w);
-        const char *pad = static_cast<const char *>(a.pad_page) + ((blockIdx.x & 31) << 7) + ((lane & 7) << 4);
+        // The producers share their SIMDs with waves that keep the matrix pipe busy, and there EVERY instruction of
+        // theirs -- vector or scalar -- takes ~17 cycles to issue: two extra scalar instructions per piece cost the
+        // layer 25 % (measured).  So the source address of a piece is a 64-bit register pair that is rebuilt (tap
+        // offset, validity -> pad page) only when the K cursor enters a new filter tap, and advanced by one
+        // 128-byte channel group per K tile: per piece one vector add, the LDS destination, the request.
+        // (pad page: 8 x 512 bytes so that up to four channel groups of increments stay inside it)
+        const uint64_t padp = (uint64_t)(uintptr_t)(static_cast<const char *>(a.pad_page) + ((blockIdx.x & 7) << 9) + ((lane & 7) << 4));
+        uint64_t cur[G::NA], wcur[G::NWT];
+#pragma unroll
+        for (int j = 0; j < G::NWT; ++j) wcur[j] = (uint64_t)(uintptr_t)(w_base + woff[j]);
         int u_tx = 0, u_ty = 0, u_cc = 0;  // tap and position inside it of the next K tile to be requested
-        int w_step = 0;
         int slot_b = 0;                    // ring slot (byte offset) of the next K tile to be requested
         const int groups_per_tap = pix_bytes / BKBT;
         char *const dma_pix = smem + pw * G::NA * 1024;
         char *const dma_wgt = smem + G::PIX_B + pw * G::NWT * 1024;
         auto issue = [&]() {
             if (!(dbg & 4)) {
-                const int delta = (u_ty * a.dh * a.W + u_tx * a.dw) * pix_bytes + u_cc * BKBT;
-                const uint32_t bit = (1u << u_ty) | (0x10000u << u_tx);
+                if (u_cc == 0) {  // a new filter tap
+                    const int delta = (u_ty * a.dh * a.W + u_tx * a.dw) * pix_bytes;
+                    const uint32_t bit = (1u << u_ty) | (0x10000u << u_tx);
+#pragma unroll
+                    for (int q = 0; q < G::NA; ++q) {
+                        const bool ok = (amask[q] & bit) == bit;
+                        cur[q] = ok ? (uint64_t)(uintptr_t)(in_base + (aoff[q] + delta)) : padp;
+                    }
+                }
                 // weights and pixels alternate: neighbouring requests go to different tensors / L2 sets
 #pragma unroll
                 for (int q = 0; q < G::NA; ++q) {
-                    const bool ok = (amask[q] & bit) == bit;
-                    glds16(ok ? in_base + (aoff[q] + delta) : pad, dma_pix + slot_b + q * 1024);
-                    if (q < G::NWT) glds16(w_base + (woff[q] + w_step), dma_wgt + slot_b + q * 1024);
+                    glds16(reinterpret_cast<const char *>(cur[q]), dma_pix + slot_b + q * 1024);
+                    cur[q] += BKBT;
+                    if (q < G::NWT) {
+                        glds16(reinterpret_cast<const char *>(wcur[q]), dma_wgt + slot_b + q * 1024);
+                        wcur[q] += BKBT;
+                    }
                 }
 #pragma unroll
-                for (int q = G::NA; q < G::NWT; ++q) glds16(w_base + (woff[q] + w_step), dma_wgt + slot_b + q * 1024);
+                for (int q = G::NA; q < G::NWT; ++q) {
+                    glds16(reinterpret_cast<const char *>(wcur[q]), dma_wgt + slot_b + q * 1024);
+                    wcur[q] += BKBT;
+                }
             }
-            w_step += BKBT;
             slot_b += G::TILE_B;
             if (slot_b == NBUF * G::TILE_B) slot_b = 0;
             if (++u_cc == groups_per_tap) {
@@ -351,7 +371,7 @@ using PC128x128 = PCGeom<128, 128, 4>;  // 32 KiB per K tile, 128 KiB
 int pc_flavour(const ConvArgs &a, int esize, bool forced)
 {
     const int cb = a.C * esize;
-    if (cb % 128 != 0 || a.Kh * a.Kw > 16 || a.kstride != a.Kh * a.Kw * cb) return -1;
+    if (cb % 128 != 0 || cb > 512 || a.Kh * a.Kw > 16 || a.kstride != a.Kh * a.Kw * cb) return -1;  // (<= 4 groups: pad page)
     if (!a.out_nchw && (a.Co * esize) % 16 != 0) return -1;
     if (a.out_nchw && ((a.Ho * a.Wo * esize) & 3) != 0) return -1;
     if (a.Co < 16 || !a.pix_tab) return -1;  // the per-pixel address table comes with the plan
