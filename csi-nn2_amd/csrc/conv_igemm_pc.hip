@@ -39,12 +39,20 @@
 
 namespace shl {
 
-template <int BM_, int BN_, int NBUF_>
+// NCONS consumer waves as 2 (channels) x NCONS/2 (pixels), NPROD producer waves.  4 + 4: one of each per SIMD, up to
+// 256 registers a wave.  8 + 8: sixteen waves of at most 128 registers -- a wave's LDS-DMA instruction takes 100-140
+// cycles to issue next to MFMA waves however little else the producer does, so the request rate of a CU scales with
+// the NUMBER of producer waves (tools/probes/l2_to_lds.hip: 41 -> 71 B per cycle from 4 -> 8), and consumers with
+// 64 x 64 wave tiles (64 accumulators) are what fits next to eight of them.
+template <int BM_, int BN_, int NBUF_, int NCONS_ = 4, int NPROD_ = 4>
 struct PCGeom {
-    static constexpr int BM = BM_, BN = BN_, NBUF = NBUF_, BKBT = 128, KS = 4, TC = 2, TP = BM_ / 64;
+    static constexpr int NCONS = NCONS_, NPROD = NPROD_, THREADS = 64 * (NCONS_ + NPROD_);
+    static constexpr int CWP = NCONS_ / 2;          // consumer waves along the pixels
+    static constexpr int WPIX = BM_ / CWP;          // pixels of a consumer's wave tile
+    static constexpr int BM = BM_, BN = BN_, NBUF = NBUF_, BKBT = 128, KS = 4, TC = 2, TP = WPIX / 32;
     static constexpr int RPP = 8;                   // rows per 1-KiB DMA piece (8 chunk slots per row)
-    static constexpr int NA = BM / RPP / 4;         // DMA pieces per producer wave per K tile: pixels
-    static constexpr int NWT = BN / RPP / 4;        //                                          weights
+    static constexpr int NA = BM / RPP / NPROD;     // DMA pieces per producer wave per K tile: pixels
+    static constexpr int NWT = BN / RPP / NPROD;    //                                          weights
     static constexpr int PER = NA + NWT;
     static constexpr int PIX_B = BM * BKBT;
     static constexpr int WGT_B = BN * BKBT;
@@ -96,12 +104,13 @@ __device__ __forceinline__ void pc_wait_b(v4i (&fa)[2], v4i &fb)
 __device__ unsigned long long g_pc_trace[1024];
 
 template <bool kI8, int EPI, typename G, int kAbl = 0>
-__global__ __launch_bounds__(512) void conv_igemm_pc_kernel(ConvArgs a)
+__global__ __launch_bounds__(G::THREADS) void conv_igemm_pc_kernel(ConvArgs a)
 {
-    int trace_k = (threadIdx.x >> 8) * 512;
+    int trace_k = threadIdx.x == 0 ? 0 : 512;  // consumer wave 0 / the first producer wave
     auto mark = [&]() {
         if constexpr ((kAbl & 32) != 0) {
-            if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (trace_k & 511) < 500) g_pc_trace[trace_k++] = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 64 * G::NCONS) && (trace_k & 511) < 500)
+                g_pc_trace[trace_k++] = __builtin_amdgcn_s_memtime();
         }
     };
     mark();
@@ -123,9 +132,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pc_kernel(ConvArgs a)
     constexpr int dbg = kAbl;
     const int nk = a.kstride / BKBT;
 
-    if (wave >= 4) {
+    if (wave >= G::NCONS) {
         // =========================================================================== producers
-        const int pw = wave - 4;
+        const int pw = wave - G::NCONS;
         if (a.debug & 64) __builtin_amdgcn_s_setprio(3);  // A/B: producers' few instructions ahead of the consumers' MFMAs
         const int drow = lane >> 3;
         const int dslot = lane & 7;
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pc_kernel(ConvArgs a)
     }
     if (a.debug & 128) __builtin_amdgcn_s_setprio(3);  // A/B: the other way round
     const int wc = wave & 1;   // channels [64 wc, +64)
-    const int wp = wave >> 1;  // pixels [BM/2 wp, +BM/2)
+    const int wp = wave >> 1;  // pixels [WPIX wp, +WPIX)
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
     // byte offset of this lane's fragment chunk inside a 32-row block, per K sub-step (row bases are multiples
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pc_kernel(ConvArgs a)
     for (int ks = 0; ks < G::KS; ++ks) sw[ks] = frow * BKBT + (((2 * ks + fhalf) ^ pc_swz(frow)) << 4);
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const uint32_t baseA = lds0 + G::PIX_B + wc * 64 * BKBT;
-    const uint32_t baseB = lds0 + wp * (G::BM / 2) * BKBT;
+    const uint32_t baseB = lds0 + wp * G::WPIX * BKBT;
 
     using acc_t = typename AccT<kI8>::type;
     acc_t acc[TC][TP];
@@ -352,21 +361,23 @@ __global__ __launch_bounds__(512) void conv_igemm_pc_kernel(ConvArgs a)
     const float *tab_mult = reinterpret_cast<const float *>(smem + G::TAB_OFF) + G::BN + wc * 64;
     const float *tab_bias = reinterpret_cast<const float *>(smem + G::TAB_OFF) + 2 * G::BN + wc * 64;
     constexpr int WS_B = 64 * (64 * ESIZE + 16);
-    static_assert(4 * WS_B <= G::TAB_OFF, "epilogue staging must fit in the ring");
+    static_assert(G::NCONS * WS_B <= G::TAB_OFF, "epilogue staging must fit in the ring");
     char *ws = smem + wave * WS_B;
 #pragma unroll
     for (int jh = 0; jh < TP / 2; ++jh)
         // kBulk: a consumer runs the epilogue alone on its SIMD (igemm_common.h)
-        igemm_store_block64<kI8, EPI, acc_t, true>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], ws,
-                                      pix0 + wp * (G::BM / 2) + jh * 64, co0 + wc * 64, tab_acc, tab_mult, tab_bias, lane);
+        igemm_store_block64<kI8, EPI, acc_t, G::NCONS == 4>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], ws,
+                                      pix0 + wp * G::WPIX + jh * 64, co0 + wc * 64, tab_acc, tab_mult, tab_bias, lane);
     mark();
 }
 
 // ---------------------------------------------------------------------------------------------------
 using PC256x128 = PCGeom<256, 128, 3>;  // 48 KiB per K tile, 144 KiB
 using PC128x128 = PCGeom<128, 128, 4>;  // 32 KiB per K tile, 128 KiB
+using PC256x128W16 = PCGeom<256, 128, 3, 8, 8>;  // sixteen waves: 8 consumers of 64 x 64, 8 producers
 
-// flavour for a problem (0: 256 x 128, 1: 128 x 128), or -1 when this kernel does not apply.
+// flavour for a problem (0: 256 x 128 with 4 + 4 waves, 1: 128 x 128, 2: 256 x 128 with 8 + 8 waves), or -1 when this
+// kernel does not apply.
 // `forced`: SHL_MI355X_IGEMM=pc, with SHL_MI355X_PC naming a flavour.
 int pc_flavour(const ConvArgs &a, int esize, bool forced)
 {
@@ -378,15 +389,15 @@ int pc_flavour(const ConvArgs &a, int esize, bool forced)
     // 32-bit source offsets inside the kernel: input and packed weights below 2 GiB
     if ((int64_t)a.N * a.H * a.W * cb >= (1ll << 31) - 65536 || (int64_t)a.Co * a.kstride >= (1ll << 31) - 65536) return -1;
     static const char *env = getenv("SHL_MI355X_PC");
-    if (env) return !strcmp(env, "128x128") ? 1 : 0;
+    if (env) return !strcmp(env, "128x128") ? 1 : !strcmp(env, "256x128w16") ? 2 : 0;
     const int64_t t256 = (((int64_t)a.M + 255) / 256) * ((a.Co + 127) / 128);
-    if (forced) return t256 >= 160 ? 0 : 1;
+    if (forced) return t256 >= 160 ? 2 : 1;
     // automatic (ResNet-50 3x3 set at batch 128, profiles/r02_notes.md): deep-K layers with at most ~one 256 x 128
     // tile per CU -- 256 -> 256 @14 27.3 -> 22.9 us, 512 -> 512 @7 (196 tiles of 128 x 128) 25.7 -> 22.9 us; with
     // more tiles than that the two-workgroups-per-CU ping-pong flavour overlaps whole tiles and stays ahead
     if (a.kstride < 1024 || t256 >= 300) return -1;
     const int64_t t128 = (((int64_t)a.M + 127) / 128) * ((a.Co + 127) / 128);
-    if (t256 >= 160) return 0;
+    if (t256 >= 160) return 2;  // sixteen waves: 22.0 vs 23.3 us on 256 -> 256 @28 s2, 21.5-22.0 vs 22.6 on 256 -> 256 @14
     return t128 >= 128 ? 1 : -1;
 }
 
@@ -402,7 +413,7 @@ static void pc_launch(const ConvArgs &a, bool i8, int epi, hipStream_t s)
                                       160 * 1024);                                                                \
             opted = true;                                                                                         \
         }                                                                                                         \
-        hipLaunchKernelGGL(KERNEL, dim3(tiles), dim3(512), G::LDS_B, s, a);                                       \
+        hipLaunchKernelGGL(KERNEL, dim3(tiles), dim3(G::THREADS), G::LDS_B, s, a);                                       \
     } while (0)
     if (!i8) {
         SHL_PC((conv_igemm_pc_kernel<false, 0, G>));
@@ -443,6 +454,7 @@ int launch_conv_igemm_pc(const ConvArgs &a, int dtype, int flavour, hipStream_t 
     switch (flavour) {
         case 0: pc_launch<PC256x128>(a, i8, epi, s); break;
         case 1: pc_launch<PC128x128>(a, i8, epi, s); break;
+        case 2: pc_launch<PC256x128W16>(a, i8, epi, s); break;
         default: return SHL_MI355X_ENOTSUP;
     }
     SHL_HIP(hipGetLastError());

@@ -54,6 +54,7 @@ VARIANTS = [
     # (SHL_MI355X_PCX=1: stride-1 "same" 3x3 shapes run its shifted-row form conv_igemm_pcx.hip)
     (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="256x128"), "pc"),
     (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="128x128"), "pc"),
+    (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="256x128w16"), "pc"),
     (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="256x128", SHL_MI355X_PCX="1"), "pc"),
     (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="128x128", SHL_MI355X_PCX="1"), "pc"),
     (dict(SHL_MI355X_IGEMM="pc"), "pc"),
