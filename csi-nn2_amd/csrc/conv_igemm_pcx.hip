@@ -1,31 +1,29 @@
 // conv_igemm_pcx.hip -- conv_igemm_pc.hip (producer / consumer waves, 128-byte K tiles) for stride-1 "same"
 // convolutions with three filter columns, with the input pixels of a filter ROW staged ONCE for its three taps.
 //
-// Why: next to waves that keep the matrix pipe busy, four LDS-DMA producer waves deliver ~30 B/clk per CU instead
-// of the ~55 they reach alone (tools/probes/l2_to_lds.hip, modes 6 / 7), and conv_igemm_pc.hip's K loop is paced by
-// exactly that (profiles/r02_pc_trace_*.txt: 1 650 ticks of DMA issue per K tile against 1 290 of MFMA).  The lever
-// left is the byte count.  With stride 1, dilation 1, Wo == W, Ho == H and pad_left == 1 the flat pixel index of
-// tap (ky, kx) of output pixel p is  q = p + (ky - pad_top) * W + (kx - 1):  the B operands of the taps kx = 0, 1, 2
-// are the SAME rows of the input, shifted by one pixel.  So K runs in the order (ky, 128-byte channel group, kx);
-// per (ky, channel group) the producers stage BM + 2 pixel rows once ("pixel stage", double buffered) and the
-// consumers read the fragment rows at row offsets 0 / 1 / 2; only the weights stream per K tile.  Bytes through
-// the vector-memory path per three K tiles: (BM + 2 + 3 * 128) * 128 instead of 3 * (BM + 128) * 128 -- 1.8x fewer
-// for the 256 x 128 tile.
+// Why: under dense MFMA issue a CU's LDS-DMA delivers ~29 B per cycle whatever the number of requesting waves
+// (profiles/r02_notes.md), and a 256 x 128 tile needs 47 at the full matrix rate: conv_igemm_pc.hip's K loop is
+// DMA-bound.  The lever left is the byte count.  With stride 1, dilation 1, Wo == W, Ho == H and pad_left == 1 the B
+// operands of the taps kx = 0, 1, 2 of a filter row are the same input pixels shifted by one.  K runs in the order
+// (ky, 128-byte channel group, kx); per (ky, channel group) the producers stage the pixel rows ONCE ("pixel stage",
+// two buffers) and the consumers read their fragment rows at row offsets 0 / 1 / 2; only the weights stream per K
+// tile (ring of 4).  Bytes through the vector-memory path per three K tiles: (~300 + 3 * 128) * 128 instead of
+// 3 * (256 + 128) * 128 -- 1.7x fewer.
 //
-// What the shift cannot express is the padding: a staged row holds the CENTRE tap (kx = 1) of output pixel
-// p_c = pix0 + row - 1, so
-//   * rows whose centre pixel has filter row ky outside the image (or lies outside the tensor) are fetched from
-//     the pad page by the producers (validity bits of the plan's per-pixel table, ConvArgs::pix_tab);
-//   * the left / right neighbours of the first / last pixel of an image row are the previous / next row's pixels
-//     in the staged data: the consumers replace those B fragments (kx = 0 at ox = 0, kx = 2 at ox = W - 1) by the
-//     zero point after the fragment has landed -- 4 v_cndmask per fragment, in the shadow of the MFMAs.
-//   Every other use of a staged row comes from pixels of the centre pixel's own image row, so one validity bit
-//   per staged row is exact.
+// Padding without touching the consumers: the staged rows are not the flat pixel range but the range of "padded
+// slots" -- every image row occupies W + 2 slots [zero point][x = 0 .. W-1][zero point]: slot(row r, x) =
+// r * (W + 2) + 1 + x.  Output pixel p = (r, ox) reads, for tap kx, slot u(p) + kx - 1 with u(p) = p + 2 r + 1, so
+// the left neighbour of ox = 0 and the right neighbour of ox = W - 1 ARE zero-point rows, fetched from the pad page
+// by the producers like the rows whose filter row ky lies above / below the image (validity bits of the plan's
+// per-pixel table).  A consumer lane's fragment row for (pixel, kx) is i + 2 (r - r0) + kx -- a per-lane constant
+// per tile, no masks, no v_cndmask (the first version of this file substituted the row-end neighbours in the
+// consumers and lost what the DMA saved).
 //
-// Synchronisation as in conv_igemm_pc.hip: one workgroup barrier per K tile, in the consumers' stream between
-// the last fragment read of tile t and the first of tile t+1.  Producer "slot" t (after barrier t) requests the
-// weights of tile t + NWB and, in the first two slots after a pixel stage has been released, the pixel pieces of
-// the stage after next; vmcnt bookkeeping in certify() below.
+// Sixteen waves as conv_igemm_pc.hip's 256x128w16 flavour: 8 consumers (64 channels x 64 pixels) + 8 producers.
+// Synchronisation as there: one workgroup barrier per K tile, in the consumers' stream between the last fragment
+// read of tile t and the first of tile t+1.  Producer "slot" t (after barrier t) requests the weights of tile
+// t + NWB and, in the first two slots after a pixel stage has been released, the pixel pieces of the stage after
+// next; vmcnt bookkeeping in certify() below.
 //
 // Replaces shl_ref_conv2d_nhwc_f32 / shl_ref_conv2d_nchw_f32 + conv_im2col_sgemm_avx
 // (source/reference/convolution.c:28-139, conv_avx.h:109-1008) inside shl_ref_conv2d_quant.
@@ -38,18 +36,18 @@
 
 namespace shl {
 
-template <int BM_, int NWB_>
 struct PCXGeom {
-    static constexpr int BM = BM_, BN = 128, NWB = NWB_, NPS = 2, BKBT = 128, KS = 4, TC = 2, TP = BM_ / 64;
-    static constexpr int RPP = 8;                       // rows per 1-KiB DMA piece
-    static constexpr int PS_ROWS = BM + 8;              // rows 0 .. BM+1 are used
-    static constexpr int PS_B = PS_ROWS * BKBT;         // one pixel stage
-    static constexpr int WGT_B = BN * BKBT;             // one K tile of weights
-    static constexpr int NAF = BM / RPP / 4;            // full pixel pieces per producer wave per stage
-    static constexpr int NAS = NAF + 1;                 // ... plus its 2-row piece behind row BM
-    static constexpr int PA = (NAS + 1) / 2;            // pixel pieces requested in the slot after the releasing barrier
-    static constexpr int PB = NAS - PA;                 // ... and in the slot after that
-    static constexpr int NWT = BN / RPP / 4;            // weight pieces per producer wave per K tile
+    static constexpr int BM = 256, BN = 128, NWB = 4, NPS = 2, BKBT = 128, KS = 4, TC = 2, TP = 2;
+    static constexpr int NCONS = 8, NPROD = 8, THREADS = 64 * (NCONS + NPROD);
+    static constexpr int RPP = 8;                        // rows per 1-KiB DMA piece
+    static constexpr int PS_PIECES = 43;                 // staged rows: at most 256 + 2 * 38 + 2 = 334 (W >= 7)
+    static constexpr int PS_ROWS = PS_PIECES * RPP;      // 344
+    static constexpr int PS_B = PS_ROWS * BKBT;          // one pixel stage: 43 KiB
+    static constexpr int WGT_B = BN * BKBT;              // one K tile of weights: 16 KiB
+    static constexpr int NAS = (PS_PIECES + NPROD - 1) / NPROD;  // pixel pieces per producer wave per stage (6)
+    static constexpr int PA = (NAS + 1) / 2;             // ... requested in the slot after the releasing barrier
+    static constexpr int PB = NAS - PA;                  // ... and in the slot after that
+    static constexpr int NWT = BN / RPP / NPROD;         // weight pieces per producer wave per K tile (2)
     static constexpr int WGT_OFF = NPS * PS_B;
     static constexpr int TAB_OFF = WGT_OFF + NWB * WGT_B;
     static constexpr int LDS_B = TAB_OFF + 3 * BN * 4;
@@ -67,6 +65,23 @@ __device__ __forceinline__ void pcx_barrier()
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// v / d for 0 <= v < 2^22 by fp32 reciprocal (error at most one, corrected); rem = v % d
+__device__ __forceinline__ int pcx_div(int v, int d, float rcp, int &rem)
+{
+    int q = (int)((float)v * rcp);
+    int r = v - q * d;
+    if (r < 0) {
+        --q;
+        r += d;
+    }
+    if (r >= d) {
+        ++q;
+        r -= d;
+    }
+    rem = r;
+    return q;
+}
+
 template <int CNT>
 __device__ __forceinline__ void pcx_wait_b(v4i (&fa)[2], v4i &fb)
 {
@@ -74,14 +89,9 @@ __device__ __forceinline__ void pcx_wait_b(v4i (&fa)[2], v4i &fb)
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int TP>
-__device__ __forceinline__ void pcx_wait_all(v4i (&fa)[2], v4i (&fb)[TP])
+__device__ __forceinline__ void pcx_wait_all(v4i (&fa)[2], v4i (&fb)[2])
 {
-    if constexpr (TP == 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]));
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1]));
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -104,13 +114,15 @@ __device__ __forceinline__ void pcx_wait_vmcnt(int n)
 // SHL_MI355X_DEBUG=32: phase stamps as in conv_igemm_pc.hip (tools/pp_trace.py --pc)
 __device__ unsigned long long g_pcx_trace[1024];
 
-template <bool kI8, int EPI, typename G, bool kTrace = false>
-__global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
+template <bool kI8, int EPI, bool kTrace = false>
+__global__ __launch_bounds__(PCXGeom::THREADS) void conv_igemm_pcx_kernel(ConvArgs a)
 {
-    int trace_k = (threadIdx.x >> 8) * 512;
+    using G = PCXGeom;
+    int trace_k = threadIdx.x == 0 ? 0 : 512;
     auto mark = [&]() {
         if constexpr (kTrace) {
-            if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (trace_k & 511) < 500) g_pcx_trace[trace_k++] = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 64 * G::NCONS) && (trace_k & 511) < 500)
+                g_pcx_trace[trace_k++] = __builtin_amdgcn_s_memtime();
         }
     };
     mark();
@@ -132,22 +144,32 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
     const int groups = pix_bytes / BKBT;   // 128-byte channel groups per pixel
     const int nstage = a.Kh * groups;      // pixel stages (ky, channel group)
     const int nk = nstage * 3;             // K tiles
+    // padded slots: image row r (global: n * H + oy) occupies slots [r * (W + 2), +W + 2); the tile's staged row s is
+    // slot s0 + s, s0 = u(pix0) - 1 = pix0 + 2 * r0
+    const int r0 = pix0 / a.W;
+    const int s0 = pix0 + 2 * r0;
 
-    if (wave >= 4) {
+    if (wave >= G::NCONS) {
         // =========================================================================== producers
-        const int pw = wave - 4;
+        const int pw = wave - G::NCONS;
         const int drow = lane >> 3;
         const int dslot = lane & 7;
-        int32_t poff[G::NAS];    // centre-tap source offset of the staged row's pixel, filter row 0, chunk slot folded in
-        uint32_t pmask[G::NAS];  // valid ky bits (0: the row's centre pixel lies outside the tensor)
+        int32_t poff[G::NAS];    // source offset of the staged row's pixel, filter row 0, chunk slot folded in
+        uint32_t pmask[G::NAS];  // valid ky bits (0: a zero-point slot, or outside the tensor)
         int32_t woff[G::NWT];
+        const int w2 = a.W + 2;
+        const float rcp_w2 = __frcp_rn((float)w2);
 #pragma unroll
         for (int j = 0; j < G::NAS; ++j) {
-            // full pieces: rows 8 * (pw * NAF + j) + drow; last piece: rows BM + 2 * pw + drow of lanes 0-15
-            const int s = j < G::NAF ? (pw * G::NAF + j) * G::RPP + drow : G::BM + 2 * pw + (drow & 1);
-            const int pc = pix0 + s - 1;
-            const bool inside = pc >= 0 && pc < a.M;
-            const int2 e = a.pix_tab[inside ? pc : 0];
+            // piece j * NPROD + pw (pieces past the last one repeat this wave's previous piece: same rows, same data)
+            int pi = j * G::NPROD + pw;
+            pi = pi < G::PS_PIECES ? pi : pi - G::NPROD;
+            const int s = pi * G::RPP + drow;
+            int c;
+            const int r = pcx_div(s0 + s, w2, rcp_w2, c);
+            const int p = r * a.W + c - 1;
+            const bool inside = c != 0 && c != a.W + 1 && p < a.M;
+            const int2 e = a.pix_tab[inside ? p : 0];
             poff[j] = e.x + a.pl * pix_bytes + ((dslot ^ pcx_swz(s)) << 4);
             pmask[j] = inside ? ((uint32_t)e.y & 0xffffu) : 0u;
         }
@@ -189,12 +211,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
 #pragma unroll
             for (int j = FROM; j < TO; ++j) {
                 const bool ok = ((pmask[j] >> p_ky) & 1u) != 0;
-                const char *src = ok ? in_base + (poff[j] + delta) : pad;
-                if (j < G::NAF) {
-                    glds16(src, buf + (pw * G::NAF + j) * 1024);
-                } else if (lane < 16) {  // two rows behind row BM
-                    glds16(src, buf + (G::BM + 2 * pw) * BKBT);
-                }
+                int pi = j * G::NPROD + pw;
+                pi = pi < G::PS_PIECES ? pi : pi - G::NPROD;
+                glds16(ok ? in_base + (poff[j] + delta) : pad, buf + pi * 1024);
             }
         };
         auto next_stage = [&]() {
@@ -275,30 +294,31 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
         t_bias = a.bias[c];
     }
     const int wc = wave & 1;   // channels [64 wc, +64)
-    const int wp = wave >> 1;  // pixels [BM/2 wp, +BM/2)
+    const int wp = wave >> 1;  // pixels [64 wp, +64)
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
-    // x validity of this lane's pixels (one per 32-pixel block): bit kx of the table's column mask
-    uint32_t xmask[TP];
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        const int p = pix0 + wp * (G::BM / 2) + j * 32 + frow;
-        xmask[j] = (uint32_t)a.pix_tab[p < a.M ? p : a.M - 1].y >> 16;
-    }
-    const int zpb = kI8 ? (a.in_zp & 0xff) * 0x01010101 : 0;
-    const v4i zpv = {zpb, zpb, zpb, zpb};
-    // byte offsets of this lane's fragment chunk: weights by K sub-step; pixels by (column tap, K sub-step) -- the
-    // staged row of tap kx is frow + kx, whose swizzle differs (block bases are multiples of 32 rows: no effect)
-    uint32_t swa[G::KS], swb[3][G::KS];
-#pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {
-        swa[ks] = frow * BKBT + (((2 * ks + fhalf) ^ pcx_swz(frow)) << 4);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) swb[kx][ks] = (frow + kx) * BKBT + (((2 * ks + fhalf) ^ pcx_swz(frow + kx)) << 4);
-    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    // byte offset (K sub-step 0; sub-step ks: ^ ks << 5) of this lane's pixel fragment chunk inside a pixel stage, by
+    // pixel block j and column tap kx: staged row i + 2 (r - r0) + kx, chunk slot swizzled by the row
+    uint32_t adrb[TP][3];
+    {
+        const float rcp_w = __frcp_rn((float)a.W);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int i = wp * 64 + j * 32 + frow;
+            int p = pix0 + i;
+            p = p < a.M ? p : a.M - 1;
+            int ox;
+            const int r = pcx_div(p, a.W, rcp_w, ox);
+            const int row = (p - pix0) + 2 * (r - r0);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) adrb[j][kx] = lds0 + (row + kx) * BKBT + ((fhalf ^ pcx_swz(row + kx)) << 4);
+        }
+    }
+    uint32_t swa[G::KS];  // weights: byte offset of the lane's chunk inside a 32-row block, by K sub-step
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) swa[ks] = frow * BKBT + (((2 * ks + fhalf) ^ pcx_swz(frow)) << 4);
     const uint32_t baseA = lds0 + G::WGT_OFF + wc * 64 * BKBT;
-    const uint32_t baseB = lds0 + wp * (G::BM / 2) * BKBT;
 
     using acc_t = typename AccT<kI8>::type;
     acc_t acc[TC][TP];
@@ -310,54 +330,47 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-    // One K sub-step of a tile with column tap KXC: 2*TP MFMAs on (fa, fb), the reads of the next sub-step (weights
-    // at wnext + swa[ks], pixels of column tap KXN at pnext + swb[KXN][ks]) one per MFMA gap, counted waits as in
-    // conv_igemm_pc.hip, and the zero-point substitution of a B fragment right after the wait that certifies it.
-    auto substep = [&](auto kxc_c, auto kxn_c, v4i(&fa)[TC], v4i(&fb)[TP], uint32_t wnext, uint32_t pnext, int ks, v4i(&na)[TC],
-                       v4i(&nb)[TP]) {
-        constexpr int KXC = decltype(kxc_c)::value, KXN = decltype(kxn_c)::value;
+    // One K sub-step: 4 MFMAs on (fa, fb); the 4 reads of the next sub-step (weights at wnext + swa[ks], pixels of
+    // column tap KXN, sub-step ks, in the pixel buffer at byte offset pnext) one per MFMA gap; reads are issued in the
+    // order A0 A1 B0 B1, MFMAs as (A0,B0) (A1,B0) (A0,B1) (A1,B1): waits for all but 1, then all but 2 (+ new reads).
+    auto substep = [&](auto kxn_c, v4i(&fa)[TC], v4i(&fb)[TP], uint32_t wnext, uint32_t pnext, int ks, v4i(&na)[TC], v4i(&nb)[TP]) {
+        constexpr int KXN = decltype(kxn_c)::value;
         const uint32_t oa = baseA + wnext + swa[ks];
-        const uint32_t ob = baseB + pnext + swb[KXN][ks];
-        static_for<TC * TP>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            constexpr int i = m % TC, j = m / TC;
-            if constexpr (i == 0) {
-                constexpr int issued = m < G::NR ? m : G::NR;
-                pcx_wait_b<TP - 1 - j + issued>(fa, fb[j]);
-                if constexpr (KXC != 1) {
-                    const bool keep = ((xmask[j] >> KXC) & 1u) != 0;
-                    fb[j][0] = keep ? fb[j][0] : zpv[0];
-                    fb[j][1] = keep ? fb[j][1] : zpv[1];
-                    fb[j][2] = keep ? fb[j][2] : zpv[2];
-                    fb[j][3] = keep ? fb[j][3] : zpv[3];
-                }
-            }
-            acc[i][j] = mfma<kI8>(fa[i], fb[j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (m < G::NR) {
-                if constexpr (m < TC)
-                    lds_read128_async<m * 32 * BKBT>(na[m], oa);
-                else
-                    lds_read128_async<(m - TC) * 32 * BKBT>(nb[m - TC], ob);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
+        const uint32_t x = (uint32_t)ks << 5;
+        pcx_wait_b<1>(fa, fb[0]);
+        acc[0][0] = mfma<kI8>(fa[0], fb[0], acc[0][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_read128_async<0>(na[0], oa);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1][0] = mfma<kI8>(fa[1], fb[0], acc[1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_read128_async<32 * BKBT>(na[1], oa);
+        __builtin_amdgcn_sched_barrier(0);
+        pcx_wait_b<2>(fa, fb[1]);
+        acc[0][1] = mfma<kI8>(fa[0], fb[1], acc[0][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_read128_async<0>(nb[0], (adrb[0][KXN] ^ x) + pnext);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1][1] = mfma<kI8>(fa[1], fb[1], acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_read128_async<0>(nb[1], (adrb[1][KXN] ^ x) + pnext);
+        __builtin_amdgcn_sched_barrier(0);
     };
     // one K tile with column tap KX; the tile after it has column tap (KX + 1) % 3, pixel buffer pn, weight slot wn
     auto ktile = [&](auto kx_c, uint32_t wcur, uint32_t pcur, uint32_t wn, uint32_t pn) {
         constexpr int KX = decltype(kx_c)::value;
         using C = std::integral_constant<int, KX>;
         using N = std::integral_constant<int, (KX + 1) % 3>;
-        substep(C{}, C{}, fa0, fb0, wcur, pcur, 1, fa1, fb1);
-        substep(C{}, C{}, fa1, fb1, wcur, pcur, 2, fa0, fb0);
-        substep(C{}, C{}, fa0, fb0, wcur, pcur, 3, fa1, fb1);
+        substep(C{}, fa0, fb0, wcur, pcur, 1, fa1, fb1);
+        substep(C{}, fa1, fb1, wcur, pcur, 2, fa0, fb0);
+        substep(C{}, fa0, fb0, wcur, pcur, 3, fa1, fb1);
         mark();
-        pcx_wait_all<TP>(fa1, fb1);  // the last reads of this tile have landed
+        pcx_wait_all(fa1, fb1);  // the last reads of this tile have landed
         mark();
-        pcx_barrier();               // barrier t
+        pcx_barrier();           // barrier t
         mark();
         // unconditional: after the last tile these reads fetch stale slots that nobody consumes
-        substep(C{}, N{}, fa1, fb1, wn, pn, 0, fa0, fb0);
+        substep(N{}, fa1, fb1, wn, pn, 0, fa0, fb0);
         mark();
     };
 
@@ -371,15 +384,11 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
     pcx_barrier();  // barrier P: pixel stage 0 and the weights of tile 0 are complete
     mark();
     {
-        const uint32_t oa = baseA + swa[0], ob = baseB + swb[0][0];
+        const uint32_t oa = baseA + swa[0];
         lds_read128_async<0>(fa0[0], oa);
         lds_read128_async<32 * BKBT>(fa0[1], oa);
-        lds_read128_async<0>(fb0[0], ob);
-        lds_read128_async<32 * BKBT>(fb0[1], ob);
-        if constexpr (TP == 4) {
-            lds_read128_async<64 * BKBT>(fb0[2], ob);
-            lds_read128_async<96 * BKBT>(fb0[3], ob);
-        }
+        lds_read128_async<0>(fb0[0], adrb[0][0]);
+        lds_read128_async<0>(fb0[1], adrb[1][0]);
     }
     uint32_t ws = 0;  // weight ring slot (byte offset) of the tile being consumed
     uint32_t pb = 0;  // pixel buffer (byte offset) of the stage being consumed
@@ -396,62 +405,58 @@ __global__ __launch_bounds__(512) void conv_igemm_pcx_kernel(ConvArgs a)
         ws = w3;
         pb = pnext;
     }
-    pcx_wait_all<TP>(fa0, fb0);  // the stale prefetch must have landed before its registers are reused
+    pcx_wait_all(fa0, fb0);  // the stale prefetch must have landed before its registers are reused
 
-    // ---- epilogue (consumer waves; no ring reads are outstanding)
+    // ---- epilogue (the eight consumer waves, one 64 x 64 block each; no ring reads are outstanding)
     const int32_t *tab_acc = reinterpret_cast<const int32_t *>(smem + G::TAB_OFF) + wc * 64;
     const float *tab_mult = reinterpret_cast<const float *>(smem + G::TAB_OFF) + G::BN + wc * 64;
     const float *tab_bias = reinterpret_cast<const float *>(smem + G::TAB_OFF) + 2 * G::BN + wc * 64;
     constexpr int WS_B = 64 * (64 * ESIZE + 16);
-    static_assert(4 * WS_B <= G::TAB_OFF, "epilogue staging must fit in front of the tables");
+    static_assert(G::NCONS * WS_B <= G::TAB_OFF, "epilogue staging must fit in front of the tables");
     char *wsb = smem + wave * WS_B;
-#pragma unroll
-    for (int jh = 0; jh < TP / 2; ++jh)
-        // kBulk: a consumer runs the epilogue alone on its SIMD (igemm_common.h)
-        igemm_store_block64<kI8, EPI, acc_t, true>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], wsb,
-                                      pix0 + wp * (G::BM / 2) + jh * 64, co0 + wc * 64, tab_acc, tab_mult, tab_bias, lane);
+    igemm_store_block64<kI8, EPI>(a, acc[0][0], acc[0][1], acc[1][0], acc[1][1], wsb, pix0 + wp * 64, co0 + wc * 64, tab_acc,
+                                  tab_mult, tab_bias, lane);
     mark();
 }
 
 // ---------------------------------------------------------------------------------------------------
-using PCX256 = PCXGeom<256, 5>;  // 2 x 33 KiB of pixels + 5 x 16 KiB of weights
-using PCX128 = PCXGeom<128, 6>;  // 2 x 17 KiB + 6 x 16 KiB
-
-// stride-1 "same" convolution with three filter columns: the shifted-row staging applies
+// stride-1 "same" convolution with three filter columns and images at least 7 pixels wide: the padded-slot staging
+// applies (344 staged rows hold 256 pixels + two zero-point slots per image row they span)
 bool pcx_applies(const ConvArgs &a)
 {
-    return a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && a.Kw == 3 && a.pl == 1 && a.Wo == a.W && a.Ho == a.H && a.W >= 2;
+    return a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1 && a.Kw == 3 && a.pl == 1 && a.Wo == a.W && a.Ho == a.H && a.W >= 7 &&
+           (int64_t)a.M + 2 * ((int64_t)a.M / a.W) + 2 < (1 << 22);
 }
 
-template <typename G>
 static void pcx_launch(const ConvArgs &a, bool i8, int epi, hipStream_t s)
 {
+    using G = PCXGeom;
     const unsigned tiles = (unsigned)(((a.M + G::BM - 1) / G::BM) * ((a.Co + G::BN - 1) / G::BN));
-#define SHL_PCX(KERNEL)                                                                                           \
+#define SHL_PCX(...)                                                                                              \
     do {                                                                                                          \
         static bool opted = false;                                                                                \
         if (!opted) {                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_pcx_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024);                                                                \
             opted = true;                                                                                         \
         }                                                                                                         \
-        hipLaunchKernelGGL(KERNEL, dim3(tiles), dim3(512), G::LDS_B, s, a);                                       \
+        hipLaunchKernelGGL((conv_igemm_pcx_kernel<__VA_ARGS__>), dim3(tiles), dim3(G::THREADS), G::LDS_B, s, a);   \
     } while (0)
     if (!i8) {
-        SHL_PCX((conv_igemm_pcx_kernel<false, 0, G>));
+        SHL_PCX(false, 0);
         return;
     }
     if (a.debug == 32) {  // traced build, literal epilogue only
-        SHL_PCX((conv_igemm_pcx_kernel<true, 2, G, true>));
+        SHL_PCX(true, 2, true);
         return;
     }
     switch (epi) {
-        case 0: SHL_PCX((conv_igemm_pcx_kernel<true, 0, G>)); break;
-        case 1: SHL_PCX((conv_igemm_pcx_kernel<true, 1, G>)); break;
-        case 2: SHL_PCX((conv_igemm_pcx_kernel<true, 2, G>)); break;
-        case 3: SHL_PCX((conv_igemm_pcx_kernel<true, 3, G>)); break;
-        case 4: SHL_PCX((conv_igemm_pcx_kernel<true, 4, G>)); break;
-        default: SHL_PCX((conv_igemm_pcx_kernel<true, 5, G>)); break;
+        case 0: SHL_PCX(true, 0); break;
+        case 1: SHL_PCX(true, 1); break;
+        case 2: SHL_PCX(true, 2); break;
+        case 3: SHL_PCX(true, 3); break;
+        case 4: SHL_PCX(true, 4); break;
+        default: SHL_PCX(true, 5); break;
     }
 #undef SHL_PCX
 }
@@ -463,16 +468,12 @@ int pcx_read_trace(unsigned long long *host, int count)
     return SHL_MI355X_OK;
 }
 
-// flavour as conv_igemm_pc.hip's (0: 256 x 128, 1: 128 x 128)
+// one geometry (256 x 128, sixteen waves) whatever flavour conv_igemm_pc.hip would take
 int launch_conv_igemm_pcx(const ConvArgs &a, int dtype, int flavour, hipStream_t s)
 {
+    (void)flavour;
     const bool i8 = dtype == SHL_MI355X_I8;
-    const int epi = i8 ? epi_code(a) : 0;
-    switch (flavour) {
-        case 0: pcx_launch<PCX256>(a, i8, epi, s); break;
-        case 1: pcx_launch<PCX128>(a, i8, epi, s); break;
-        default: return SHL_MI355X_ENOTSUP;
-    }
+    pcx_launch(a, i8, i8 ? epi_code(a) : 0, s);
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }
