@@ -48,6 +48,7 @@ struct ConvArgs {
     // int8 epilogue shortcuts, all bit-identical to the literal formula (derived and verified on
     // the host at plan time, conv_plan.hip):
     int32_t div_exact;    // out_scale is a power of two: f / s == f * inv_out_scale exactly
+    int32_t div_fma;      // any other scale in a sane range: f / s == div_by_scale(f, s, inv_out_scale) exactly
     int32_t act_clamp;    // saturation + relu/relu6 collapse into clamp(r, clamp_lo, clamp_hi)
     int32_t out_zp;
     float clamp_lo;       // act_clamp (or no activation): lower / upper bound applied to
@@ -110,11 +111,54 @@ __host__ __device__ inline int epi_code(const ConvArgs &a)
     return (a.div_exact ? 3 : 0) + act_mode;
 }
 
-template <int EPI>
+// f / s, correctly rounded, for a divisor whose reciprocal y = RN(1 / s) was rounded once on the host: five VALU
+// operations instead of the hardware's division sequence (v_div_scale x2, v_rcp, five fma, v_div_fmas,
+// v_div_fixup, with the quarter-rate v_rcp in it) -- 30 -> 22 us for a 256 -> 256 3x3 layer's kernel when the
+// output scale is not a power of two, i.e. for every real model.
+//   q0 = RN(f y) is within 1.5 ulp of f / s;  r = f - s q is EXACT in one fma when q is that close;
+//   q1 = RN(q0 + r0 y) is faithful (< 1 ulp);  Markstein's theorem: for y = RN(1 / s) and a faithful q,
+//   RN(q + (f - s q) y) == RN(f / s).
+// No overflow / underflow in the range the plan admits (conv_plan.hip, div_fma); tests/test_div_by_scale.py walks
+// every significand of f against __fdiv_rn for a few thousand divisors.
+__device__ __forceinline__ float div_by_scale(float f, float s, float y)
+{
+    float q = __fmul_rn(f, y);
+    float r = __fmaf_rn(-s, q, f);
+    q = __fmaf_rn(r, y, q);
+    r = __fmaf_rn(-s, q, f);
+    return __fmaf_rn(r, y, q);
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f div_by_scale2(v2f f, float s, float y)
+{
+    const v2f ns = {-s, -s}, yy = {y, y};
+    v2f q = f * yy;
+    v2f r = __builtin_elementwise_fma(ns, q, f);
+    q = __builtin_elementwise_fma(r, yy, q);
+    r = __builtin_elementwise_fma(ns, q, f);
+    return __builtin_elementwise_fma(r, yy, q);
+}
+
+// kHwDiv: keep the hardware's division as the path for scales outside div_by_scale's range.  Only the direct
+// kernel compiles it in (plans for such scales are direct ones, conv_plan.hip): two division paths in one
+// epilogue cost registers -- the stem kernel went from 51 to 123 VGPRs with both, and the kernels with
+// asynchronous fragment reads have none to spare.
+template <bool kHwDiv>
+__device__ __forceinline__ float div_out_scale(float f, const ConvArgs &a)
+{
+    if constexpr (kHwDiv) {
+        if (!a.div_fma) return __fdiv_rn(f, a.out_scale);
+    }
+    return div_by_scale(f, a.out_scale, a.inv_out_scale);
+}
+
+template <int EPI, bool kHwDiv = false>
 __device__ __forceinline__ int requant_i8_t(int32_t S, float mult, float bias_f, const ConvArgs &a)
 {
     const float f = __fadd_rn(__fmul_rn((float)S, mult), bias_f);
-    const float quot = (EPI >= 3) ? __fmul_rn(f, a.inv_out_scale) : __fdiv_rn(f, a.out_scale);
+    const float quot = (EPI >= 3) ? __fmul_rn(f, a.inv_out_scale) : div_out_scale<kHwDiv>(f, a);
     const float r = __fadd_rn(rintf(quot), a.out_zp_f);
     constexpr int kAct = EPI % 3;
     if constexpr (kAct != 2) {
@@ -125,7 +169,8 @@ __device__ __forceinline__ int requant_i8_t(int32_t S, float mult, float bias_f,
         float x = __fmul_rn(__fsub_rn((float)q, a.out_zp_f), a.out_scale);
         x = x > 0.0f ? x : 0.0f;
         if (a.act == SHL_MI355X_ACT_RELU6) x = fminf(x, 6.0f);
-        return sat8_from_float(__fadd_rn(rintf(__fdiv_rn(x, a.out_scale)), a.out_zp_f));
+        const float back = (EPI >= 3) ? __fmul_rn(x, a.inv_out_scale) : div_out_scale<kHwDiv>(x, a);
+        return sat8_from_float(__fadd_rn(rintf(back), a.out_zp_f));
     }
 }
 
@@ -141,32 +186,39 @@ __device__ __forceinline__ uint32_t pack4_i8(int q0, int q1, int q2, int q3)
 // add / multiply chain runs on packed fp32 (v_pk_mul_f32, v_pk_add_f32: two IEEE single operations
 // per instruction, same roundings as the scalar code -- nothing is contracted), which is a third
 // fewer VALU instructions in the tile kernels' epilogues.
-typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int EPI>
+template <int EPI, bool kHwDiv = false>
 __device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3, const float4 &m, const float4 &b,
                                                   const ConvArgs &a)
 {
     if constexpr (EPI % 3 == 2) {
-        return pack4_i8(requant_i8_t<EPI>(s0, m.x, b.x, a), requant_i8_t<EPI>(s1, m.y, b.y, a),
-                        requant_i8_t<EPI>(s2, m.z, b.z, a), requant_i8_t<EPI>(s3, m.w, b.w, a));
-    } else if constexpr (EPI >= 3) {
-        // power-of-two output scale + clamp epilogue: 21 instead of 27 VALU per four values.
-        //   x = fl(fl(S m) + b) * inv                                (three packed IEEE operations, as below)
-        //   clamp FIRST, to [lo - zp, hi - zp]: both bounds are integers, rint is monotone and fixes
-        //   integers, so  rint(clamp(x)) + zp == clamp(rint(x) + zp)  -- the order the reference uses;
-        //   rint by the magic constant: |x| <= 383 after the clamp, so fl(x + 1.5 * 2^23) holds
-        //   rint(x) (ties to even, the FPU's own rounding) in its low mantissa bits, two's complement;
-        //   + zp on 16-bit halves (v_pk_add_u16: no carry between values), bytes picked by v_perm_b32.
+        return pack4_i8(requant_i8_t<EPI, kHwDiv>(s0, m.x, b.x, a), requant_i8_t<EPI, kHwDiv>(s1, m.y, b.y, a),
+                        requant_i8_t<EPI, kHwDiv>(s2, m.z, b.z, a), requant_i8_t<EPI, kHwDiv>(s3, m.w, b.w, a));
+    } else {
+        // x = fl(fl(S m) + b) / s on packed fp32: three IEEE operations when s is a power of two (x * inv),
+        // seven when the plan admits div_by_scale, the hardware's division otherwise.
         v2f lo = {(float)s0, (float)s1}, hi = {(float)s2, (float)s3};
         const v2f mlo = {m.x, m.y}, mhi = {m.z, m.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
-        const v2f inv = {a.inv_out_scale, a.inv_out_scale};
         lo = lo * mlo;
         hi = hi * mhi;
         lo = lo + blo;
         hi = hi + bhi;
-        lo = lo * inv;
-        hi = hi * inv;
+        if constexpr (EPI >= 3) {
+            const v2f inv = {a.inv_out_scale, a.inv_out_scale};
+            lo = lo * inv;
+            hi = hi * inv;
+        } else if (!kHwDiv || a.div_fma) {
+            lo = div_by_scale2(lo, a.out_scale, a.inv_out_scale);
+            hi = div_by_scale2(hi, a.out_scale, a.inv_out_scale);
+        } else {
+            lo = v2f{__fdiv_rn(lo.x, a.out_scale), __fdiv_rn(lo.y, a.out_scale)};
+            hi = v2f{__fdiv_rn(hi.x, a.out_scale), __fdiv_rn(hi.y, a.out_scale)};
+        }
+        // clamp FIRST, to [lo - zp, hi - zp]: both bounds are integers, rint is monotone and fixes integers, so
+        //   rint(clamp(x)) + zp == clamp(rint(x) + zp)  -- the order the reference uses;
+        // rint by the magic constant: |x| <= 383 after the clamp, so fl(x + 1.5 * 2^23) holds rint(x) (ties to
+        //   even, the FPU's own rounding) in its low mantissa bits, two's complement;
+        // + zp on 16-bit halves (v_pk_add_u16: no carry between values), bytes picked by v_perm_b32.
         const float cl = a.clamp_lo - a.out_zp_f, ch = a.clamp_hi - a.out_zp_f;  // exact: small integers
         const v2f magic = {12582912.0f, 12582912.0f};
         v2f c0 = {__builtin_amdgcn_fmed3f(lo.x, cl, ch), __builtin_amdgcn_fmed3f(lo.y, cl, ch)};
@@ -180,48 +232,27 @@ __device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3
         const v2u16 q01 = __builtin_bit_cast(v2u16, p01) + __builtin_bit_cast(v2u16, zp2);
         const v2u16 q23 = __builtin_bit_cast(v2u16, p23) + __builtin_bit_cast(v2u16, zp2);
         return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q23), __builtin_bit_cast(uint32_t, q01), 0x06040200u);
-    } else {
-        v2f lo = {(float)s0, (float)s1}, hi = {(float)s2, (float)s3};
-        const v2f mlo = {m.x, m.y}, mhi = {m.z, m.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
-        lo = lo * mlo;
-        hi = hi * mhi;
-        lo = lo + blo;
-        hi = hi + bhi;
-        if constexpr (EPI >= 3) {
-            const v2f inv = {a.inv_out_scale, a.inv_out_scale};
-            lo = lo * inv;
-            hi = hi * inv;
-        } else {
-            lo = v2f{__fdiv_rn(lo.x, a.out_scale), __fdiv_rn(lo.y, a.out_scale)};
-            hi = v2f{__fdiv_rn(hi.x, a.out_scale), __fdiv_rn(hi.y, a.out_scale)};
-        }
-        const v2f zp = {a.out_zp_f, a.out_zp_f};
-        lo = v2f{rintf(lo.x), rintf(lo.y)} + zp;
-        hi = v2f{rintf(hi.x), rintf(hi.y)} + zp;
-        const int q0 = (int)__builtin_amdgcn_fmed3f(lo.x, a.clamp_lo, a.clamp_hi);
-        const int q1 = (int)__builtin_amdgcn_fmed3f(lo.y, a.clamp_lo, a.clamp_hi);
-        const int q2 = (int)__builtin_amdgcn_fmed3f(hi.x, a.clamp_lo, a.clamp_hi);
-        const int q3 = (int)__builtin_amdgcn_fmed3f(hi.y, a.clamp_lo, a.clamp_hi);
-        return pack4_i8(q0, q1, q2, q3);
     }
 }
 
 // wave-uniform choice between the four epilogue code paths (EPI above)
+template <bool kHwDiv = false>
 __device__ __forceinline__ uint32_t requant4_i8_rt(int s0, int s1, int s2, int s3, const float4 &m, const float4 &b,
                                                    const ConvArgs &a)
 {
     const bool literal = a.act != SHL_MI355X_ACT_NONE && !a.act_clamp;
     if (literal)
-        return a.div_exact ? requant4_i8_t<5>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<2>(s0, s1, s2, s3, m, b, a);
-    return a.div_exact ? requant4_i8_t<3>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<0>(s0, s1, s2, s3, m, b, a);
+        return a.div_exact ? requant4_i8_t<5>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<2, kHwDiv>(s0, s1, s2, s3, m, b, a);
+    return a.div_exact ? requant4_i8_t<3>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<0, kHwDiv>(s0, s1, s2, s3, m, b, a);
 }
 
 // run-time dispatch of the same code (kernels that are not specialised on EPI)
+template <bool kHwDiv = false>
 __device__ __forceinline__ int requant_i8_fast(int32_t S, float mult, float bias_f, const ConvArgs &a)
 {
     if (a.act != SHL_MI355X_ACT_NONE && !a.act_clamp)
-        return a.div_exact ? requant_i8_t<5>(S, mult, bias_f, a) : requant_i8_t<2>(S, mult, bias_f, a);
-    return a.div_exact ? requant_i8_t<3>(S, mult, bias_f, a) : requant_i8_t<0>(S, mult, bias_f, a);
+        return a.div_exact ? requant_i8_t<5>(S, mult, bias_f, a) : requant_i8_t<2, kHwDiv>(S, mult, bias_f, a);
+    return a.div_exact ? requant_i8_t<3>(S, mult, bias_f, a) : requant_i8_t<0, kHwDiv>(S, mult, bias_f, a);
 }
 
 // 4x4 byte transpose: in[i] holds bytes (row i, col 0..3); out[j] holds (row 0..3, col j)

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a)
             }
         }
         if constexpr (sizeof(T) == 1) {
-            const int q = requant_i8_fast(acc_i, a.mult[oc], a.bias[oc], a);
+            const int q = requant_i8_fast<true>(acc_i, a.mult[oc], a.bias[oc], a);
             static_cast<int8_t *>(a.out)[idx] = (int8_t)q;
         } else {
             static_cast<uint16_t *>(a.out)[idx] = finish_f16(acc_f, a.bias[oc], a);

@@ -20,7 +20,7 @@ struct shl_mi355x_conv_plan {
     size_t off_w, off_acc, off_mult, off_bias, off_pad;
     size_t off_wfrag;  // 0: absent; pointwise int8 weights in MFMA fragment order (conv1x1_stream.hip)
     // int8 epilogue shortcuts (see ConvArgs)
-    int32_t div_exact, act_clamp;
+    int32_t div_exact, div_fma, act_clamp;
     float clamp_lo, clamp_hi, inv_out_scale;
     // NCHW through the NHWC MFMA kernel: scratch images of the input and output, sized for
     // desc.batch at plan time (no allocation may happen inside a captured forward)
@@ -101,6 +101,20 @@ static bool is_pow2_scale(float s)
     return s > 0.0f && __builtin_frexpf(s, &e) == 0.5f && e > -100 && e < 100;
 }
 
+// Division by the output scale as multiply + two fma corrections (common.h div_by_scale; y = RN(1/s) is the
+// plan's inv_out_scale, one IEEE division on the host): no overflow or underflow can touch a quotient that
+// matters when 2^-40 <= s <= 2^40 and |fl(fl(S m) + b)| <= 2^60 for every int32 S (|q| < 2^-20 rounds to 0
+// whatever its low bits are).
+static bool fma_division_ok(const shl_mi355x_conv_desc &d, const float *mult_host, const float *bias_host)
+{
+    if (d.dtype != SHL_MI355X_I8 || !(d.out_scale >= 0x1p-40f && d.out_scale <= 0x1p40f)) return false;
+    for (int oc = 0; oc < d.out_c; ++oc) {
+        const float bound = 4294967296.0f * fabsf(mult_host ? mult_host[oc] : 1.0f) + fabsf(bias_host ? bias_host[oc] : 0.0f);
+        if (!(bound <= 0x1p60f)) return false;  // also NaN
+    }
+    return true;
+}
+
 static int choose_algo(const shl_mi355x_conv_desc &d)
 {
     if (is_depthwise(d)) return (dwconv_supports(d) || dwconv_nchw_supports(d)) ? SHL_MI355X_ALGO_DW : SHL_MI355X_ALGO_DIRECT;
@@ -156,10 +170,22 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         set_error("conv_plan_create: int8 needs the per-channel multiplier table");
         return SHL_MI355X_EINVAL;
     }
+    // int8 output scales: a power of two, or a converter's scale in the range div_by_scale handles -- anything else
+    // (out_scale or multipliers beyond 2^+-40) keeps the hardware's division, which only the direct kernel carries
+    const bool i8_div_exact = d.dtype == SHL_MI355X_I8 && is_pow2_scale(d.out_scale);
+    const bool i8_div_fma = !i8_div_exact && fma_division_ok(d, mult_host, bias_host);
+    const bool fast_epilogue_ok = d.dtype != SHL_MI355X_I8 || i8_div_exact || i8_div_fma;
     int algo = d.algo;
-    if (algo == SHL_MI355X_ALGO_AUTO) algo = choose_algo(d);
+    if (algo == SHL_MI355X_ALGO_AUTO) {
+        algo = choose_algo(d);
+        if (algo >= 0 && !fast_epilogue_ok) algo = SHL_MI355X_ALGO_DIRECT;
+    }
     if (algo < 0) {
         set_error("conv_plan_create: grouped convolution (group=%d) is not supported", d.group);
+        return SHL_MI355X_ENOTSUP;
+    }
+    if (algo >= 0 && algo != SHL_MI355X_ALGO_DIRECT && !fast_epilogue_ok) {
+        set_error("conv_plan_create: only the DIRECT kernel takes an output scale (or multipliers) outside 2^-40 .. 2^40");
         return SHL_MI355X_ENOTSUP;
     }
     if (algo == SHL_MI355X_ALGO_IGEMM && !igemm_supports(d)) {
@@ -263,7 +289,8 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     }
     p->inv_out_scale = 1.0f / d.out_scale;
     if (d.dtype == SHL_MI355X_I8) {
-        p->div_exact = is_pow2_scale(d.out_scale);
+        p->div_exact = i8_div_exact;
+        p->div_fma = i8_div_fma;
         p->clamp_lo = -128.0f;
         p->clamp_hi = 127.0f;
         p->act_clamp = d.act != SHL_MI355X_ACT_NONE && derive_act_clamp(d, &p->clamp_lo, &p->clamp_hi);
@@ -525,6 +552,7 @@ static int fill_args(const shl_mi355x_conv_plan *plan, const void *input_dev, vo
     a.scale_out = (d.dtype == SHL_MI355X_F16) && (os - 1.0f > 1.1920929e-07f || 1.0f - os > 1.1920929e-07f);
     a.inv_out_scale = plan->inv_out_scale;
     a.div_exact = plan->div_exact;
+    a.div_fma = plan->div_fma;
     a.act_clamp = plan->act_clamp;
     a.clamp_lo = plan->clamp_lo;
     a.clamp_hi = plan->clamp_hi;

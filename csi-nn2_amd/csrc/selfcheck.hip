@@ -1,0 +1,67 @@
+// Device-side self checks behind the C-ABI (tests only).
+//
+// shl_mi355x_debug_div_check: the int8 epilogue divides by the output scale with common.h's div_by_scale
+// (multiply + two fma corrections) instead of the hardware's division sequence.  Rounding of f / s depends on the
+// two significands only, so walking all 2^23 significands of f (one binade, both signs) against __fdiv_rn is an
+// exhaustive check for a given divisor s; the test passes a few thousand of them (random, edge patterns, and the
+// scales of the workloads).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace shl {
+
+__global__ __launch_bounds__(256) void div_check_kernel(const float *divisors, unsigned long long *count,
+                                                        float *first)  // first[0..1] = f, s of one mismatch
+{
+    const float s = divisors[blockIdx.y];
+    const float y = __fdiv_rn(1.0f, s);
+    unsigned bad = 0;
+    float bad_f = 0.f;
+    for (uint32_t m = blockIdx.x * 256 + threadIdx.x; m < (1u << 23); m += gridDim.x * 256) {
+        const float f = __uint_as_float(0x41000000u | m);  // [8, 16)
+        const float want = __fdiv_rn(f, s);
+        const float got = div_by_scale(f, s, y);
+        const v2f got2 = div_by_scale2(v2f{f, -f}, s, y);
+        if (__float_as_uint(want) != __float_as_uint(got) || __float_as_uint(want) != __float_as_uint(got2.x) ||
+            __float_as_uint(-want) != __float_as_uint(got2.y)) {
+            ++bad;
+            bad_f = f;
+        }
+    }
+    if (bad) {
+        atomicAdd(count, (unsigned long long)bad);
+        first[0] = bad_f;
+        first[1] = s;
+    }
+}
+
+}  // namespace shl
+
+extern "C" int shl_mi355x_debug_div_check(const float *divisors_host, int32_t n, uint64_t *mismatches,
+                                          float *first_pair)
+{
+    using namespace shl;
+    if (!divisors_host || n <= 0 || !mismatches || !first_pair) return SHL_MI355X_EINVAL;
+    float *d_div = nullptr, *d_first = nullptr;
+    unsigned long long *d_count = nullptr;
+    SHL_HIP(hipMalloc((void **)&d_div, (size_t)n * 4));
+    SHL_HIP(hipMalloc((void **)&d_first, 8));
+    SHL_HIP(hipMalloc((void **)&d_count, 8));
+    SHL_HIP(hipMemcpy(d_div, divisors_host, (size_t)n * 4, hipMemcpyHostToDevice));
+    SHL_HIP(hipMemset(d_first, 0, 8));
+    SHL_HIP(hipMemset(d_count, 0, 8));
+    hipLaunchKernelGGL(div_check_kernel, dim3(64, (unsigned)n), dim3(256), 0, nullptr, d_div, d_count, d_first);
+    SHL_HIP(hipGetLastError());
+    SHL_HIP(hipDeviceSynchronize());
+    unsigned long long c = 0;
+    SHL_HIP(hipMemcpy(&c, d_count, 8, hipMemcpyDeviceToHost));
+    SHL_HIP(hipMemcpy(first_pair, d_first, 8, hipMemcpyDeviceToHost));
+    *mismatches = c;
+    (void)hipFree(d_div);
+    (void)hipFree(d_first);
+    (void)hipFree(d_count);
+    return SHL_MI355X_OK;
+}

@@ -181,6 +181,12 @@ int shl_mi355x_comm_bcast(void *comm, void *const *blocks_dev, const size_t *byt
  * (slots 0..511 wave 0, 512..1023 wave 4).  tools/pp_trace.py prints them. */
 int shl_mi355x_debug_trace(uint64_t *host, int32_t count);
 
+/* Self check of the int8 epilogue's division by the output scale (csrc/common.h div_by_scale: multiply + two fma
+ * corrections, bit-identical to the IEEE division of shl_ref's requantisation, source/nn2/utils.c:550-560 via
+ * `x / scale`): for each of the `n` divisors every significand of the dividend is compared with the hardware's
+ * correctly rounded division.  *mismatches = number of differing quotients, first_pair[0..1] = one (f, s). */
+int shl_mi355x_debug_div_check(const float *divisors_host, int32_t n, uint64_t *mismatches, float *first_pair);
+
 /*
  * Plan for CSINN_OP_DEPTHWISE_CONV2D_CHANNEL{,_RELU,_RELU6} (int8, NCHW, kernel O1HW): the reference's one
  * integer-accumulating convolution, shl_ref_depthwise_conv2d_channel_nchw_i8
