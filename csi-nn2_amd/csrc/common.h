@@ -47,7 +47,7 @@ struct ConvArgs {
     int32_t scale_out;    // f16 only: out_scale differs from 1
     // int8 epilogue shortcuts, all bit-identical to the literal formula (derived and verified on
     // the host at plan time, conv_plan.hip):
-    int32_t div_exact;    // out_scale is a power of two: f / s == f * inv_out_scale exactly
+    int32_t div_exact;    // out_scale is a power of two: mult and bias already carry the factor 1 / out_scale (exact)
     int32_t div_fma;      // any other scale in a sane range: f / s == div_by_scale(f, s, inv_out_scale) exactly
     int32_t act_clamp;    // saturation + relu/relu6 collapse into clamp(r, clamp_lo, clamp_hi)
     int32_t out_zp;
@@ -158,7 +158,7 @@ template <int EPI, bool kHwDiv = false>
 __device__ __forceinline__ int requant_i8_t(int32_t S, float mult, float bias_f, const ConvArgs &a)
 {
     const float f = __fadd_rn(__fmul_rn((float)S, mult), bias_f);
-    const float quot = (EPI >= 3) ? __fmul_rn(f, a.inv_out_scale) : div_out_scale<kHwDiv>(f, a);
+    const float quot = (EPI >= 3) ? f : div_out_scale<kHwDiv>(f, a);  // EPI >= 3: tables pre-scaled by 1 / s
     const float r = __fadd_rn(rintf(quot), a.out_zp_f);
     constexpr int kAct = EPI % 3;
     if constexpr (kAct != 2) {
@@ -195,8 +195,9 @@ __device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3
         return pack4_i8(requant_i8_t<EPI, kHwDiv>(s0, m.x, b.x, a), requant_i8_t<EPI, kHwDiv>(s1, m.y, b.y, a),
                         requant_i8_t<EPI, kHwDiv>(s2, m.z, b.z, a), requant_i8_t<EPI, kHwDiv>(s3, m.w, b.w, a));
     } else {
-        // x = fl(fl(S m) + b) / s on packed fp32: three IEEE operations when s is a power of two (x * inv),
-        // seven when the plan admits div_by_scale, the hardware's division otherwise.
+        // x = fl(fl(S m) + b) / s on packed fp32: two IEEE operations when s is a power of two (the plan folded
+        // 1 / s into both tables, which is exact), six when the plan admits div_by_scale, the hardware's division
+        // otherwise.
         v2f lo = {(float)s0, (float)s1}, hi = {(float)s2, (float)s3};
         const v2f mlo = {m.x, m.y}, mhi = {m.z, m.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
         lo = lo * mlo;
@@ -204,9 +205,7 @@ __device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3
         lo = lo + blo;
         hi = hi + bhi;
         if constexpr (EPI >= 3) {
-            const v2f inv = {a.inv_out_scale, a.inv_out_scale};
-            lo = lo * inv;
-            hi = hi * inv;
+            // power-of-two scale: the plan multiplied both tables by 1 / s (exact), fl(fl(S m') + b') IS the quotient
         } else if (!kHwDiv || a.div_fma) {
             lo = div_by_scale2(lo, a.out_scale, a.inv_out_scale);
             hi = div_by_scale2(hi, a.out_scale, a.inv_out_scale);
@@ -218,7 +217,8 @@ __device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3
         //   rint(clamp(x)) + zp == clamp(rint(x) + zp)  -- the order the reference uses;
         // rint by the magic constant: |x| <= 383 after the clamp, so fl(x + 1.5 * 2^23) holds rint(x) (ties to
         //   even, the FPU's own rounding) in its low mantissa bits, two's complement;
-        // + zp on 16-bit halves (v_pk_add_u16: no carry between values), bytes picked by v_perm_b32.
+        // + zp on 16-bit halves (v_pk_add_u16: no carry between values), bytes picked by v_perm_b32.  (zp cannot
+        //   ride in the magic constant: an odd zp flips the parity that decides the ties.)
         const float cl = a.clamp_lo - a.out_zp_f, ch = a.clamp_hi - a.out_zp_f;  // exact: small integers
         const v2f magic = {12582912.0f, 12582912.0f};
         v2f c0 = {__builtin_amdgcn_fmed3f(lo.x, cl, ch), __builtin_amdgcn_fmed3f(lo.y, cl, ch)};

@@ -293,11 +293,16 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
     using acc_t = typename AccT<kI8>::type;
     acc_t acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        if constexpr (kI8) {
+            igemm_acc_from_table(acc[i], a.acc_init + co0 + wr * 32 * MI + i * 32, lane >> 5);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+        }
+    }
 
     if (tid < G::TBN) {
         reinterpret_cast<int32_t *>(smem + G::TAB_OFF)[tid] = t_acc;
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
     if constexpr (kNchwOut) {  // the shared staged epilogue, NCHW planes (igemm_common.h)
 #pragma unroll
         for (int ih = 0; ih < MI / 2; ++ih)
-            igemm_store_block64_impl<kI8, EPI, true>(a, acc[2 * ih][0], acc[2 * ih][1], acc[2 * ih + 1][0], acc[2 * ih + 1][1], ws,
+            igemm_store_block64_impl<kI8, EPI, true, acc_t, false, kI8>(a, acc[2 * ih][0], acc[2 * ih][1], acc[2 * ih + 1][0], acc[2 * ih + 1][1], ws,
                                                      pix0 + wc * 64, co0 + wr * 32 * MI + ih * 64,
                                                      tab_acc + wr * 32 * MI + ih * 64, tab_mult + wr * 32 * MI + ih * 64,
                                                      tab_bias + wr * 32 * MI + ih * 64, lane);
@@ -404,11 +409,9 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
                     const float4 bi = *reinterpret_cast<const float4 *>(tab_bias + ch);
                     char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
                     if constexpr (kI8) {
-                        const int4 ai = *reinterpret_cast<const int4 *>(tab_acc + ch);
-                        const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + ch);
+                        const float4 mu = *reinterpret_cast<const float4 *>(tab_mult + ch);  // (acc_init: in the accumulators)
                         *reinterpret_cast<uint32_t *>(dst) = requant4_i8_t<EPI>(
-                            acc[i][j][4 * g + 0] + ai.x, acc[i][j][4 * g + 1] + ai.y, acc[i][j][4 * g + 2] + ai.z,
-                            acc[i][j][4 * g + 3] + ai.w, mu, bi, a);
+                            acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], mu, bi, a);
                     } else {
                         const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
                         const uint32_t h1 = finish_f16(acc[i][j][4 * g + 1], bi.y, a);

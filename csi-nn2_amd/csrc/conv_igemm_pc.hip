@@ -273,11 +273,16 @@ __global__ __launch_bounds__(G::THREADS) void conv_igemm_pc_kernel(ConvArgs a)
     acc_t acc[TC][TP];
     v4i fa0[TC], fb0[TP], fa1[TC], fb1[TP];  // two fragment sets: even / odd K sub-steps
 #pragma unroll
-    for (int i = 0; i < TC; ++i)
+    for (int i = 0; i < TC; ++i) {
+        if constexpr (kI8) {
+            igemm_acc_from_table(acc[i], a.acc_init + co0 + wc * 64 + i * 32, fhalf);
+        } else {
 #pragma unroll
-        for (int j = 0; j < TP; ++j)
+            for (int j = 0; j < TP; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+        }
+    }
 
     auto read_frags = [&](uint32_t slot_off, int ks, v4i(&fa)[TC], v4i(&fb)[TP]) {
         if (dbg & 16) return;
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(G::THREADS) void conv_igemm_pc_kernel(ConvArgs a)
 #pragma unroll
     for (int jh = 0; jh < TP / 2; ++jh)
         // kBulk: a consumer runs the epilogue alone on its SIMD (igemm_common.h)
-        igemm_store_block64<kI8, EPI, acc_t, G::NCONS == 4>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], ws,
+        igemm_store_block64<kI8, EPI, acc_t, G::NCONS == 4, kI8>(a, acc[0][2 * jh], acc[0][2 * jh + 1], acc[1][2 * jh], acc[1][2 * jh + 1], ws,
                                       pix0 + wp * G::WPIX + jh * 64, co0 + wc * 64, tab_acc, tab_mult, tab_bias, lane);
     mark();
 }

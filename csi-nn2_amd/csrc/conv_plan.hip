@@ -98,7 +98,20 @@ static bool derive_act_clamp(const shl_mi355x_conv_desc &d, float *lo, float *hi
 static bool is_pow2_scale(float s)
 {
     int e;
-    return s > 0.0f && __builtin_frexpf(s, &e) == 0.5f && e > -100 && e < 100;
+    return s > 0.0f && __builtin_frexpf(s, &e) == 0.5f && e > -40 && e < 40;
+}
+
+// A power-of-two output scale is folded into the multiplier and bias tables: fl(fl(S m) + b) / s ==
+// fl(fl(S (m / s)) + b / s) as long as no operand leaves the normal range, which these bounds guarantee
+// (scaling by a power of two commutes with rounding).  Two packed multiplications less per four outputs.
+static bool pow2_fold_ok(const shl_mi355x_conv_desc &d, const float *mult_host, const float *bias_host)
+{
+    if (d.dtype != SHL_MI355X_I8 || !is_pow2_scale(d.out_scale)) return false;
+    for (int oc = 0; oc < d.out_c; ++oc) {
+        const float m = fabsf(mult_host ? mult_host[oc] : 1.0f), b = fabsf(bias_host ? bias_host[oc] : 0.0f);
+        if (!((m == 0.0f || (m >= 0x1p-60f && m <= 0x1p28f)) && (b == 0.0f || (b >= 0x1p-60f && b <= 0x1p60f)))) return false;
+    }
+    return true;
 }
 
 // Division by the output scale as multiply + two fma corrections (common.h div_by_scale; y = RN(1/s) is the
@@ -172,7 +185,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     }
     // int8 output scales: a power of two, or a converter's scale in the range div_by_scale handles -- anything else
     // (out_scale or multipliers beyond 2^+-40) keeps the hardware's division, which only the direct kernel carries
-    const bool i8_div_exact = d.dtype == SHL_MI355X_I8 && is_pow2_scale(d.out_scale);
+    const bool i8_div_exact = pow2_fold_ok(d, mult_host, bias_host);
     const bool i8_div_fma = !i8_div_exact && fma_division_ok(d, mult_host, bias_host);
     const bool fast_epilogue_ok = d.dtype != SHL_MI355X_I8 || i8_div_exact || i8_div_fma;
     int algo = d.algo;
@@ -331,6 +344,10 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         for (int oc = 0; oc < d.out_c; ++oc) {
             mult[oc] = mult_host ? mult_host[oc] : 1.0f;
             bias[oc] = bias_host ? bias_host[oc] : 0.0f;
+            if (p->div_exact) {  // see pow2_fold_ok
+                mult[oc] *= p->inv_out_scale;
+                bias[oc] *= p->inv_out_scale;
+            }
             acc[oc] = 0;
         }
         if (algo == SHL_MI355X_ALGO_STEM) {

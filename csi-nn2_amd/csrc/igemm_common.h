@@ -99,6 +99,26 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb)
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
 }
 
+// The int8 accumulators of one 32-channel MFMA tile row start at the plan's per-channel acc_init (= -zp_in * sum(w),
+// global table, padded to 128 channels) instead of zero, so that the epilogue has nothing to add: four VALU and one
+// table read per four outputs less, for four loads in a prologue that waits for the first K tile anyway.
+// C/D layout: register 4 g + e of a lane holds channel 8 g + 4 (lane >> 5) + e of the tile.
+template <typename Acc, int TP>
+__device__ __forceinline__ void igemm_acc_from_table(Acc (&acc)[TP], const int32_t *acc_init_tile, int fhalf)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int4 v = *reinterpret_cast<const int4 *>(acc_init_tile + 8 * g + 4 * fhalf);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            acc[j][4 * g + 0] = v.x;
+            acc[j][4 * g + 1] = v.y;
+            acc[j][4 * g + 2] = v.z;
+            acc[j][4 * g + 3] = v.w;
+        }
+    }
+}
+
 // ---- epilogue of one 64-pixel x 64-channel block held by a wave as 2 x 2 MFMA tiles -----------------
 // acc[i][j]: i = 32-channel tile, j = 32-pixel tile; C/D layout: column (pixel) = lane & 31, row (channel)
 // = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -107,7 +127,8 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb)
 // its eight independent requantisation chains, instead of three reads in front of every chain: a wave that runs the
 // epilogue alone on its SIMD (conv_igemm_res.hip, conv_igemm_pc.hip) otherwise pays one LDS round trip plus one
 // fully dependent ~30-instruction chain sixteen times in a row (measured ~10 000 ticks per 64 x 64 block).
-template <bool kI8, int EPI, bool kNchw, typename Acc, bool kBulk = false>
+// kAccInit: the int8 accumulators were started at the plan's acc_init (igemm_acc_from_table): nothing to add here
+template <bool kI8, int EPI, bool kNchw, typename Acc, bool kBulk = false, bool kAccInit = false>
 __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, const Acc &a00, const Acc &a01, const Acc &a10,
                                                const Acc &a11, char *ws, int pix_first, int co_first,
                                                const int32_t *tab_acc, const float *tab_mult, const float *tab_bias, int lane)
@@ -125,8 +146,9 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
         char *dst = ws + (j * 32 + frow) * PITCH + c * ESIZE;
         char *dst_t = ws + c * PITCH + (j * 32 + frow) * ESIZE;  // NCHW output: [channel][pixel]
         if constexpr (kI8) {
-            const uint32_t pk = requant4_i8_t<EPI>(acc[4 * g + 0] + ai.x, acc[4 * g + 1] + ai.y, acc[4 * g + 2] + ai.z,
-                                                   acc[4 * g + 3] + ai.w, mu, bi, a);
+            const uint32_t pk = kAccInit ? requant4_i8_t<EPI>(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], mu, bi, a)
+                                         : requant4_i8_t<EPI>(acc[4 * g + 0] + ai.x, acc[4 * g + 1] + ai.y, acc[4 * g + 2] + ai.z,
+                                                              acc[4 * g + 3] + ai.w, mu, bi, a);
             if constexpr (kNchw) {
                 // 4 x 4 byte transposition across the four lanes of a quad (= four consecutive pixels):
                 // lane k ends up with channel c + k of pixels 4q .. 4q+3 -- one dword store instead of
@@ -169,7 +191,7 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
                 const int c = i2 * 32 + 8 * g + 4 * fhalf;
                 bi[g] = *reinterpret_cast<const float4 *>(tab_bias + c);
                 mu[g] = *reinterpret_cast<const float4 *>(tab_mult + c);
-                ai[g] = *reinterpret_cast<const int4 *>(tab_acc + c);
+                if constexpr (!kAccInit) ai[g] = *reinterpret_cast<const int4 *>(tab_acc + c);
             }
             // all eight requantisations of the half first (independent chains the scheduler can interleave: nothing
             // between them touches LDS, which it could not tell apart from the staging stores), then the eight stores
@@ -179,8 +201,9 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const Acc &acc = i2 == 0 ? (j == 0 ? a00 : a01) : (j == 0 ? a10 : a11);
-                    pk[j][g] = requant4_i8_t<EPI>(acc[4 * g + 0] + ai[g].x, acc[4 * g + 1] + ai[g].y, acc[4 * g + 2] + ai[g].z,
-                                                  acc[4 * g + 3] + ai[g].w, mu[g], bi[g], a);
+                    pk[j][g] = kAccInit ? requant4_i8_t<EPI>(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], mu[g], bi[g], a)
+                                        : requant4_i8_t<EPI>(acc[4 * g + 0] + ai[g].x, acc[4 * g + 1] + ai[g].y,
+                                                             acc[4 * g + 2] + ai[g].z, acc[4 * g + 3] + ai[g].w, mu[g], bi[g], a);
                 }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -217,7 +240,7 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
                     int4 ai = {0, 0, 0, 0};
                     if constexpr (kI8) {
                         mu = *reinterpret_cast<const float4 *>(tab_mult + c);
-                        ai = *reinterpret_cast<const int4 *>(tab_acc + c);
+                        if constexpr (!kAccInit) ai = *reinterpret_cast<const int4 *>(tab_acc + c);
                     }
                     emit(acc, j, g, c, bi, mu, ai);
                 }
@@ -269,16 +292,16 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
 
 // the output layout is a launch constant: one wave-uniform branch, two straight-line bodies (a run-time test
 // per staged group cost the 64 -> 64 @56 layer 6 us of its 35)
-template <bool kI8, int EPI, typename Acc, bool kBulk = false>
+template <bool kI8, int EPI, typename Acc, bool kBulk = false, bool kAccInit = false>
 __device__ __forceinline__ void igemm_store_block64(const ConvArgs &a, const Acc &a00, const Acc &a01, const Acc &a10,
                                                     const Acc &a11, char *ws, int pix_first, int co_first,
                                                     const int32_t *tab_acc, const float *tab_mult, const float *tab_bias,
                                                     int lane)
 {
     if (a.out_nchw)
-        igemm_store_block64_impl<kI8, EPI, true, Acc, kBulk>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
+        igemm_store_block64_impl<kI8, EPI, true, Acc, kBulk, kAccInit>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
     else
-        igemm_store_block64_impl<kI8, EPI, false, Acc, kBulk>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
+        igemm_store_block64_impl<kI8, EPI, false, Acc, kBulk, kAccInit>(a, a00, a01, a10, a11, ws, pix_first, co_first, tab_acc, tab_mult, tab_bias, lane);
 }
 
 // ping-pong kernel for MFMA-bound layers (conv_igemm_pp.hip): flavour for a problem (-1: does not apply)
