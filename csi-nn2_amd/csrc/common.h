@@ -374,6 +374,6 @@ int launch_stemdw_fused(const ConvArgs &stem, const ConvArgs &dw, hipStream_t s)
 bool pwdw_stream_eligible(const ConvArgs &pw, const ConvArgs &dw);
 int launch_pwdw_stream(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
 // [N][R][S] -> [N][S][R] for 1- or 2-byte elements (layout.hip)
-int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s);
+int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s, int to_nhwc);
 
 }  // namespace shl

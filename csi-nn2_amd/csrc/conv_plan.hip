@@ -615,7 +615,7 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
                 return SHL_MI355X_EINVAL;
             }
             const int es = d.dtype == SHL_MI355X_I8 ? 1 : 2;
-            int rc = launch_transpose(input_dev, plan->scratch_in, a.N, a.C, a.H * a.W, es, s);
+            int rc = launch_transpose(input_dev, plan->scratch_in, a.N, a.C, a.H * a.W, es, s, 1);
             if (rc != SHL_MI355X_OK) return rc;
             a.in = plan->scratch_in;
             // the tile kernel's epilogue stores NCHW itself; planes whose byte size is not a multiple of
@@ -627,7 +627,7 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
             a.out = plan->scratch_out;
             rc = launch_conv_igemm(a, d.dtype, SHL_MI355X_NHWC, s);
             if (rc != SHL_MI355X_OK) return rc;
-            return launch_transpose(plan->scratch_out, output_dev, a.N, a.Ho * a.Wo, a.Co, es, s);
+            return launch_transpose(plan->scratch_out, output_dev, a.N, a.Ho * a.Wo, a.Co, es, s, 0);
         }
         case SHL_MI355X_ALGO_DW:
             if (d.layout == SHL_MI355X_NCHW) return launch_dwconv_nchw(a, d.dtype, s);

@@ -233,7 +233,8 @@ def test_relu_kernels(gpu):
 
 @pytest.mark.parametrize("n,c,hw,dt", [(2, 64, 56 * 56, np.int8), (3, 20, 36, np.int8), (1, 7, 49, np.int8),
                                        (2, 128, 196, np.int8), (2, 64, 28 * 28, np.float16), (1, 6, 10, np.float16),
-                                       (1, 5, 7, np.float16), (1, 1024, 49, np.int8), (1, 48, 4, np.int8)])
+                                       (1, 5, 7, np.float16), (1, 1024, 49, np.int8), (1, 48, 4, np.int8),
+                                       (3, 192, 255, np.int8), (2, 64, 1, np.int8), (2, 256, 256, np.int8), (2, 64, 257, np.int8)])
 def test_layout_convert_round_trip(gpu, n, c, hw, dt):
     """NCHW <-> NHWC re-layout kernels (fast tiled forms and the generic form) against numpy."""
     fe, hip, opt, dev = gpu
