@@ -8,18 +8,18 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
-python bench.py --detail > "$OUT/bench_line.json" 2> "$OUT/bench_detail.txt"
-python bench.py --extra --no-cpu-baseline > "$OUT/bench_line_extra.json" 2> /dev/null
+timeout 600 python bench.py --detail > "$OUT/bench_line.json" 2> "$OUT/bench_detail.txt"
+timeout 900 python bench.py --extra --no-cpu-baseline > "$OUT/bench_line_extra.json" 2> /dev/null
 cd /tmp
 # ---- headline
-rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o t -- python "$REPO/bench.py" --no-cpu-baseline --no-configs > "$OUT/prof.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o t -- python "$REPO/bench.py" --steps-only --steps 20 --warmup 2 --windows 1 > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o t -- python "$REPO/bench.py" --steps-only --steps 20 --warmup 2 --windows 1 > "$OUT/pmc_write.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o t -- python "$REPO/bench.py" --no-cpu-baseline --no-configs > "$OUT/prof.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o t -- python "$REPO/bench.py" --steps-only --steps 20 --warmup 2 --windows 1 > "$OUT/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o t -- python "$REPO/bench.py" --steps-only --steps 20 --warmup 2 --windows 1 > "$OUT/pmc_write.log" 2>&1
 # ---- configs[2]: ResNet-50 3x3, batch 128, both layouts
 for L in NHWC NCHW; do
-  rocprofv3 --kernel-trace --stats -d "$OUT/prof_resnet_$L" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout $L --steps 5 --warmup 2 --windows 1 --no-cpu-baseline --no-configs > "$OUT/prof_resnet_$L.log" 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_resnet_$L" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout $L --steps-only --steps 3 --warmup 1 --windows 1 > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_resnet_$L" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout $L --steps-only --steps 3 --warmup 1 --windows 1 > /dev/null 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/prof_resnet_$L" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout $L --steps 5 --warmup 2 --windows 1 --no-cpu-baseline --no-configs > "$OUT/prof_resnet_$L.log" 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_resnet_$L" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout $L --steps-only --steps 3 --warmup 1 --windows 1 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_resnet_$L" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout $L --steps-only --steps 3 --warmup 1 --windows 1 > /dev/null 2>&1
 done
 cd "$REPO"
 python tools/rocprof_summary.py $(find "$OUT/prof" -name '*.db' | head -1) > "$OUT/rocprof_summary.txt" 2>&1
@@ -29,6 +29,6 @@ for L in NHWC NCHW; do
   python tools/pmc_traffic.py "$OUT/pmc_fetch_resnet_$L" "$OUT/pmc_write_resnet_$L" > "$OUT/traffic_resnet_$L.json" 2> "$OUT/traffic_resnet_$L.err"
 done
 # MFMA busy / waits / LDS conflicts / L2 hit rate of the ResNet kernels (three more passes)
-bash tools/pmc_resnet.sh > "$OUT/pmc_resnet_counters.txt" 2>&1
+timeout 900 bash tools/pmc_resnet.sh > "$OUT/pmc_resnet_counters.txt" 2>&1
 rm -rf "$OUT"/prof "$OUT"/prof_resnet_* "$OUT"/pmc_fetch* "$OUT"/pmc_write*   # the .db / csv trees are large; the summaries are what gets committed
 tail -c 600 "$OUT/bench_line.json"
