@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# The oracle (and the genuine reference library) open an OpenMP team per convolution.  With the default of one
+# thread per core that costs ~120 ms per call on the 256-core GPU host whatever the size of the layer (18 ms here):
+# 11 of the GPU suite's 15 minutes were spent starting and joining thread teams.  Must be set before libgomp loads.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
