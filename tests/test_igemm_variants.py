@@ -129,12 +129,14 @@ def _one_image(case, i):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", [NHWC, NCHW])
+@pytest.mark.parametrize("layout,exact", [(NHWC, True), (NCHW, True), (NHWC, False)], ids=["NHWC", "NCHW", "NHWC-converter-scales"])
 @pytest.mark.parametrize("idx", range(len(RESNET_3X3)), ids=["%d_%d_at%d" % (s["c"], s["co"], s["h"]) for s in RESNET_3X3])
-def test_resnet50_3x3_batch128_full_size(gpu, idx, layout):
+def test_resnet50_3x3_batch128_full_size(gpu, idx, layout, exact):
+    """exact=False: arbitrary (converter) scales, per channel -- the epilogue then divides by the output scale with
+    div_by_scale (tests/test_div_by_scale.py) inside the block-tile kernels at their full size."""
     fe, hip, opt, dev = gpu
     batch = 128
-    case = cases.make_case(9100 + idx, n=batch, layout=layout, act=1, **RESNET_3X3[idx])
+    case = cases.make_case(9100 + idx, n=batch, layout=layout, act=1, exact=exact, per_channel=not exact, **RESNET_3X3[idx])
     kept = []
     got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
     kname = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
