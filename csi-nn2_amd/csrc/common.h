@@ -69,6 +69,16 @@ struct ConvArgs {
     float ch_in_scale;    // input scale
     float ch_out_scale;   // output scale from the record's multiplier / shift (shl_ref_get_scale)
     int32_t ch_has_bias;
+    // conv_igemm_patch.hip (3x3 stride-1 "same" int8, im2col in LDS from one staged row patch, NHWC or NCHW native)
+    const void *w_patch;  // weights as the per-wave fragment streams of that kernel, or null
+    int32_t in_nchw;      // the INPUT tensor is NCHW (only the patch kernel reads it natively)
+    int32_t pt_geom;      // kc | pg << 8 | ob << 12 | kp << 16 (channels per stage, wave roles); 0: none
+    int32_t pt_rows;      // output rows per pixel group (rows * Wo <= 416)
+    int32_t pt_prows;     // patch rows per buffer (capacity over all tiles)
+    int32_t pt_bufb;      // bytes per patch buffer
+    int32_t pt_nitc;      // NCHW staging: iterations of 256 (run segment, 16-channel group) items per stage
+    int32_t pt_spr;       // NCHW staging: 16-byte segments per image run
+    int32_t pt_ntm;       // row tiles
 };
 
 // The pad page is 4 KiB so that concurrent readers can be spread over 32 cache lines instead of
@@ -373,6 +383,14 @@ int launch_stemdw_fused(const ConvArgs &stem, const ConvArgs &dw, hipStream_t s)
 // the same pair in bandwidth form for large batches (pwdw_stream.hip)
 bool pwdw_stream_eligible(const ConvArgs &pw, const ConvArgs &dw);
 int launch_pwdw_stream(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
+// 3x3 stride-1 "same" int8 convolution with the im2col matrix implicit in ONE staged row patch (conv_igemm_patch.hip)
+bool patch_supports(const shl_mi355x_conv_desc &d);                 // shape class the kernel takes at all
+int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch); // pt_geom for a batch (plan time), 0: none
+size_t patch_weight_bytes(const shl_mi355x_conv_desc &d, int geom);
+void patch_pack_weights(const shl_mi355x_conv_desc &d, int geom, const int8_t *src, int8_t *dst);
+bool patch_setup(ConvArgs &a);                                      // fills pt_rows .. pt_spr for a.N; false: does not fit
+bool patch_auto(const ConvArgs &a);                                 // the automatic choice takes it (enough tiles)
+int launch_conv_igemm_patch(const ConvArgs &a, hipStream_t s);
 // [N][R][S] -> [N][S][R] for 1- or 2-byte elements (layout.hip)
 int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s, int to_nhwc);
 

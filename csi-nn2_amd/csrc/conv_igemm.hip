@@ -960,6 +960,16 @@ const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
     const char *ov = variant_override();
     if (flavour) *flavour = -1;
     if (!ov[0] && conv_gemv_pick(a, esize)) return "gemv";
+    const bool forced_patch = !strcmp(ov, "patch");
+    if ((forced_patch || !ov[0]) && esize == 1 && a.w_patch) {  // 3x3 stride-1 "same" from one staged row patch (conv_igemm_patch.hip)
+        if (forced_patch) {
+            ConvArgs t = a;
+            if ((a.act == SHL_MI355X_ACT_NONE || a.act_clamp) && patch_setup(t)) return "patch";
+        } else if (patch_auto(a)) {
+            return "patch";
+        }
+    }
+    if (forced_patch) return "tile";
     if ((!ov[0] || !strcmp(ov, "res")) && res_applies(a, esize)) return "res";
     if (!strcmp(ov, "res")) return "tile";  // shapes the resident-weights kernel does not take
     const bool forced_pc = !strcmp(ov, "pc");
@@ -990,13 +1000,13 @@ bool igemm_fuses_nchw_out(const ConvArgs &a, int esize)
     ConvArgs t = a;
     t.out_nchw = 1;
     const char *v = igemm_pick(t, esize, nullptr);
-    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc") || !strcmp(v, "res");
+    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc") || !strcmp(v, "res") || !strcmp(v, "patch");
 }
 
 const char *igemm_variant(int64_t M, int64_t Co)
 {
     const char *ov = variant_override();
-    if (ov[0] && strcmp(ov, "pp") && strcmp(ov, "pc") && strcmp(ov, "res")) return ov;
+    if (ov[0] && strcmp(ov, "pp") && strcmp(ov, "pc") && strcmp(ov, "res") && strcmp(ov, "patch")) return ov;
     if (ov[0]) return "tile";
     // LDS tile kernel once there is at least ~one 128x128 tile for every other CU; below that
     // (MobileNetV1 at batch 1: 1-98 tiles) latency dominates and the barrier-free wave kernel wins
@@ -1014,6 +1024,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     if (!variant_override()[0] && conv_gemv_pick(a, esize)) return launch_conv_gemv(a, dtype, s);
     int ppf = -1;
     const char *v = igemm_pick(a, esize, &ppf);
+    if (!strcmp(v, "patch")) return launch_conv_igemm_patch(a, s);
     if (!strcmp(v, "pp")) return launch_conv_igemm_pp(a, dtype, ppf, s);
     if (!strcmp(v, "res")) return launch_conv_igemm_res(a, s);
     if (!strcmp(v, "pc")) {

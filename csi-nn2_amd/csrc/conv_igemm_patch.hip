@@ -1,0 +1,813 @@
+// conv_igemm_patch.hip -- 3x3 stride-1 "same" int8 convolution as an implicit GEMM whose im2col matrix exists
+// only as ONE staged row patch in LDS, read NHWC or NCHW natively (row a5 of SURVEY 8: no re-layout pass).
+//
+// Why another kernel (profiles/r02_notes.md): the block-tile kernels fetch every input byte nine times through
+// the CU's L2 -> LDS path (one piece per filter tap), and that path -- ~29 B per cycle next to busy matrix
+// cores -- paced their K loops at half the MFMA rate; ResNet-50's layers at batch 128 are ONE tile per CU, so
+// nothing overlapped the fixed costs either.  Here
+//   * a workgroup owns R whole output rows (R * W <= 416 pixels = 13 MFMA pixel blocks) of TN = 32 * OB output
+//     channels.  Per 64 / 128-channel stage the rows' input patch (+ one halo row above / below, one shared
+//     padding column per row, padding rows between images) is staged ONCE as [patch pixel][KC + 16 bytes]: a
+//     filter tap is a constant LDS address offset (ty * (W + 1) + tx) * pitch, so all nine taps -- the whole
+//     im2col expansion -- are served from LDS and the L2 -> LDS traffic drops ~6x.  The 16-byte pad slot per
+//     pixel makes the pitch an odd number of 16-byte slots: every ds_read_b128 lane group hits 64 distinct
+//     banks whatever the tap shift (no XOR swizzle, which would not commute with the shift);
+//   * weights never touch LDS: a wave owns ONE 32-channel block (x a K part), nobody else needs its A
+//     fragments, so they stream global -> VGPR from a plan-time copy in fragment order (one coalesced 1-KiB
+//     load per K step, three steps of look-ahead);
+//   * four waves, one per SIMD, up to 512 registers each: 13 x 16 accumulators, an 8-deep ring of B
+//     fragments read 7 MFMAs ahead, and the staging of the NEXT stage (global -> VGPR -> LDS) in the same
+//     instruction stream under the MFMAs -- NHWC: 16-byte pieces as they are; NCHW: a lane loads 16 pixels x
+//     16 channels of plane runs (unaligned 16-byte loads: tools/probes/unaligned.hip), transposes 16 x 16
+//     bytes in registers (128 v_perm_b32 per 256 bytes, ~3 % of a stage's issue slots) and writes pixel-major.
+//     With one staging per nine taps this costs less than one LDS-DMA piece per tap did;
+//   * wave roles (PG pixel groups x OB channel blocks x KP K parts = 4) are chosen so that a layer is ~one
+//     round of tiles on the 256 CUs: ResNet-50 at batch 128 = exactly 256 (or 512) tiles for every 3x3 layer
+//     (64ch @56: 2 x 2 x 1, 128 @28: 1 x 4 x 1, 256 @14: 1 x 2 x 2, 512 @7: 1 x 1 x 4).  K parts are summed
+//     exactly (int32) through LDS in the epilogue;
+//   * epilogue from registers: a wave has ONE channel block, so its per-channel tables are 2 (NCHW: lane =
+//     channel) or 32 (NHWC) registers; v_permlane32_swap gives every lane 16 consecutive bytes of the output
+//     tensor's fastest dimension -> one 16-byte store per MFMA block per lane in either layout.
+// Numerical contract: common.h (exact int32 sums, two-rounding fp32 epilogue) -- bit-identical to every other
+// int8 kernel of the library and to oracle formulation X.
+//
+// Replaces shl_ref_conv2d_nhwc_f32 / shl_ref_conv2d_nchw_f32 + conv_im2col_sgemm_avx
+// (source/reference/convolution.c:28-139, conv_avx.h:109-1008) inside shl_ref_conv2d_quant (:370-400).
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "dw_mfma.h"
+#include "igemm_common.h"
+
+namespace shl {
+
+constexpr int PT_NB = 13;                // MFMA pixel blocks (32 pixels) per wave
+constexpr int PT_PIX = PT_NB * 32;       // 416
+constexpr int PT_D = 7;                  // B fragments are read this many MFMAs ahead (ring of 8)
+constexpr int PT_TRASH = 4096;           // LDS bytes that swallow the writes of invalid staging items (16 B per lane)
+constexpr int PT_NIT = 16;               // NHWC staging: 16-byte items per lane per stage
+constexpr int PT_TABLES = 4096;          // row tables of the prologue (behind the trash area)
+constexpr int PT_LDS_MAX = 160 * 1024;
+
+#define PT_KC(g) ((g) & 0xff)
+#define PT_PG(g) (((g) >> 8) & 0xf)
+#define PT_OB(g) (((g) >> 12) & 0xf)
+#define PT_KP(g) (((g) >> 16) & 0xf)
+
+// x / d for x < 2^22 (q is within one of the quotient after the float multiply)
+__device__ __forceinline__ uint32_t pt_div(uint32_t x, uint32_t d, float rcp)
+{
+    uint32_t q = (uint32_t)(__uint2float_rn(x) * rcp);
+    const int32_t r = (int32_t)(x - q * d);
+    if (r < 0)
+        --q;
+    else if ((uint32_t)r >= d)
+        ++q;
+    return q;
+}
+
+__device__ __forceinline__ void pt_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+typedef uint32_t pt_u4 __attribute__((ext_vector_type(4), aligned(1)));  // 16 bytes at any byte address
+
+// SHL_MI355X_DEBUG=32: wave 0 of workgroup 0 stamps s_memtime at its phase boundaries (tools/pp_trace.py --patch)
+__device__ unsigned long long g_pt_trace[64];
+
+template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
+__global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
+{
+    int trace_k = 0;
+    auto mark = [&]() {
+        if ((a.debug & 32) && blockIdx.x == 0 && threadIdx.x == 0 && trace_k < 64) g_pt_trace[trace_k++] = __builtin_amdgcn_s_memtime();
+    };
+    mark();
+    static_assert(PG * OB * KP == 4, "four waves");
+    constexpr int NB = PT_NB, D = PT_D;
+    constexpr int U = KC / 32;          // 32-byte K sub-steps per tap and stage
+    constexpr int UI = U / KP;          // ... of which this wave takes every KP-th
+    constexpr int NSTEP = 9 * UI;       // K steps (13 MFMAs each) per stage and wave
+    constexpr int NF = NSTEP * NB;      // MFMAs per stage and wave
+    constexpr int PITCH = KC + 16;
+    constexpr int SLOTS = KC / 16;
+    constexpr int CG = KC / 16;         // 16-channel groups per stage (NCHW staging)
+    static_assert(U % KP == 0, "K parts split the sub-steps of a tap");
+    static_assert(NSTEP % 9 == 0, "weight fragment ring of nine");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, frow = lane & 31, fhalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kp = wave % KP, ob = (wave / KP) % OB, pg = wave / (KP * OB);
+    const int W = a.W, H = a.H, W1 = W + 1, H1 = H + 1, HW = H * W;
+    const int R = a.pt_rows, TR = PG * R, RW = R * W;
+    const int total_rows = a.N * H;
+    const int ocblks = (a.Co + 31) >> 5;
+    const int nt_n = (ocblks + OB - 1) / OB;
+    const int nt_m = a.pt_ntm;  // (total_rows + TR - 1) / TR, from the host: every integer division here is ~40 instructions
+    // XCD-aware order: one XCD walks all channel tiles of a run of row tiles -- its L2 fetches every input row
+    // once, the (small) weight tensor once per XCD
+    const int t = xcd_contiguous_block(blockIdx.x, nt_n * nt_m);
+    const int tile_m = (int)pt_div((uint32_t)t, nt_n, 1.0f / (float)nt_n), tile_n = t - tile_m * nt_n;
+    const int row0 = tile_m * TR;  // first output row (n * H + y) of the tile
+    int ocb = tile_n * OB + ob;
+    const bool ocb_ok = ocb < ocblks;
+    if (!ocb_ok) ocb = ocblks - 1;
+    const int nstg = a.C / KC;
+    const uint32_t bufb = (uint32_t)a.pt_bufb;
+    const float rW = 1.0f / (float)W, rH = 1.0f / (float)H, rH1 = 1.0f / (float)H1, rW1 = 1.0f / (float)W1;
+    // "virtual" rows: every image is followed by ONE padding row (bottom halo of its last row = top halo of the
+    // next image's first row): v(g) = g + g / H.  Patch row pr holds virtual row v0 + pr.
+    const int v0 = row0 + (int)pt_div((uint32_t)row0, H, rH) - 1;
+    const int last_row = (row0 + TR < total_rows ? row0 + TR : total_rows) - 1;
+    const int prows = last_row + (int)pt_div((uint32_t)last_row, H, rH) - v0 + 2;
+
+    // ---- weights: this wave's fragment stream, 1 KiB per K step; a ring of nine fragments = eight steps
+    // (~3 300 cycles) of look-ahead: vector loads return in order, so a weight load issued behind the next stage's
+    // staging loads (HBM latency) or behind a first touch of the weights is late by that much
+    const char *wsb = static_cast<const char *>(a.w_patch) + ((size_t)(ocb * KP + kp) * nstg * NSTEP) * 1024;
+    const int wl = lane * 16;
+    v4i fa[9];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fa[q] = *reinterpret_cast<const v4i *>(wsb + q * 1024 + wl);
+
+    // ---- row tables in LDS (one division per ROW instead of two per staging item and pixel block):
+    //   prow_tab[pr]  patch row pr  -> byte offset of input row (n, y) in an NHWC tensor, or -1 (a padding row)
+    //   trow_tab[r]   tile row r    -> its patch row
+    //   inv_tab[i]    the padding rows of the patch, compacted (count in inv_cnt)
+    int32_t *const prow_tab = reinterpret_cast<int32_t *>(smem + 2 * bufb + PT_TRASH);             // <= 512 rows
+    uint16_t *const trow_tab = reinterpret_cast<uint16_t *>(smem + 2 * bufb + PT_TRASH + 2048);    // <= 512 rows
+    uint16_t *const inv_tab = reinterpret_cast<uint16_t *>(smem + 2 * bufb + PT_TRASH + 3072);     // <= 256 rows
+    int32_t *const inv_cnt = reinterpret_cast<int32_t *>(smem + 2 * bufb + PT_TRASH + 3584);
+    // epilogue tables of the four waves (written after the row tables are dead): 32 multipliers + 32 biases each
+    float *const epi_tab = reinterpret_cast<float *>(smem + 2 * bufb + PT_TRASH) + wave * 96;
+    // requested now, used at the very end
+    const float t_mult = a.mult[ocb * 32 + frow], t_bias = a.bias[ocb * 32 + frow];
+    const int32_t t_acc = a.acc_init[ocb * 32 + frow];
+    if (wave == 0) {
+        int ninv = 0;
+        for (int pr = lane; pr < ((a.pt_prows + 63) & ~63); pr += 64) {
+            const int v = v0 + pr;
+            const uint32_t vv = v < 0 ? 0 : (uint32_t)v;
+            const uint32_t n = pt_div(vv, H1, rH1), y = vv - n * H1;
+            const bool in_patch = pr < a.pt_prows;
+            const bool ok = pr < prows && v >= 0 && y < (uint32_t)H && n < (uint32_t)a.N;
+            if (in_patch) prow_tab[pr] = ok ? (int32_t)(((n * H + y) * W) * (kNchw ? 1 : a.C)) : -1;
+            const uint64_t bad = __ballot(in_patch && !ok);
+            if (in_patch && !ok) inv_tab[ninv + __popcll(bad & ((1ull << lane) - 1))] = (uint16_t)pr;
+            ninv += __popcll(bad);
+        }
+        if (lane == 0) *inv_cnt = ninv;
+    } else {
+        for (int r = tid - 64; r < TR; r += 192) {
+            const uint32_t g = (uint32_t)row0 + r;
+            trow_tab[r] = (uint16_t)(g + pt_div(g, H, rH) - (uint32_t)v0);
+        }
+    }
+    pt_barrier();
+
+    // ---- staging items of this lane (the same for every stage) -------------------------------------------
+    // NHWC: item = (patch pixel, 16-byte slot); NCHW: item = (image run, 16-channel group, 16-pixel segment)
+    constexpr int NSRC = kNchw ? 2 : PT_NIT;
+    constexpr int NDST = kNchw ? 32 : PT_NIT;
+    uint32_t s_src[NSRC], s_dst[NDST];
+    const uint32_t trash = 2 * bufb + lane * 16 + (wave & 3) * 1024;
+    if constexpr (!kNchw) {
+        constexpr int PS = 256 / SLOTS;  // pixels between a lane's consecutive items
+        const uint32_t slot = tid % SLOTS;
+        uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - pr * W;
+        const uint32_t dpr = pt_div(PS, W, rW), dx = PS - dpr * W;
+#pragma unroll
+        for (int it = 0; it < PT_NIT; ++it) {
+            const int32_t row = (int)pr < prows ? prow_tab[pr] : -1;
+            s_src[it] = row >= 0 ? (uint32_t)row + x * a.C + slot * 16 : 0;
+            s_dst[it] = row >= 0 ? (pr * W1 + x + 1) * PITCH + slot * 16 : trash;
+            x += dx, pr += dpr;
+            if (x >= (uint32_t)W) x -= W, ++pr;
+        }
+    } else {
+        const uint32_t nf = v0 < 0 ? 0 : pt_div((uint32_t)v0, H1, rH1);  // first image the patch touches
+        const uint32_t spr = (uint32_t)a.pt_spr;
+        const float rspr = 1.0f / (float)spr;
+        const int total = a.N * a.C * HW;  // < 2^31 (checked on the host)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            // consecutive lanes = consecutive 16-byte segments of one channel's run: a wave-level load touches a few
+            // whole lines (with the channel group fastest every lane had a line of its own: 350 cycles per instruction)
+            const uint32_t item = it * 256 + tid;
+            const uint32_t rest = pt_div(item, spr, rspr), seg = item - rest * spr;
+            const uint32_t cg = rest % CG, run = rest / CG;
+            const uint32_t n = nf + run;
+            // rows [ya, yb] of image n inside the patch's virtual rows [v0, v0 + prows - 1]
+            const int lo = (int)(n * H1), hi = lo + H - 1;
+            const int va = v0 > lo ? v0 : lo, vb = v0 + prows - 1 < hi ? v0 + prows - 1 : hi;
+            const bool run_ok = it < a.pt_nitc && n < (uint32_t)a.N && vb >= va;
+            const int ya = va - lo, runlen = run_ok ? (vb - va + 1) * W : 0;
+            int k0 = (int)seg * 16;
+            // byte offset of (image n, channel cg * 16, row ya, pixel k0) in the NCHW tensor; the window of the LAST
+            // channel of the LAST stage must end inside the tensor: slide the window back (its first bytes then
+            // belong to pixels in front of the segment and are dropped)
+            int off = ((int)n * a.C + (int)cg * 16) * HW + ya * W + k0;
+            const int over = run_ok ? off + (a.C - KC + 15) * HW + 16 - total : 0;
+            if (over > 0) {
+                off -= over;
+                k0 -= over;
+            }
+            if (!run_ok || off < 0) off = 0;
+            s_src[it] = (uint32_t)off;
+            // pixel k of the run is patch pixel (row lo + ya + k / W - v0, k % W): one division, then increments
+            const uint32_t kf = k0 < 0 ? 0u : (uint32_t)k0;
+            uint32_t yy = pt_div(kf, W, rW), x = kf - yy * W;
+            const uint32_t pr0 = (uint32_t)(lo + ya - v0);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const int k = k0 + b;
+                const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
+                s_dst[it * 16 + b] = ok ? ((pr0 + yy) * W1 + x + 1) * PITCH + cg * 16 : trash;
+                if (k >= 0) {
+                    if (++x == (uint32_t)W) x = 0, ++yy;
+                }
+            }
+        }
+    }
+
+    // ---- staging of one stage, cut into sixteen pieces so that the K loop can place one piece per MFMA slot:
+    // NHWC sd[q] = item q's 16 bytes; NCHW sd[c] = 16 pixels of channel c of the lane's 16-channel group
+    v4i sd[16];
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.in), 0, 0x7fffffff, 0x00020000);
+    uint32_t tr_o[4][4];  // NCHW: the four pixels of one dword column, transposed
+    auto stage_load_one = [&](int stage, int it, auto qc) {
+        constexpr int q = decltype(qc)::value;
+        // NHWC: buffer loads (descriptor + 32-bit lane offset + scalar stage offset): as plain global loads the
+        // optimiser turns the sixteen loop-invariant lane offsets into 64-bit pointers held across the K loop
+        if constexpr (!kNchw) {
+            sd[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)s_src[q], stage * KC, 0));
+        } else {
+            const char *base = static_cast<const char *>(a.in) + (size_t)stage * KC * HW;
+            const uint32_t o = it == 0 ? s_src[0] : s_src[1];
+            sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * HW))));
+        }
+    };
+    auto stage_write_one = [&](uint32_t bufoff, int it, auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (!kNchw) {
+            const uint32_t d = s_dst[q];
+            *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = sd[q];
+        } else {
+            // piece q = (dword column jd = q / 4, channel quad ca = q % 4): one 4 x 4 byte block of the 16 channels x
+            // 16 pixels -> 16 pixels x 16 channels transposition; after the fourth quad the column's four pixels go out
+            constexpr int jd = q / 4, ca = q % 4;
+            const uint32_t in4[4] = {(uint32_t)sd[4 * ca + 0][jd], (uint32_t)sd[4 * ca + 1][jd], (uint32_t)sd[4 * ca + 2][jd],
+                                     (uint32_t)sd[4 * ca + 3][jd]};
+            uint32_t out4[4];
+            transpose4x4_bytes(in4, out4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tr_o[e][ca] = out4[e];
+            if constexpr (ca == 3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t d = it == 0 ? s_dst[4 * jd + e] : s_dst[16 + 4 * jd + e];
+                    const v4i v = {(int)tr_o[e][0], (int)tr_o[e][1], (int)tr_o[e][2], (int)tr_o[e][3]};
+                    *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = v;
+                }
+            }
+        }
+    };
+
+    mark();  // 1: staging items computed
+    static_for<16>([&](auto qc) { stage_load_one(0, 0, qc); });
+
+    // ---- padding: column 0 of every patch row (= right padding of the row before) and the rows outside an image get
+    // the input zero point, in both buffers, once (staging never writes there).  One 16-byte write per unit =
+    // (padding pixel, slot, buffer), units dealt out to the threads (a loop over all patch pixels kept 1 lane in W + 1
+    // busy per ds_write_b128: 3 000 cycles)
+    {
+        const uint32_t zp4 = (uint32_t)(a.in_zp & 0xff) * 0x01010101u;
+        const v4i zv = {(int)zp4, (int)zp4, (int)zp4, (int)zp4};
+        constexpr int S2 = 2 * SLOTS;
+        const uint32_t n0 = ((uint32_t)a.pt_prows + 1) * S2;
+        for (uint32_t u = tid; u < n0; u += 256) {
+            const uint32_t pr = u / S2, sb = u % S2;
+            *reinterpret_cast<v4i *>(smem + (sb / SLOTS) * bufb + pr * W1 * PITCH + (sb % SLOTS) * 16) = zv;
+        }
+        const uint32_t per_row = (uint32_t)W * S2;
+        const uint32_t n1 = (uint32_t)*inv_cnt * per_row;
+        const float rper = 1.0f / (float)per_row;
+        for (uint32_t u = tid; u < n1; u += 256) {
+            const uint32_t i = pt_div(u, per_row, rper), r2 = u - i * per_row;
+            const uint32_t x = r2 / S2, sb = r2 % S2;
+            const uint32_t q = (uint32_t)inv_tab[i] * W1 + x + 1;
+            *reinterpret_cast<v4i *>(smem + (sb / SLOTS) * bufb + q * PITCH + (sb % SLOTS) * 16) = zv;
+        }
+    }
+
+    mark();  // 2: padding written
+    // ---- this lane's pixel of each MFMA block: LDS offset of patch pixel (row - 1, x - 1), i.e. of tap (0, 0)
+    uint32_t pbase[NB];
+    {
+        uint32_t r = pt_div(frow, W, rW), x = frow - r * W;
+        const uint32_t d32r = pt_div(32, W, rW), d32x = 32 - d32r * W;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const bool ok = (uint32_t)(j * 32 + frow) < (uint32_t)RW && row0 + pg * R + (int)r < total_rows;
+            const uint32_t prow = trow_tab[ok ? pg * R + r : 0];  // patch row of the pixel's own input row (>= 1)
+            pbase[j] = ((prow - 1) * W1 + (ok ? x : 0)) * PITCH + fhalf * 16 + kp * 32;
+            x += d32x, r += d32r;
+            if (x >= (uint32_t)W) x -= W, ++r;
+        }
+    }
+
+    // ---- accumulators start at zero; the plan's acc_init (= -zp_in * sum(w)) is added in the epilogue, once, after
+    // the K parts have been summed (initial values held in registers made the allocator split accumulators into
+    // VGPRs and spill)
+    v16i acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0;
+
+    mark();  // 3: pixel offsets computed
+    static_for<16>([&](auto qc) { stage_write_one(0, 0, qc); });
+    if constexpr (kNchw) {
+        if (a.pt_nitc > 1) {
+            static_for<16>([&](auto qc) { stage_load_one(0, 1, qc); });
+            static_for<16>([&](auto qc) { stage_write_one(0, 1, qc); });
+        }
+    }
+    mark();  // 4: stage 0 written
+    pt_barrier();
+    mark();  // 5: barrier passed
+    if constexpr (!kNchw) {  // the row tables are dead: this wave's multipliers and biases take their place
+        if (fhalf == 0) epi_tab[frow] = t_mult, epi_tab[64 + frow] = __int_as_float(t_acc);
+        else epi_tab[32 + frow] = t_bias;
+    }
+
+    // ---- K loop ----------------------------------------------------------------------------------------------
+    // One K step = 13 MFMAs (one per pixel block) on one weight fragment.  The instruction order is pinned
+    // (sched_barrier after every MFMA: left to itself the scheduler hoists the LDS reads of a whole stage and
+    // spills): slot j issues the B read that is D MFMAs ahead -- block j + D of this step, or block j + D - 13 of
+    // the next one, into the register its own MFMA freed D - 13 slots ago -- then at most two staging pieces, then
+    // the MFMA.  Waits are the compiler's own counted s_waitcnt (plain loads; LDS and VMEM return in order).
+    v4i rb[NB];
+    auto tap_off = [&](int step) -> uint32_t {  // LDS offset of a K step's (tap, sub-step); wave-uniform
+        const int tap = step / UI, ui = step - tap * UI;
+        const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+        return (uint32_t)((ty * W1 + tx) * PITCH + ui * (KP * 32));
+    };
+    // ONE loop body for every step (nine steps per iteration: the weight ring's index is static): the accumulators
+    // have a single chain of definitions through the loop, and the staging pieces of the next stage sit in small
+    // wave-uniform branches that contain no MFMA -- branches AROUND whole steps made the register allocator split
+    // accumulators into VGPRs and spill.  Staging rides on step 0 (loads), step 4 (LDS writes, + the loads of the
+    // second NCHW round) and step 7 (its writes).
+    auto kstep = [&](auto fc, int s, int step, uint32_t bufoff, bool more) {
+        constexpr int F = decltype(fc)::value;
+        const uint32_t cur = bufoff + tap_off(step), nxt = bufoff + tap_off(step + 1);
+        const uint32_t nbufoff = bufb - bufoff;
+        // the weights of eight steps ahead (the plan pads the copy: no tail test)
+        fa[(F + 8) % 9] = *reinterpret_cast<const v4i *>(wsb + ((size_t)(s * NSTEP + step + 8)) * 1024 + wl);
+        const bool do_load = F == 0 && more && step == 0;
+        const bool do_write0 = F == 4 && more && step == 4;
+        const bool do_write1 = kNchw && F == 7 && more && step == 7 && a.pt_nitc > 1;
+        static_for<NB>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            // the last step of a stage reads "next" fragments nobody uses (one code path; LDS reads cannot fault)
+            if constexpr (j + D < NB)
+                rb[j + D] = *reinterpret_cast<const v4i *>(smem + (pbase[j + D] + cur));
+            else
+                rb[j + D - NB] = *reinterpret_cast<const v4i *>(smem + (pbase[j + D - NB] + nxt));
+            // sixteen staging pieces on thirteen slots, IN ORDER (the NCHW transposition finishes a dword column with
+            // its fourth piece): slots 0 .. 9 take one piece, slots 10 .. 12 two
+            constexpr int P0 = j < 10 ? j : 10 + 2 * (j - 10);
+            constexpr int P1 = j < 10 ? -1 : P0 + 1;
+            if constexpr (F == 0) {
+                if (do_load) {
+                    stage_load_one(s + 1, 0, std::integral_constant<int, P0>{});
+                    if constexpr (P1 >= 0) stage_load_one(s + 1, 0, std::integral_constant<int, P1>{});
+                }
+            }
+            if constexpr (F == 4) {
+                if (do_write0) {
+                    stage_write_one(nbufoff, 0, std::integral_constant<int, P0>{});
+                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 0, std::integral_constant<int, P1>{});
+                }
+            }
+            if constexpr (kNchw && F == 7) {
+                if (do_write1) {
+                    stage_write_one(nbufoff, 1, std::integral_constant<int, P0>{});
+                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 1, std::integral_constant<int, P1>{});
+                }
+            }
+            if constexpr (kNchw)
+                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[j], fa[F], acc[j], 0, 0, 0);  // rows = pixels
+            else
+                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[F], rb[j], acc[j], 0, 0, 0);  // rows = channels
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (kNchw && F == 4) {
+            if (do_write0 && a.pt_nitc > 1) static_for<16>([&](auto qc) { stage_load_one(s + 1, 1, qc); });
+        }
+    };
+    for (int s = 0; s < nstg; ++s) {
+        const uint32_t bufoff = (s & 1) ? bufb : 0u;
+        const bool more = s + 1 < nstg;
+        {
+            const uint32_t cur = bufoff + tap_off(0);
+            static_for<D>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                rb[j] = *reinterpret_cast<const v4i *>(smem + (pbase[j] + cur));
+            });
+        }
+        for (int step = 0; step < NSTEP; step += 9)
+            static_for<9>([&](auto fc) { kstep(fc, s, step + decltype(fc)::value, bufoff, more); });
+        mark();        // 6 + 2 s: K steps of the stage done
+        pt_barrier();  // every wave is done with this buffer; the next one is complete
+        mark();        // 7 + 2 s
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------------------
+    const int pixbase = (row0 + pg * R) * W;  // flat output pixel of the pixel group's first pixel
+    char *out = static_cast<char *>(a.out);
+    // per-channel tables: NCHW lane = channel (column), NHWC 16 channels per lane (rows 8 g + 4 fhalf + e)
+    float4 mu[4], bi[4];
+    int4 ai[4];
+    if constexpr (kNchw) {
+        mu[0] = make_float4(t_mult, t_mult, t_mult, t_mult);
+        bi[0] = make_float4(t_bias, t_bias, t_bias, t_bias);
+        ai[0] = make_int4(t_acc, t_acc, t_acc, t_acc);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mu[g] = *reinterpret_cast<const float4 *>(epi_tab + 8 * g + 4 * fhalf);
+            bi[g] = *reinterpret_cast<const float4 *>(epi_tab + 32 + 8 * g + 4 * fhalf);
+            ai[g] = *reinterpret_cast<const int4 *>(epi_tab + 64 + 8 * g + 4 * fhalf);
+        }
+    }
+    // NCHW: (image, offset inside its plane) of the lane's first pixel of block 0 -- one exact division, then
+    // advanced by 32 pixels per block
+    uint32_t e_n = 0, e_rem = 0;
+    if constexpr (kNchw) {
+        const uint32_t m00 = (uint32_t)(pixbase + fhalf * 16);
+        e_n = m00 / (uint32_t)HW;
+        e_rem = m00 - e_n * HW;
+    }
+    auto advance = [&]() {
+        if constexpr (kNchw) {
+            e_rem += 32;
+            while (e_rem >= (uint32_t)HW) e_rem -= HW, ++e_n;
+        }
+    };
+    auto finalize = [&](int j, const v16i &c) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int4 i4 = kNchw ? ai[0] : ai[g];
+            pk[g] = requant4_i8_t<EPI>(c[4 * g + 0] + i4.x, c[4 * g + 1] + i4.y, c[4 * g + 2] + i4.z, c[4 * g + 3] + i4.w, kNchw ? mu[0] : mu[g],
+                                       kNchw ? bi[0] : bi[g], a);
+        }
+        const uint4 v = tile_channels_16(pk);  // 16 consecutive rows 16 fhalf .. + 15 of the lane's column
+        if (a.debug & 2) return;
+        if constexpr (!kNchw) {
+            const int pl = j * 32 + frow;
+            const int m = pixbase + pl;
+            const int oc = ocb * 32 + fhalf * 16;
+            if (ocb_ok && pl < RW && m < a.M && oc < a.Co) *reinterpret_cast<uint4 *>(out + (int64_t)m * a.Co + oc) = v;
+        } else {
+            const int oc = ocb * 32 + frow;
+            const int pl0 = j * 32 + fhalf * 16;
+            const int m0 = pixbase + pl0;
+            if (!ocb_ok || oc >= a.Co || pl0 >= RW || m0 >= a.M) return;
+            char *dst = out + ((int64_t)e_n * a.Co + oc) * HW + e_rem;
+            const bool full = pl0 + 16 <= RW && m0 + 16 <= a.M;
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            if (full && e_rem + 16 <= (uint32_t)HW) {  // 16 pixels of one plane: one store at whatever byte address
+                const pt_u4 t4 = {v.x, v.y, v.z, v.w};
+                *reinterpret_cast<pt_u4 *>(dst) = t4;
+            } else if (full && HW >= 16) {
+                // the run crosses into the next image once (planes of 49 or 196 bytes): dwords that lie inside one piece
+                // go out whole, the one that straddles the boundary byte by byte
+                const int len1 = HW - (int)e_rem;                      // bytes that still belong to image n
+                char *dst2 = dst + (int64_t)(a.Co - 1) * HW;             // = plane (n + 1, oc) - len1: byte b >= len1 goes to dst2 + b
+                typedef uint32_t u1_a1 __attribute__((aligned(1)));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (4 * d + 4 <= len1) {
+                        *reinterpret_cast<u1_a1 *>(dst + 4 * d) = w4[d];
+                    } else if (4 * d >= len1) {
+                        *reinterpret_cast<u1_a1 *>(dst2 + 4 * d) = w4[d];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            char *p = 4 * d + e < len1 ? dst + 4 * d + e : dst2 + 4 * d + e;
+                            *p = (char)(w4[d] >> (8 * e));
+                        }
+                    }
+                }
+            } else {
+                uint32_t r2 = e_rem;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (pl0 + e < RW && m0 + e < a.M) *dst = (char)(w4[e >> 2] >> (8 * (e & 3)));
+                    ++dst;
+                    if (++r2 == (uint32_t)HW) {  // next image: same channel plane, Co planes further
+                        r2 = 0;
+                        dst += (int64_t)(a.Co - 1) * HW;
+                    }
+                }
+            }
+        }
+    };
+
+    if constexpr (KP == 1) {
+        // two blocks at a time: their requantisation chains are independent (a wave alone on its SIMD runs one chain
+        // latency-bound), the pairs are kept apart so that the accumulators' copies do not pile up in registers
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            finalize(j, acc[j]);
+            advance();
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // K parts: block j is finished by the wave with kp == j % KP; the others hand their partial sums over
+        // through LDS (exact int32 adds), eight blocks per round (8 x 4 KiB per wave)
+        static_assert(4 * 8 * 4096 <= PT_LDS_MAX, "exchange area");
+        char *const mine = smem + wave * (8 * 4096);
+        static_for<2>([&](auto rc) {
+            constexpr int rb = decltype(rc)::value * 8;
+            constexpr int re = rb + 8 < NB ? rb + 8 : NB;
+            static_for<re - rb>([&](auto jc) {
+                constexpr int j = rb + decltype(jc)::value;
+                if (j % KP != kp) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                        *reinterpret_cast<v4i *>(mine + ((j - rb) * 4 + g) * 1024 + lane * 16) = v;
+                    }
+                }
+            });
+            pt_barrier();
+            static_for<re - rb>([&](auto jc) {
+                constexpr int j = rb + decltype(jc)::value;
+                if (j % KP == kp) {
+                    v16i c = acc[j];
+#pragma unroll
+                    for (int o = 1; o < KP; ++o) {
+                        const int other = wave - kp + (kp + o) % KP;
+                        const char *src = smem + other * (8 * 4096) + (j - rb) * 4096 + lane * 16;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const v4i v = *reinterpret_cast<const v4i *>(src + g * 1024);
+                            c[4 * g] += v[0];
+                            c[4 * g + 1] += v[1];
+                            c[4 * g + 2] += v[2];
+                            c[4 * g + 3] += v[3];
+                        }
+                    }
+                    finalize(j, c);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                advance();
+            });
+            if constexpr (rb == 0) pt_barrier();
+        });
+    }
+    mark();  // last: epilogue done
+}
+
+// =================================================================================================== host side
+bool patch_supports(const shl_mi355x_conv_desc &d)
+{
+    if (d.dtype != SHL_MI355X_I8 || d.group != 1) return false;
+    if (d.kernel_h != 3 || d.kernel_w != 3 || d.stride_h != 1 || d.stride_w != 1 || d.dilation_h != 1 || d.dilation_w != 1) return false;
+    if (d.pad_top != 1 || d.pad_left != 1 || d.out_h != d.in_h || d.out_w != d.in_w) return false;
+    if (d.in_c % 64 != 0 || d.in_w > PT_PIX) return false;
+    if (d.layout == SHL_MI355X_NHWC && d.out_c % 16 != 0) return false;  // 16-byte stores of 16 channels
+    if (d.in_zp < -128 || d.in_zp > 127) return false;
+    return true;
+}
+
+namespace {
+
+struct PatchShape {
+    int rows, prows, bufb, lds, nt_m, nt_n, nitc, spr;
+};
+
+// geometry of a forward pass with batch n; false when the patch does not fit LDS / the staging item budget
+bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchShape *ps)
+{
+    const int kc = PT_KC(geom), pg = PT_PG(geom), ob = PT_OB(geom), kp = PT_KP(geom);
+    if (!kc || C % kc != 0) return false;
+    const int64_t total_rows = (int64_t)n * H;
+    if (total_rows + n >= (1 << 22) || (int64_t)n * H * W >= (1ll << 31) - 4096) return false;
+    if ((int64_t)n * H * W * C >= (1ll << 31) - 65536) return false;  // 32-bit source offsets
+    int rows = PT_PIX / W;
+    if ((int64_t)rows * pg > total_rows) rows = (int)((total_rows + pg - 1) / pg);
+    const int pitch = kc + 16, slots = kc / 16;
+    for (; rows >= 1; --rows) {
+        const int tr = rows * pg;
+        const int nt_m = (int)((total_rows + tr - 1) / tr);
+        int prows = 0, runs = 0;
+        for (int tm = 0; tm < nt_m; ++tm) {  // exact capacity over the tiles of this batch
+            const int64_t r0 = (int64_t)tm * tr, rl = (r0 + tr < total_rows ? r0 + tr : total_rows) - 1;
+            const int64_t v0 = r0 + r0 / H - 1;
+            const int p = (int)(rl + rl / H - v0 + 2);
+            prows = p > prows ? p : prows;
+            const int64_t nf = v0 < 0 ? 0 : v0 / (H + 1), nl = (v0 + p - 1) / (H + 1);
+            const int ru = (int)(nl - nf + 1);
+            runs = ru > runs ? ru : runs;
+        }
+        const int px = prows * (W + 1) + 1;
+        const int bufb = (px * pitch + 255) & ~255;
+        int lds = 2 * bufb + PT_TRASH + PT_TABLES;
+        if (prows > 512 || tr > 512 || runs > 250) continue;  // row tables of the prologue
+        if (kp > 1 && lds < 4 * 8 * 4096) lds = 4 * 8 * 4096;
+        if (lds > PT_LDS_MAX) continue;
+        if (!nchw && (int64_t)prows * W * slots > PT_NIT * 256) continue;
+        int nitc = 1, spr = 1;
+        if (nchw) {
+            const int maxrun = (rows * pg + 2 < H ? rows * pg + 2 : H) * W;
+            spr = (maxrun + 15) / 16;
+            const int items = runs * spr * (kc / 16);
+            nitc = (items + 255) / 256;
+            if (nitc > 2) continue;
+        }
+        ps->rows = rows, ps->prows = prows, ps->bufb = bufb, ps->lds = lds, ps->nt_m = nt_m;
+        ps->nt_n = (((Co + 31) / 32) + ob - 1) / ob;
+        ps->nitc = nitc, ps->spr = spr;
+        return true;
+    }
+    return false;
+}
+
+int make_geom(int kc, int pg, int ob, int kp) { return kc | pg << 8 | ob << 12 | kp << 16; }
+
+}  // namespace
+
+// wave roles for a batch: the candidate with the fewest (rounds of tiles on 256 CUs) x (K share), ties to fewer
+// K parts (no exchange) and more channel blocks per tile (fewer staged patches)
+int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
+{
+    if (!patch_supports(d) || batch <= 0) return 0;
+    static const char *env = getenv("SHL_MI355X_PATCH");  // "pg,ob,kp" forces the roles (tests, A/B)
+    const int kc = d.in_c % 128 == 0 ? 128 : 64;
+    const int u = kc / 32;
+    const bool nchw = d.layout == SHL_MI355X_NCHW;
+    if (env && env[0] && env[0] != '0' && env[0] != '1') {
+        int pg = 0, ob = 0, kp = 0;
+        if (sscanf(env, "%d,%d,%d", &pg, &ob, &kp) == 3 && pg * ob * kp == 4 && u % kp == 0 && pg != 4 && !(pg == 2 && kp == 2)) {
+            PatchShape ps;
+            const int g = make_geom(kc, pg, ob, kp);
+            return patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps) ? g : 0;
+        }
+    }
+    static const int cand[][3] = {{1, 4, 1}, {2, 2, 1}, {1, 2, 2}, {1, 1, 4}};
+    const int ocblks = (d.out_c + 31) / 32;
+    int best = 0;
+    double best_cost = 0;
+    for (const auto &c : cand) {
+        const int pg = c[0], ob = c[1], kp = c[2];
+        if (u % kp != 0) continue;
+        if (ob > 1 && ob / 2 >= ocblks) continue;  // half of the channel blocks of a tile would be empty
+        PatchShape ps;
+        const int g = make_geom(kc, pg, ob, kp);
+        if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) continue;
+        const int64_t tiles = (int64_t)ps.nt_m * ps.nt_n;
+        const double rounds = (double)((tiles + 255) / 256);
+        // per tile and wave: a K loop over K / kp for 13 pixel blocks + fixed costs (prologue, epilogue; the exchange
+        // of partial sums for K parts)
+        const double total = rounds * (1.0 / kp + 0.12 + (kp > 1 ? 0.04 : 0.0));
+        if (!best || total < best_cost - 1e-9) best = g, best_cost = total;
+    }
+    return best;
+}
+
+size_t patch_weight_bytes(const shl_mi355x_conv_desc &d, int geom)
+{
+    const int ocblks = (d.out_c + 31) / 32;
+    return (size_t)ocblks * 32 * 9 * d.in_c + 9 * 1024;  // + eight fragments of read-ahead past the last K step
+}
+
+// [channel block][K part][stage][tap][sub-step of the part][lane][16 B]: lane = (channel & 31) | (K half << 5)
+void patch_pack_weights(const shl_mi355x_conv_desc &d, int geom, const int8_t *src, int8_t *dst)
+{
+    const int kc = PT_KC(geom), kp = PT_KP(geom);
+    const int u = kc / 32, ui_n = u / kp, nstg = d.in_c / kc, C = d.in_c;
+    const int ocblks = (d.out_c + 31) / 32;
+    memset(dst, 0, patch_weight_bytes(d, geom));
+    for (int ocb = 0; ocb < ocblks; ++ocb)
+        for (int p = 0; p < kp; ++p)
+            for (int st = 0; st < nstg; ++st)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ui = 0; ui < ui_n; ++ui) {
+                        int8_t *frag = dst + ((((size_t)(ocb * kp + p) * nstg + st) * 9 + tap) * ui_n + ui) * 1024;
+                        const int usub = p + kp * ui;
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int oc = ocb * 32 + (lane & 31);
+                            if (oc >= d.out_c) continue;
+                            const int c0 = st * kc + usub * 32 + (lane >> 5) * 16;
+                            const int ky = tap / 3, kx = tap % 3;
+                            for (int b = 0; b < 16; ++b) {
+                                const int c = c0 + b;
+                                const size_t s = d.layout == SHL_MI355X_NHWC ? (((size_t)oc * 3 + ky) * 3 + kx) * C + c
+                                                                             : (((size_t)oc * C + c) * 3 + ky) * 3 + kx;
+                                frag[lane * 16 + b] = src[s];
+                            }
+                        }
+                    }
+}
+
+bool patch_setup(ConvArgs &a)
+{
+    if (!a.w_patch || !a.pt_geom) return false;
+    PatchShape ps;
+    if (!patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps)) return false;
+    a.pt_rows = ps.rows;
+    a.pt_prows = ps.prows;
+    a.pt_bufb = ps.bufb;
+    a.pt_nitc = ps.nitc;
+    a.pt_spr = ps.spr;
+    a.pt_ntm = ps.nt_m;
+    return true;
+}
+
+bool patch_auto(const ConvArgs &a)
+{
+    static const char *env = getenv("SHL_MI355X_PATCH");
+    if (env && env[0] == '0') return false;
+    // literal dequantise-relu-requantise epilogues stay with the older kernels (two epilogue builds here)
+    if (a.act != SHL_MI355X_ACT_NONE && !a.act_clamp) return false;
+    ConvArgs t = a;
+    if (!patch_setup(t)) return false;
+    PatchShape ps;
+    patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
+    return (int64_t)ps.nt_m * ps.nt_n >= 96;  // fewer tiles than that: the latency-oriented kernels
+}
+
+template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
+static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
+{
+    auto kernel = conv_igemm_patch_kernel<EPI, kNchw, KC, PG, OB, KP>;
+    static bool opted = false;
+    if (!opted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
+        opted = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), lds, s, a);
+}
+
+template <int KC, int PG, int OB, int KP>
+static void patch_launch_geom(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
+{
+    if constexpr ((KC / 32) % KP == 0) {
+        const bool pow2 = a.div_exact != 0;
+        if (a.in_nchw) {
+            if (pow2) patch_launch_one<3, true, KC, PG, OB, KP>(a, tiles, lds, s);
+            else patch_launch_one<0, true, KC, PG, OB, KP>(a, tiles, lds, s);
+        } else {
+            if (pow2) patch_launch_one<3, false, KC, PG, OB, KP>(a, tiles, lds, s);
+            else patch_launch_one<0, false, KC, PG, OB, KP>(a, tiles, lds, s);
+        }
+    }
+}
+
+int patch_read_trace(unsigned long long *host, int count)
+{
+    if (count > 64) count = 64;
+    SHL_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pt_trace), (size_t)count * 8));
+    return SHL_MI355X_OK;
+}
+
+int launch_conv_igemm_patch(const ConvArgs &a0, hipStream_t s)
+{
+    ConvArgs a = a0;
+    if (!patch_setup(a) || (a.act != SHL_MI355X_ACT_NONE && !a.act_clamp)) {
+        set_error("conv_igemm_patch: the layer does not fit the row-patch kernel");
+        return SHL_MI355X_ENOTSUP;
+    }
+    PatchShape ps;
+    patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
+    const unsigned tiles = (unsigned)(ps.nt_m * ps.nt_n);
+    const int kc = PT_KC(a.pt_geom), key = PT_PG(a.pt_geom) * 100 + PT_OB(a.pt_geom) * 10 + PT_KP(a.pt_geom);
+#define SHL_PT(KCV)                                                          \
+    switch (key) {                                                           \
+        case 141: patch_launch_geom<KCV, 1, 4, 1>(a, tiles, ps.lds, s); break; \
+        case 221: patch_launch_geom<KCV, 2, 2, 1>(a, tiles, ps.lds, s); break; \
+        case 122: patch_launch_geom<KCV, 1, 2, 2>(a, tiles, ps.lds, s); break; \
+        case 114: patch_launch_geom<KCV, 1, 1, 4>(a, tiles, ps.lds, s); break; \
+        default: return SHL_MI355X_ENOTSUP;                                  \
+    }
+    if (kc == 128) {
+        SHL_PT(128)
+    } else {
+        SHL_PT(64)
+    }
+#undef SHL_PT
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}
+
+}  // namespace shl

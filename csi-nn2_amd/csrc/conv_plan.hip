@@ -19,6 +19,8 @@ struct shl_mi355x_conv_plan {
     size_t block_bytes;
     size_t off_w, off_acc, off_mult, off_bias, off_pad;
     size_t off_wfrag;  // 0: absent; pointwise int8 weights in MFMA fragment order (conv1x1_stream.hip)
+    size_t off_wpatch; // 0: absent; 3x3 weights as the per-wave fragment streams of conv_igemm_patch.hip
+    int32_t pt_geom;   // wave roles of that kernel, chosen for desc.batch (the packing depends on them)
     // int8 epilogue shortcuts (see ConvArgs)
     int32_t div_exact, div_fma, act_clamp;
     float clamp_lo, clamp_hi, inv_out_scale;
@@ -237,6 +239,15 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         const bool i8 = d.dtype == SHL_MI355X_I8;
         ConvArgs probe = {};
         probe.pix_tab = reinterpret_cast<const int2 *>(&probe);  // "will exist": built below when the pick needs it
+        p->pt_geom = patch_choose_geom(d, d.batch);
+        if (p->pt_geom) {
+            probe.w_patch = &probe;  // "will exist"
+            probe.pt_geom = p->pt_geom;
+            probe.in_nchw = d.layout == SHL_MI355X_NCHW;
+            probe.act = d.act;
+            float lo, hi;
+            probe.act_clamp = d.act != SHL_MI355X_ACT_NONE && derive_act_clamp(d, &lo, &hi);
+        }
         probe.Kh = d.kernel_h, probe.Kw = d.kernel_w, probe.sh = d.stride_h, probe.sw = d.stride_w;
         probe.dh = d.dilation_h, probe.dw = d.dilation_w;
         probe.pt = d.pad_top, probe.pl = d.pad_left, probe.H = d.in_h, probe.W = d.in_w, probe.Ho = d.out_h, probe.Wo = d.out_w;
@@ -251,6 +262,8 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             p->kernel_name = i8 ? "conv_igemm_regs_i8_mfma32x32x32" : "conv_igemm_regs_f16_mfma32x32x16";
         else if (!strcmp(v, "gemv"))
             p->kernel_name = i8 ? "conv_gemv_i8_dot4" : "conv_gemv_f16_fma";
+        else if (!strcmp(v, "patch"))
+            p->kernel_name = "conv_igemm_patch_i8_mfma32x32x32";
         else if (!strcmp(v, "pp"))
             p->kernel_name = i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
         else if (!strcmp(v, "res")) {
@@ -300,6 +313,10 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         p->off_wfrag = p->block_bytes;
         p->block_bytes += (size_t)d.out_c * d.in_c * es;
     }
+    if (algo == SHL_MI355X_ALGO_IGEMM && p->pt_geom) {
+        p->off_wpatch = align_up(p->block_bytes, 256);
+        p->block_bytes = p->off_wpatch + patch_weight_bytes(d, p->pt_geom);
+    }
     p->inv_out_scale = 1.0f / d.out_scale;
     if (d.dtype == SHL_MI355X_I8) {
         p->div_exact = i8_div_exact;
@@ -329,6 +346,9 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
                         for (int lane = 0; lane < 64; ++lane, dst += 16)
                             memcpy(dst, host.data() + p->off_w + (size_t)(g * 32 + (lane & 31)) * p->kstride + sub * 32 + (lane >> 5) * 16, 16);
             }
+            if (p->off_wpatch)
+                patch_pack_weights(d, p->pt_geom, reinterpret_cast<const int8_t *>(src),
+                                   reinterpret_cast<int8_t *>(host.data() + p->off_wpatch));
         }
         else if (algo == SHL_MI355X_ALGO_STEM)
             stem_pack_weights(d, reinterpret_cast<const int8_t *>(src),
@@ -540,6 +560,8 @@ static int fill_args(const shl_mi355x_conv_plan *plan, const void *input_dev, vo
     a.out = output_dev;
     a.w = plan->block + plan->off_w;
     a.w_frag = plan->off_wfrag ? plan->block + plan->off_wfrag : nullptr;
+    a.w_patch = plan->off_wpatch ? plan->block + plan->off_wpatch : nullptr;
+    a.pt_geom = plan->pt_geom;
     a.acc_init = reinterpret_cast<const int32_t *>(plan->block + plan->off_acc);
     a.mult = reinterpret_cast<const float *>(plan->block + plan->off_mult);
     a.bias = reinterpret_cast<const float *>(plan->block + plan->off_bias);
@@ -574,7 +596,8 @@ static int fill_args(const shl_mi355x_conv_plan *plan, const void *input_dev, vo
     a.clamp_lo = plan->clamp_lo;
     a.clamp_hi = plan->clamp_hi;
     a.pad_page = plan->block + plan->off_pad;
-    a.pix_tab = plan->pix_tab;
+    // the per-pixel table covers desc.batch images: a larger batch runs on the kernels that do their own index arithmetic
+    a.pix_tab = a.N <= d.batch ? plan->pix_tab : nullptr;
     a.ch_in_scale = plan->ch_in_scale;
     a.ch_out_scale = plan->ch_out_scale;
     a.ch_has_bias = plan->ch_has_bias;
@@ -609,6 +632,12 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
             // latency-bound pointwise layers read and write NCHW directly (nchw_small.hip)
             if (!strcmp(igemm_variant(a.M, a.Co), "wave") && conv1x1_nchw_eligible(a))
                 return launch_conv1x1_nchw(a, d.dtype, s);
+            // 3x3 stride-1 "same" int8: the row-patch kernel reads and writes NCHW itself (conv_igemm_patch.hip)
+            if (a.w_patch) {
+                ConvArgs t = a;
+                t.in_nchw = t.out_nchw = 1;
+                if (!strcmp(igemm_pick_name(t, 1), "patch")) return launch_conv_igemm_patch(t, s);
+            }
             // NCHW: [C][HW] -> [HW][C] scratch, NHWC kernel, [HoWo][Co] -> [Co][HoWo]
             if (a.N > d.batch || !plan->scratch_in) {
                 set_error("conv_forward: NCHW plan was created for batch %d, got %d", d.batch, a.N);
@@ -646,6 +675,7 @@ int shl_mi355x_debug_trace(uint64_t *host, int32_t count)
 {
     if (!host || count <= 0) return SHL_MI355X_EINVAL;
     const char *v = getenv("SHL_MI355X_IGEMM");  // which kernel's stamps: the producer / consumer kernel when it is forced
+    if (v && !strcmp(v, "patch")) return patch_read_trace(reinterpret_cast<unsigned long long *>(host), count);
     if (v && !strcmp(v, "res")) return res_read_trace(reinterpret_cast<unsigned long long *>(host), count);
     const char *x = getenv("SHL_MI355X_PCX");
     if (v && !strcmp(v, "pc") && x && x[0] == '1') return pcx_read_trace(reinterpret_cast<unsigned long long *>(host), count);

@@ -318,6 +318,7 @@ int launch_conv_igemm_res(const ConvArgs &a, hipStream_t s);
 int res_read_trace(unsigned long long *host, int count);
 const char *igemm_pick(const ConvArgs &a, int esize, int *flavour);
 int pp_read_trace(unsigned long long *host, int count);
+int patch_read_trace(unsigned long long *host, int count);  // conv_igemm_patch.hip
 
 // launchers of the halo-staged kernel (conv_igemm_halo.hip)
 bool halo_eligible(const ConvArgs &a, int esize);

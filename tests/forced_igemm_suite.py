@@ -44,6 +44,15 @@ SHAPES = [
     dict(c=64, co=48, h=9, w=13, n=5),                               # 64-byte pixels, Cout = 48: images inside one 512-pixel tile
     dict(c=64, co=64, h=17, w=19, n=4, pad=(1, 0, 1, 2), act=1),     # asymmetric padding, M = 1292 (ragged against 512)
     dict(c=64, co=16, k=(2, 2), pad=(0, 0, 1, 1), h=12, w=12, n=3),  # four taps
+    # row-patch kernel (conv_igemm_patch.hip): tiles of whole rows that straddle images, 7 x 7 planes (49 bytes: unaligned
+    # NCHW runs), several 128-channel stages, a width above half a tile, a tail tile, two NCHW staging rounds
+    dict(c=128, co=64, h=7, w=7, n=19),
+    dict(c=512, co=96, h=7, w=7, n=9, act=1),
+    dict(c=256, co=64, h=14, w=14, n=5, act=1),
+    dict(c=64, co=32, h=30, w=56, n=2),
+    dict(c=128, co=160, h=3, w=5, n=37),
+    dict(c=64, co=64, h=5, w=300, n=1),
+    dict(c=192, co=48, h=33, w=17, n=2, act=2),
 ]
 F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19]
 

@@ -61,6 +61,13 @@ VARIANTS = [
     # persistent workgroups with resident weights (conv_igemm_res.hip): int8, 64-byte pixels, Cout <= 64, stride 1
     (dict(SHL_MI355X_IGEMM="res", SHL_MI355X_RES="1"), "res"),
     (dict(SHL_MI355X_IGEMM="res", SHL_MI355X_RES="1", SHL_MI355X_RES_GROUPS="2"), "res"),
+    # row-patch kernel (conv_igemm_patch.hip): int8 3x3 stride-1 "same", C % 64 == 0; NHWC and NCHW native; automatic
+    # wave roles and every role assignment forced (pixel groups, channel blocks, K parts)
+    (dict(SHL_MI355X_IGEMM="patch"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="1,4,1"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="2,2,1"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="1,2,2"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="1,1,4"), "patch"),
 ]
 
 
@@ -75,8 +82,7 @@ def _run_variant(variant):
     env["SHL_EXPECT_KERNEL"] = expect
     if expect in ("pp", "pc"):
         env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "30"
-    if expect == "res":
-        env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "16"
+XX
     return subprocess.run([sys.executable, "-m", "pytest", SUITE, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
                           capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
 
@@ -111,7 +117,7 @@ RESNET_3X3 = [dict(c=64, co=64, h=56, w=56), dict(c=128, co=128, h=56, w=56, str
               dict(c=128, co=128, h=28, w=28), dict(c=256, co=256, h=28, w=28, stride=(2, 2)),
               dict(c=256, co=256, h=14, w=14), dict(c=512, co=512, h=14, w=14, stride=(2, 2)),
               dict(c=512, co=512, h=7, w=7)]
-BLOCK_TILE_KERNELS = ("tile", "pp", "pc", "res", "halo")
+BLOCK_TILE_KERNELS = ("tile", "pp", "pc", "res", "halo", "patch")
 
 
 @pytest.fixture(scope="module")

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--periods", type=int, default=6)
     ap.add_argument("--res", action="store_true", help="resident-weights kernel (SHL_MI355X_IGEMM=res SHL_MI355X_DEBUG=32)")
     ap.add_argument("--pc", action="store_true", help="producer / consumer kernel (SHL_MI355X_IGEMM=pc SHL_MI355X_DEBUG=32)")
+    ap.add_argument("--patch", action="store_true", help="row-patch kernel (SHL_MI355X_IGEMM=patch SHL_MI355X_DEBUG=32)")
+    ap.add_argument("--layout", default="NHWC")
     a = ap.parse_args()
     import cases
     pkg = cases.pkg
@@ -33,7 +35,7 @@ def main():
     fe = pkg.load_frontend("standalone")
     hip, opt = pkg.load_backend(fe)
     dev = cases.HipDevice(hip)
-    chain = wl.LayerChain(fe, hip, opt, [wl.RESNET50_3X3[a.layer]], a.batch, dev.alloc, dev.upload, chained=False)
+    chain = wl.LayerChain(fe, hip, opt, [wl.RESNET50_3X3[a.layer]], a.batch, dev.alloc, dev.upload, chained=False, layout=a.layout)
     for _ in range(3):
         chain.run_layer(0)
     hip.shl_mi355x_stream_sync(None)
@@ -41,6 +43,20 @@ def main():
     pkg.check(hip.shl_mi355x_debug_trace(buf, 1024), hip, "debug_trace")
     t = np.array(buf[:], dtype=np.uint64).astype(np.int64)
     print(wl.layer_name(chain.entries[0]["layer"]), chain.entries[0]["kernel_name"])
+    if a.patch:
+        # stamps: start | items | padding | pixel offsets | stage 0 written | barrier | per stage: steps done, barrier | end
+        n = int((t[:64] != 0).sum())
+        d = np.diff(t[:n])
+        names = ["staging items", "padding", "pixel offsets", "stage-0 wait+write", "barrier"]
+        k = 0
+        for nm in names:
+            print("  %-22s %7d" % (nm, d[k])); k += 1
+        st = 0
+        while k + 1 < len(d) - 0 and k + 2 <= len(d) - 1:
+            print("  stage %d steps %7d  barrier %6d" % (st, d[k], d[k + 1])); k += 2; st += 1
+        print("  %-22s %7d" % ("epilogue", d[-1]))
+        print("  total %d ticks" % (t[n - 1] - t[0]))
+        return
     if a.res:
         # stamps: start | prologue requests | first wait | then per period: barrier passed, and either
         # (K-loop role) next-patch requests, K loop, DMA wait  or  (epilogue role) epilogue
