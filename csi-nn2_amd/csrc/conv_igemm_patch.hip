@@ -60,13 +60,15 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 __device__ __forceinline__ uint32_t pt_div(uint32_t x, uint32_t d, float rcp)
 {
     uint32_t q = (uint32_t)(__uint2float_rn(x) * rcp);
-    const int32_t r = (int32_t)(x - q * d);
+    const int32_t r = (int32_t)(x - __umul24(q, d));  // operands < 2^22
     if (r < 0)
         --q;
     else if ((uint32_t)r >= d)
         ++q;
     return q;
 }
+
+__device__ __forceinline__ uint32_t m24(uint32_t x, uint32_t y) { return __umul24(x, y); }  // full-rate multiply (v_mul_lo_u32 is quarter rate)
 
 __device__ __forceinline__ void pt_barrier()
 {
@@ -79,6 +81,7 @@ typedef uint32_t pt_u4 __attribute__((ext_vector_type(4), aligned(1)));  // 16 b
 
 // SHL_MI355X_DEBUG=32: wave 0 of workgroup 0 stamps s_memtime at its phase boundaries (tools/pp_trace.py --patch)
 __device__ unsigned long long g_pt_trace[64];
+__device__ unsigned long long g_pt_span[2 * 1024];  // SHL_MI355X_DEBUG=32: [start, end] of wave 0 of every workgroup (s_memrealtime, 100 MHz)
 
 template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
 __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         if ((a.debug & 32) && blockIdx.x == 0 && threadIdx.x == 0 && trace_k < 64) g_pt_trace[trace_k++] = __builtin_amdgcn_s_memtime();
     };
     mark();
+    if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     static_assert(PG * OB * KP == 4, "four waves");
     constexpr int NB = PT_NB, D = PT_D;
     constexpr int U = KC / 32;          // 32-byte K sub-steps per tap and stage
@@ -101,6 +105,16 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     static_assert(NSTEP % 9 == 0, "weight fragment ring of nine");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    // every kernel argument the kernel will ever read, requested NOW in one batch: left to the compiler the scalar
+    // loads are sunk to their first uses, and each of the half dozen groups then costs its own 500 - 1 000 cycles of
+    // argument-segment latency in a prologue that nothing overlaps
+#define PT_PIN(x) asm volatile("" ::"s"(x))
+    PT_PIN(a.in); PT_PIN(a.out); PT_PIN(a.w_patch); PT_PIN(a.acc_init); PT_PIN(a.mult); PT_PIN(a.bias);
+    PT_PIN(a.N); PT_PIN(a.H); PT_PIN(a.W); PT_PIN(a.C); PT_PIN(a.Co); PT_PIN(a.M); PT_PIN(a.in_zp);
+    PT_PIN(a.pt_rows); PT_PIN(a.pt_prows); PT_PIN(a.pt_bufb); PT_PIN(a.pt_nitc); PT_PIN(a.pt_spr); PT_PIN(a.pt_ntm);
+    PT_PIN(a.pt_rW); PT_PIN(a.pt_rH); PT_PIN(a.pt_rH1); PT_PIN(a.pt_rspr); PT_PIN(a.pt_rntn);
+    PT_PIN(a.out_scale); PT_PIN(a.inv_out_scale); PT_PIN(a.out_zp_f); PT_PIN(a.out_zp); PT_PIN(a.clamp_lo); PT_PIN(a.clamp_hi);
+#undef PT_PIN
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 31, fhalf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kp = wave % KP, ob = (wave / KP) % OB, pg = wave / (KP * OB);
@@ -113,20 +127,21 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     // XCD-aware order: one XCD walks all channel tiles of a run of row tiles -- its L2 fetches every input row
     // once, the (small) weight tensor once per XCD
     const int t = xcd_contiguous_block(blockIdx.x, nt_n * nt_m);
-    const int tile_m = (int)pt_div((uint32_t)t, nt_n, 1.0f / (float)nt_n), tile_n = t - tile_m * nt_n;
+    const int tile_m = (int)pt_div((uint32_t)t, nt_n, a.pt_rntn), tile_n = t - tile_m * nt_n;
     const int row0 = tile_m * TR;  // first output row (n * H + y) of the tile
     int ocb = tile_n * OB + ob;
     const bool ocb_ok = ocb < ocblks;
     if (!ocb_ok) ocb = ocblks - 1;
     const int nstg = a.C / KC;
     const uint32_t bufb = (uint32_t)a.pt_bufb;
-    const float rW = 1.0f / (float)W, rH = 1.0f / (float)H, rH1 = 1.0f / (float)H1, rW1 = 1.0f / (float)W1;
+    const float rW = a.pt_rW, rH = a.pt_rH, rH1 = a.pt_rH1;  // reciprocals from the host (a division is ~12 instructions)
     // "virtual" rows: every image is followed by ONE padding row (bottom halo of its last row = top halo of the
     // next image's first row): v(g) = g + g / H.  Patch row pr holds virtual row v0 + pr.
     const int v0 = row0 + (int)pt_div((uint32_t)row0, H, rH) - 1;
     const int last_row = (row0 + TR < total_rows ? row0 + TR : total_rows) - 1;
     const int prows = last_row + (int)pt_div((uint32_t)last_row, H, rH) - v0 + 2;
 
+    mark();  // 1: tile decoded
     // ---- weights: this wave's fragment stream, 1 KiB per K step; a ring of nine fragments = eight steps
     // (~3 300 cycles) of look-ahead: vector loads return in order, so a weight load issued behind the next stage's
     // staging loads (HBM latency) or behind a first touch of the weights is late by that much
@@ -136,6 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
 #pragma unroll
     for (int q = 0; q < 8; ++q) fa[q] = *reinterpret_cast<const v4i *>(wsb + q * 1024 + wl);
 
+    mark();  // 2: weight loads issued
     // ---- row tables in LDS (one division per ROW instead of two per staging item and pixel block):
     //   prow_tab[pr]  patch row pr  -> byte offset of input row (n, y) in an NHWC tensor, or -1 (a padding row)
     //   trow_tab[r]   tile row r    -> its patch row
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             const uint32_t n = pt_div(vv, H1, rH1), y = vv - n * H1;
             const bool in_patch = pr < a.pt_prows;
             const bool ok = pr < prows && v >= 0 && y < (uint32_t)H && n < (uint32_t)a.N;
-            if (in_patch) prow_tab[pr] = ok ? (int32_t)(((n * H + y) * W) * (kNchw ? 1 : a.C)) : -1;
+            if (in_patch) prow_tab[pr] = ok ? (int32_t)(m24(m24(n, H) + y, W) * (kNchw ? 1 : a.C)) : -1;
             const uint64_t bad = __ballot(in_patch && !ok);
             if (in_patch && !ok) inv_tab[ninv + __popcll(bad & ((1ull << lane) - 1))] = (uint16_t)pr;
             ninv += __popcll(bad);
@@ -169,7 +185,9 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             trow_tab[r] = (uint16_t)(g + pt_div(g, H, rH) - (uint32_t)v0);
         }
     }
+    mark();  // 3: row tables written
     pt_barrier();
+    mark();  // 4: barrier
 
     // ---- staging items of this lane (the same for every stage) -------------------------------------------
     // NHWC: item = (patch pixel, 16-byte slot); NCHW: item = (image run, 16-channel group, 16-pixel segment)
@@ -180,23 +198,37 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     if constexpr (!kNchw) {
         constexpr int PS = 256 / SLOTS;  // pixels between a lane's consecutive items
         const uint32_t slot = tid % SLOTS;
-        uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - pr * W;
-        const uint32_t dpr = pt_div(PS, W, rW), dx = PS - dpr * W;
+        uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - m24(pr, W);
+        const uint32_t dpr = pt_div(PS, W, rW), dx = PS - m24(dpr, W);
+        const uint32_t last = (uint32_t)a.pt_prows - 1;
+        // all sixteen table reads first (one LDS round trip instead of sixteen), no branches: rows past the patch read
+        // the table's last entry and are dropped by the comparison
+        int32_t row[PT_NIT];
+        uint32_t prs[PT_NIT], xs[PT_NIT];
 #pragma unroll
         for (int it = 0; it < PT_NIT; ++it) {
-            const int32_t row = (int)pr < prows ? prow_tab[pr] : -1;
-            s_src[it] = row >= 0 ? (uint32_t)row + x * a.C + slot * 16 : 0;
-            s_dst[it] = row >= 0 ? (pr * W1 + x + 1) * PITCH + slot * 16 : trash;
+            prs[it] = pr, xs[it] = x;
+            row[it] = prow_tab[pr < last ? pr : last];
             x += dx, pr += dpr;
             if (x >= (uint32_t)W) x -= W, ++pr;
+        }
+#pragma unroll
+        for (int it = 0; it < PT_NIT; ++it) {
+            const bool ok = row[it] >= 0 && prs[it] <= last;
+            s_src[it] = ok ? (uint32_t)row[it] + m24(xs[it], a.C) + slot * 16 : 0;
+            s_dst[it] = ok ? m24(m24(prs[it], W1) + xs[it] + 1, PITCH) + slot * 16 : trash;
         }
     } else {
         const uint32_t nf = v0 < 0 ? 0 : pt_div((uint32_t)v0, H1, rH1);  // first image the patch touches
         const uint32_t spr = (uint32_t)a.pt_spr;
-        const float rspr = 1.0f / (float)spr;
+        const float rspr = a.pt_rspr;
         const int total = a.N * a.C * HW;  // < 2^31 (checked on the host)
 #pragma unroll
+        for (int q = 0; q < 16; ++q) s_dst[16 + q] = trash;
+        s_src[1] = 0;
+#pragma unroll
         for (int it = 0; it < 2; ++it) {
+            if (it == 1 && a.pt_nitc < 2) break;  // wave-uniform: the second round exists for few shapes only
             // consecutive lanes = consecutive 16-byte segments of one channel's run: a wave-level load touches a few
             // whole lines (with the channel group fastest every lane had a line of its own: 350 cycles per instruction)
             const uint32_t item = it * 256 + tid;
@@ -204,15 +236,15 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             const uint32_t cg = rest % CG, run = rest / CG;
             const uint32_t n = nf + run;
             // rows [ya, yb] of image n inside the patch's virtual rows [v0, v0 + prows - 1]
-            const int lo = (int)(n * H1), hi = lo + H - 1;
+            const int lo = (int)m24(n, H1), hi = lo + H - 1;
             const int va = v0 > lo ? v0 : lo, vb = v0 + prows - 1 < hi ? v0 + prows - 1 : hi;
             const bool run_ok = it < a.pt_nitc && n < (uint32_t)a.N && vb >= va;
-            const int ya = va - lo, runlen = run_ok ? (vb - va + 1) * W : 0;
+            const int ya = va - lo, runlen = run_ok ? (int)m24(vb - va + 1, W) : 0;
             int k0 = (int)seg * 16;
             // byte offset of (image n, channel cg * 16, row ya, pixel k0) in the NCHW tensor; the window of the LAST
             // channel of the LAST stage must end inside the tensor: slide the window back (its first bytes then
             // belong to pixels in front of the segment and are dropped)
-            int off = ((int)n * a.C + (int)cg * 16) * HW + ya * W + k0;
+            int off = (int)m24(m24(n, a.C) + cg * 16, HW) + (int)m24(ya, W) + k0;
             const int over = run_ok ? off + (a.C - KC + 15) * HW + 16 - total : 0;
             if (over > 0) {
                 off -= over;
@@ -228,7 +260,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             for (int b = 0; b < 16; ++b) {
                 const int k = k0 + b;
                 const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
-                s_dst[it * 16 + b] = ok ? ((pr0 + yy) * W1 + x + 1) * PITCH + cg * 16 : trash;
+                s_dst[it * 16 + b] = ok ? m24(m24(pr0 + yy, W1) + x + 1, PITCH) + cg * 16 : trash;
                 if (k >= 0) {
                     if (++x == (uint32_t)W) x = 0, ++yy;
                 }
@@ -279,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         }
     };
 
-    mark();  // 1: staging items computed
+    mark();  // 5: staging items computed
     static_for<16>([&](auto qc) { stage_load_one(0, 0, qc); });
 
     // ---- padding: column 0 of every patch row (= right padding of the row before) and the rows outside an image get
@@ -293,45 +325,52 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         const uint32_t n0 = ((uint32_t)a.pt_prows + 1) * S2;
         for (uint32_t u = tid; u < n0; u += 256) {
             const uint32_t pr = u / S2, sb = u % S2;
-            *reinterpret_cast<v4i *>(smem + (sb / SLOTS) * bufb + pr * W1 * PITCH + (sb % SLOTS) * 16) = zv;
+            *reinterpret_cast<v4i *>(smem + (sb / SLOTS ? bufb : 0u) + m24(m24(pr, W1), PITCH) + (sb % SLOTS) * 16) = zv;
         }
         const uint32_t per_row = (uint32_t)W * S2;
         const uint32_t n1 = (uint32_t)*inv_cnt * per_row;
-        const float rper = 1.0f / (float)per_row;
+        const float rper = a.pt_rW * (1.0f / S2);  // exact: S2 is a power of two
         for (uint32_t u = tid; u < n1; u += 256) {
-            const uint32_t i = pt_div(u, per_row, rper), r2 = u - i * per_row;
+            const uint32_t i = pt_div(u, per_row, rper), r2 = u - m24(i, per_row);
             const uint32_t x = r2 / S2, sb = r2 % S2;
-            const uint32_t q = (uint32_t)inv_tab[i] * W1 + x + 1;
-            *reinterpret_cast<v4i *>(smem + (sb / SLOTS) * bufb + q * PITCH + (sb % SLOTS) * 16) = zv;
+            const uint32_t q = m24(inv_tab[i], W1) + x + 1;
+            *reinterpret_cast<v4i *>(smem + (sb / SLOTS ? bufb : 0u) + m24(q, PITCH) + (sb % SLOTS) * 16) = zv;
         }
     }
 
-    mark();  // 2: padding written
+    mark();  // 6: padding written
     // ---- this lane's pixel of each MFMA block: LDS offset of patch pixel (row - 1, x - 1), i.e. of tap (0, 0)
     uint32_t pbase[NB];
     {
-        uint32_t r = pt_div(frow, W, rW), x = frow - r * W;
-        const uint32_t d32r = pt_div(32, W, rW), d32x = 32 - d32r * W;
+        uint32_t r = pt_div(frow, W, rW), x = frow - m24(r, W);
+        const uint32_t d32r = pt_div(32, W, rW), d32x = 32 - m24(d32r, W);
+        uint32_t prow[NB], xs[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
+        for (int j = 0; j < NB; ++j) {  // thirteen table reads, then the arithmetic
             const bool ok = (uint32_t)(j * 32 + frow) < (uint32_t)RW && row0 + pg * R + (int)r < total_rows;
-            const uint32_t prow = trow_tab[ok ? pg * R + r : 0];  // patch row of the pixel's own input row (>= 1)
-            pbase[j] = ((prow - 1) * W1 + (ok ? x : 0)) * PITCH + fhalf * 16 + kp * 32;
+            prow[j] = trow_tab[ok ? pg * R + r : 0];  // patch row of the pixel's own input row (>= 1)
+            xs[j] = ok ? x : 0;
             x += d32x, r += d32r;
             if (x >= (uint32_t)W) x -= W, ++r;
         }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) pbase[j] = m24(m24(prow[j] - 1, W1) + xs[j], PITCH) + fhalf * 16 + kp * 32;
     }
 
     // ---- accumulators start at zero; the plan's acc_init (= -zp_in * sum(w)) is added in the epilogue, once, after
     // the K parts have been summed (initial values held in registers made the allocator split accumulators into
     // VGPRs and spill)
     v16i acc[NB];
+    {
+        // 13 MFMAs on zero operands with the constant 0 as C instead of 208 register writes
+        v4i z = {0, 0, 0, 0};
+        asm volatile("" : "+v"(z));
+        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0;
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(z, z, zero16, 0, 0, 0);
+    }
 
-    mark();  // 3: pixel offsets computed
+    mark();  // 7: pixel offsets computed
     static_for<16>([&](auto qc) { stage_write_one(0, 0, qc); });
     if constexpr (kNchw) {
         if (a.pt_nitc > 1) {
@@ -339,9 +378,10 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             static_for<16>([&](auto qc) { stage_write_one(0, 1, qc); });
         }
     }
-    mark();  // 4: stage 0 written
+    if (nstg > 1) static_for<16>([&](auto qc) { stage_load_one(1, 0, qc); });  // stage 1: written at step 4 of stage 0
+    mark();  // 8: stage 0 written
     pt_barrier();
-    mark();  // 5: barrier passed
+    mark();  // 9: barrier passed
     if constexpr (!kNchw) {  // the row tables are dead: this wave's multipliers and biases take their place
         if (fhalf == 0) epi_tab[frow] = t_mult, epi_tab[64 + frow] = __int_as_float(t_acc);
         else epi_tab[32 + frow] = t_bias;
@@ -357,22 +397,25 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     auto tap_off = [&](int step) -> uint32_t {  // LDS offset of a K step's (tap, sub-step); wave-uniform
         const int tap = step / UI, ui = step - tap * UI;
         const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
-        return (uint32_t)((ty * W1 + tx) * PITCH + ui * (KP * 32));
+        return m24((uint32_t)(ty * W1 + tx), PITCH) + ui * (KP * 32);
     };
     // ONE loop body for every step (nine steps per iteration: the weight ring's index is static): the accumulators
     // have a single chain of definitions through the loop, and the staging pieces of the next stage sit in small
     // wave-uniform branches that contain no MFMA -- branches AROUND whole steps made the register allocator split
-    // accumulators into VGPRs and spill.  Staging rides on step 0 (loads), step 4 (LDS writes, + the loads of the
-    // second NCHW round) and step 7 (its writes).
+    // accumulators into VGPRs and spill.  Staging rides on step 4 (LDS writes of the next stage, + the loads of the
+    // second NCHW round), step 7 (its writes) and step 5 / 8 (the loads of the stage after that).
     auto kstep = [&](auto fc, int s, int step, uint32_t bufoff, bool more) {
         constexpr int F = decltype(fc)::value;
         const uint32_t cur = bufoff + tap_off(step), nxt = bufoff + tap_off(step + 1);
         const uint32_t nbufoff = bufb - bufoff;
         // the weights of eight steps ahead (the plan pads the copy: no tail test)
         fa[(F + 8) % 9] = *reinterpret_cast<const v4i *>(wsb + ((size_t)(s * NSTEP + step + 8)) * 1024 + wl);
-        const bool do_load = F == 0 && more && step == 0;
+        // the data of stage s + 1 was requested a whole stage ago (at step 5 / 8 of stage s - 1, or in the prologue):
+        // requested only four steps ahead, the LDS writes of step 4 waited ~3 000 cycles for HBM in every stage
+        const bool two = kNchw && a.pt_nitc > 1;
         const bool do_write0 = F == 4 && more && step == 4;
-        const bool do_write1 = kNchw && F == 7 && more && step == 7 && a.pt_nitc > 1;
+        const bool do_write1 = F == 7 && more && step == 7 && two;
+        const bool do_load = (two ? F == 8 && step == 8 : F == 5 && step == 5) && s + 2 < nstg;
         static_for<NB>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             // the last step of a stage reads "next" fragments nobody uses (one code path; LDS reads cannot fault)
@@ -384,10 +427,10 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             // its fourth piece): slots 0 .. 9 take one piece, slots 10 .. 12 two
             constexpr int P0 = j < 10 ? j : 10 + 2 * (j - 10);
             constexpr int P1 = j < 10 ? -1 : P0 + 1;
-            if constexpr (F == 0) {
+            if constexpr (F == 5 || (kNchw && F == 8)) {
                 if (do_load) {
-                    stage_load_one(s + 1, 0, std::integral_constant<int, P0>{});
-                    if constexpr (P1 >= 0) stage_load_one(s + 1, 0, std::integral_constant<int, P1>{});
+                    stage_load_one(s + 2, 0, std::integral_constant<int, P0>{});
+                    if constexpr (P1 >= 0) stage_load_one(s + 2, 0, std::integral_constant<int, P1>{});
                 }
             }
             if constexpr (F == 4) {
@@ -452,13 +495,22 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     uint32_t e_n = 0, e_rem = 0;
     if constexpr (kNchw) {
         const uint32_t m00 = (uint32_t)(pixbase + fhalf * 16);
-        e_n = m00 / (uint32_t)HW;
-        e_rem = m00 - e_n * HW;
+        e_n = pt_div(m00, HW, a.pt_rHW);
+        e_rem = m00 - m24(e_n, HW);
     }
+    char *e_ptr = out;  // NHWC: address of the lane's 16 channels of its pixel of block 0, advanced by 32 pixels per block
+    if constexpr (!kNchw) e_ptr = out + (int64_t)(pixbase + frow) * a.Co + (ocb * 32 + fhalf * 16);
+    const int64_t e_step = (int64_t)32 * a.Co;
     auto advance = [&]() {
         if constexpr (kNchw) {
             e_rem += 32;
-            while (e_rem >= (uint32_t)HW) e_rem -= HW, ++e_n;
+            if (HW >= 32) {  // wave-uniform: one image boundary at most
+                if (e_rem >= (uint32_t)HW) e_rem -= HW, ++e_n;
+            } else {
+                while (e_rem >= (uint32_t)HW) e_rem -= HW, ++e_n;
+            }
+        } else {
+            e_ptr += e_step;
         }
     };
     auto finalize = [&](int j, const v16i &c) {
@@ -475,43 +527,45 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             const int pl = j * 32 + frow;
             const int m = pixbase + pl;
             const int oc = ocb * 32 + fhalf * 16;
-            if (ocb_ok && pl < RW && m < a.M && oc < a.Co) *reinterpret_cast<uint4 *>(out + (int64_t)m * a.Co + oc) = v;
+            if (ocb_ok && pl < RW && m < a.M && oc < a.Co) *reinterpret_cast<uint4 *>(e_ptr) = v;
         } else {
             const int oc = ocb * 32 + frow;
             const int pl0 = j * 32 + fhalf * 16;
             const int m0 = pixbase + pl0;
             if (!ocb_ok || oc >= a.Co || pl0 >= RW || m0 >= a.M) return;
-            char *dst = out + ((int64_t)e_n * a.Co + oc) * HW + e_rem;
+            char *dst = out + ((int64_t)(m24(e_n, a.Co) + oc) * HW + e_rem);
             const bool full = pl0 + 16 <= RW && m0 + 16 <= a.M;
             const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-            if (full && e_rem + 16 <= (uint32_t)HW) {  // 16 pixels of one plane: one store at whatever byte address
+            if (full && e_rem + 16 <= (uint32_t)HW) {  // 16 pixels of one plane
                 const pt_u4 t4 = {v.x, v.y, v.z, v.w};
                 *reinterpret_cast<pt_u4 *>(dst) = t4;
             } else if (full && HW >= 16) {
                 // the run crosses into the next image once (planes of 49 or 196 bytes): dwords that lie inside one piece
-                // go out whole, the one that straddles the boundary byte by byte
-                const int len1 = HW - (int)e_rem;                      // bytes that still belong to image n
+                // go out whole (at whatever byte address), the one that straddles the boundary byte by byte.  Kept small
+                // on purpose: this code sits in every one of the thirteen unrolled blocks
+                const int len1 = HW - (int)e_rem;                        // bytes that still belong to image n
                 char *dst2 = dst + (int64_t)(a.Co - 1) * HW;             // = plane (n + 1, oc) - len1: byte b >= len1 goes to dst2 + b
                 typedef uint32_t u1_a1 __attribute__((aligned(1)));
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    if (4 * d + 4 <= len1) {
-                        *reinterpret_cast<u1_a1 *>(dst + 4 * d) = w4[d];
-                    } else if (4 * d >= len1) {
-                        *reinterpret_cast<u1_a1 *>(dst2 + 4 * d) = w4[d];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            char *p = 4 * d + e < len1 ? dst + 4 * d + e : dst2 + 4 * d + e;
-                            *p = (char)(w4[d] >> (8 * e));
-                        }
+                    char *p = 4 * d >= len1 ? dst2 : dst;
+                    if (4 * d + 4 <= len1 || 4 * d >= len1) *reinterpret_cast<u1_a1 *>(p + 4 * d) = w4[d];
+                }
+                if (len1 & 3) {
+                    const int d = len1 >> 2;
+                    const uint32_t w = d == 0 ? w4[0] : d == 1 ? w4[1] : d == 2 ? w4[2] : w4[3];
+#pragma unroll 1
+                    for (int e = 0; e < 4; ++e) {
+                        char *p = 4 * d + e < len1 ? dst : dst2;
+                        p[4 * d + e] = (char)(w >> (8 * e));
                     }
                 }
             } else {
                 uint32_t r2 = e_rem;
-#pragma unroll
+#pragma unroll 1
                 for (int e = 0; e < 16; ++e) {
-                    if (pl0 + e < RW && m0 + e < a.M) *dst = (char)(w4[e >> 2] >> (8 * (e & 3)));
+                    const uint32_t w = (e >> 2) == 0 ? w4[0] : (e >> 2) == 1 ? w4[1] : (e >> 2) == 2 ? w4[2] : w4[3];
+                    if (pl0 + e < RW && m0 + e < a.M) *dst = (char)(w >> (8 * (e & 3)));
                     ++dst;
                     if (++r2 == (uint32_t)HW) {  // next image: same channel plane, Co planes further
                         r2 = 0;
@@ -576,6 +630,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         });
     }
     mark();  // last: epilogue done
+    if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // =================================================================================================== host side
@@ -602,7 +657,7 @@ bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchS
     const int kc = PT_KC(geom), pg = PT_PG(geom), ob = PT_OB(geom), kp = PT_KP(geom);
     if (!kc || C % kc != 0) return false;
     const int64_t total_rows = (int64_t)n * H;
-    if (total_rows + n >= (1 << 22) || (int64_t)n * H * W >= (1ll << 31) - 4096) return false;
+    if (total_rows + n >= (1 << 22) || (int64_t)n * H * W >= (1 << 24) || (int64_t)n * C >= (1 << 24)) return false;  // 24-bit multiplies
     if ((int64_t)n * H * W * C >= (1ll << 31) - 65536) return false;  // 32-bit source offsets
     int rows = PT_PIX / W;
     if ((int64_t)rows * pg > total_rows) rows = (int)((total_rows + pg - 1) / pg);
@@ -731,6 +786,12 @@ bool patch_setup(ConvArgs &a)
     a.pt_nitc = ps.nitc;
     a.pt_spr = ps.spr;
     a.pt_ntm = ps.nt_m;
+    a.pt_rW = 1.0f / (float)a.W;
+    a.pt_rH = 1.0f / (float)a.H;
+    a.pt_rH1 = 1.0f / (float)(a.H + 1);
+    a.pt_rspr = 1.0f / (float)ps.spr;
+    a.pt_rntn = 1.0f / (float)ps.nt_n;
+    a.pt_rHW = 1.0f / (float)(a.H * a.W);
     return true;
 }
 
@@ -744,7 +805,12 @@ bool patch_auto(const ConvArgs &a)
     if (!patch_setup(t)) return false;
     PatchShape ps;
     patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
-    return (int64_t)ps.nt_m * ps.nt_n >= 96;  // fewer tiles than that: the latency-oriented kernels
+    if ((int64_t)ps.nt_m * ps.nt_n < 96) return false;  // fewer tiles than that: the latency-oriented kernels
+    // NHWC with four K parts (512 channels @7 at batch 128): nine K steps per stage and the exchange of partial sums
+    // leave it behind the producer / consumer kernel (25.4 vs 22.4 us); NCHW takes it anyway -- the alternative there
+    // is two re-layout passes around that kernel (39 vs 47 us)
+    if (!a.in_nchw && PT_KP(a.pt_geom) == 4) return false;
+    return true;
 }
 
 template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
@@ -776,8 +842,9 @@ static void patch_launch_geom(const ConvArgs &a, unsigned tiles, size_t lds, hip
 
 int patch_read_trace(unsigned long long *host, int count)
 {
-    if (count > 64) count = 64;
-    SHL_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pt_trace), (size_t)count * 8));
+    const int n0 = count > 64 ? 64 : count;
+    SHL_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pt_trace), (size_t)n0 * 8));
+    if (count >= 64 + 2048) SHL_HIP(hipMemcpyFromSymbol(host + 64, HIP_SYMBOL(g_pt_span), (size_t)2048 * 8));
     return SHL_MI355X_OK;
 }
 

@@ -82,7 +82,10 @@ def _run_variant(variant):
     env["SHL_EXPECT_KERNEL"] = expect
     if expect in ("pp", "pc"):
         env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "30"
-XX
+    if expect == "res":
+        env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "16"
+    if expect == "patch":
+        env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "8" if extra.get("SHL_MI355X_PATCH") == "1,1,4" else "24"
     return subprocess.run([sys.executable, "-m", "pytest", SUITE, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
                           capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
 

@@ -1,0 +1,4 @@
+export SHL_MI355X_IGEMM=patch SHL_MI355X_DEBUG=36
+for lay in NHWC NCHW; do for l in 4 14; do python tools/pp_trace.py --patch --layer $l --layout $lay 2>&1 | grep "epilogue\|total\|workgroups:"; done; done
+export SHL_MI355X_IGEMM=patch SHL_MI355X_DEBUG=32
+for lay in NHWC NCHW; do for l in 4 14; do python tools/pp_trace.py --patch --layer $l --layout $lay 2>&1 | grep "epilogue\|total\|workgroups:"; done; done

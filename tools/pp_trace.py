@@ -39,15 +39,16 @@ def main():
     for _ in range(3):
         chain.run_layer(0)
     hip.shl_mi355x_stream_sync(None)
-    buf = (C.c_uint64 * 1024)()
-    pkg.check(hip.shl_mi355x_debug_trace(buf, 1024), hip, "debug_trace")
+    nbuf = 64 + 2048 if a.patch else 1024
+    buf = (C.c_uint64 * nbuf)()
+    pkg.check(hip.shl_mi355x_debug_trace(buf, nbuf), hip, "debug_trace")
     t = np.array(buf[:], dtype=np.uint64).astype(np.int64)
     print(wl.layer_name(chain.entries[0]["layer"]), chain.entries[0]["kernel_name"])
     if a.patch:
         # stamps: start | items | padding | pixel offsets | stage 0 written | barrier | per stage: steps done, barrier | end
         n = int((t[:64] != 0).sum())
         d = np.diff(t[:n])
-        names = ["staging items", "padding", "pixel offsets", "stage-0 wait+write", "barrier"]
+        names = ["tile decode", "weight loads issued", "row tables", "barrier", "staging items", "padding", "pixel offsets", "stage-0 wait+write", "barrier"]
         k = 0
         for nm in names:
             print("  %-22s %7d" % (nm, d[k])); k += 1
@@ -56,6 +57,16 @@ def main():
             print("  stage %d steps %7d  barrier %6d" % (st, d[k], d[k + 1])); k += 2; st += 1
         print("  %-22s %7d" % ("epilogue", d[-1]))
         print("  total %d ticks" % (t[n - 1] - t[0]))
+        sp = t[64:64 + 2048].reshape(-1, 2)
+        sp = sp[sp[:, 1] != 0]
+        if len(sp):
+            t0 = sp[:, 0].min()
+            st, en = (sp[:, 0] - t0) * 10, (sp[:, 1] - t0) * 10  # ns (100 MHz counter)
+            du = en - st
+            print("  %d workgroups: start skew max %d ns; duration min / median / max %d / %d / %d ns; last end %d ns" %
+                  (len(sp), st.max(), du.min(), np.median(du), du.max(), en.max()))
+            order = np.argsort(du)
+            print("  slowest workgroups:", [(int(i), int(du[i])) for i in order[-6:]], " fastest:", [(int(i), int(du[i])) for i in order[:4]])
         return
     if a.res:
         # stamps: start | prologue requests | first wait | then per period: barrier passed, and either
