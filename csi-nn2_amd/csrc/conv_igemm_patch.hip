@@ -33,6 +33,7 @@
 //
 // Replaces shl_ref_conv2d_nhwc_f32 / shl_ref_conv2d_nchw_f32 + conv_im2col_sgemm_avx
 // (source/reference/convolution.c:28-139, conv_avx.h:109-1008) inside shl_ref_conv2d_quant (:370-400).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -55,6 +56,7 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 #define PT_PG(g) (((g) >> 8) & 0xf)
 #define PT_OB(g) (((g) >> 12) & 0xf)
 #define PT_KP(g) (((g) >> 16) & 0xf)
+#define PT_NW8(g) (((g) >> 20) & 1)  // eight waves (two per SIMD) instead of four
 
 // x / d for x < 2^22 (q is within one of the quotient after the float multiply)
 __device__ __forceinline__ uint32_t pt_div(uint32_t x, uint32_t d, float rcp)
@@ -83,8 +85,12 @@ typedef uint32_t pt_u4 __attribute__((ext_vector_type(4), aligned(1)));  // 16 b
 __device__ unsigned long long g_pt_trace[64];
 __device__ unsigned long long g_pt_span[2 * 1024];  // SHL_MI355X_DEBUG=32: [start, end] of wave 0 of every workgroup (s_memrealtime, 100 MHz)
 
-template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
-__global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
+// NW = 4: four waves of 13 pixel blocks, one per SIMD.  NW = 8: two waves per SIMD, the 13 blocks of a (pixel group,
+// channel block, K part) split 7 + 6 between them (half h; NBW = this wave's blocks): the prologue and the epilogue are
+// long dependent scalar / VALU chains that a wave alone on its SIMD runs at ~6 cycles per instruction, and they are
+// half as long per wave and interleave with the partner's.  At most 256 registers per wave then: 7 x 16 accumulators.
+template <int EPI, bool kNchw, int KC, int PG, int OB, int KP, int NW, int NBW>
+__device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, const int h)
 {
     int trace_k = 0;
     auto mark = [&]() {
@@ -92,19 +98,27 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     };
     mark();
     if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-    static_assert(PG * OB * KP == 4, "four waves");
-    constexpr int NB = PT_NB, D = PT_D;
+    static_assert(PG * OB * KP == 4, "four wave roles");
+    static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
+    constexpr int NB = NBW;                  // MFMA pixel blocks of this wave
+    constexpr int HB = NW == 8 ? 7 : 0;      // blocks of half 0 in front of half 1's
+    constexpr int D = NB >= 13 ? PT_D : 4;   // B fragments are read this many MFMAs ahead
+    constexpr int NT = NW * 64;              // threads
+    constexpr int NIT = PT_NIT * 4 / NW;     // NHWC staging items per lane and stage
+    constexpr int CI = NW == 8 ? 8 : 16;     // NCHW staging: channels per item
+    constexpr int NP = kNchw ? CI : NIT;     // staging pieces per round (loads, and again writes)
+    constexpr bool kTwo = kNchw && NW == 4;  // NCHW staging may take a second round of items (eight waves: the host
+                                             // falls back to four when one round does not cover a stage)
+    constexpr int FR = (NW == 8 && kNchw) ? 3 : 9;  // weight fragment ring (256 registers per wave: NCHW staging needs the rest)
     constexpr int U = KC / 32;          // 32-byte K sub-steps per tap and stage
     constexpr int UI = U / KP;          // ... of which this wave takes every KP-th
     constexpr int NSTEP = 9 * UI;       // K steps (13 MFMAs each) per stage and wave
     constexpr int NF = NSTEP * NB;      // MFMAs per stage and wave
     constexpr int PITCH = KC + 16;
     constexpr int SLOTS = KC / 16;
-    constexpr int CG = KC / 16;         // 16-channel groups per stage (NCHW staging)
+    constexpr int CG = KC / CI;         // channel groups per stage (NCHW staging)
     static_assert(U % KP == 0, "K parts split the sub-steps of a tap");
     static_assert(NSTEP % 9 == 0, "weight fragment ring of nine");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
     // every kernel argument the kernel will ever read, requested NOW in one batch: left to the compiler the scalar
     // loads are sunk to their first uses, and each of the half dozen groups then costs its own 500 - 1 000 cycles of
     // argument-segment latency in a prologue that nothing overlaps
@@ -117,7 +131,9 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
 #undef PT_PIN
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 31, fhalf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kp = wave % KP, ob = (wave / KP) % OB, pg = wave / (KP * OB);
+    const int wv = NW == 8 ? wave >> 1 : wave;  // role: (pixel group, channel block, K part)
+    const int kp = wv % KP, ob = (wv / KP) % OB, pg = wv / (KP * OB);
+    const int hb = h * HB;                      // first pixel block of this wave inside the pixel group
     const int W = a.W, H = a.H, W1 = W + 1, H1 = H + 1, HW = H * W;
     const int R = a.pt_rows, TR = PG * R, RW = R * W;
     const int total_rows = a.N * H;
@@ -147,9 +163,9 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     // staging loads (HBM latency) or behind a first touch of the weights is late by that much
     const char *wsb = static_cast<const char *>(a.w_patch) + ((size_t)(ocb * KP + kp) * nstg * NSTEP) * 1024;
     const int wl = lane * 16;
-    v4i fa[9];
+    v4i fa[FR];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) fa[q] = *reinterpret_cast<const v4i *>(wsb + q * 1024 + wl);
+    for (int q = 0; q < FR - 1; ++q) fa[q] = *reinterpret_cast<const v4i *>(wsb + q * 1024 + wl);
 
     mark();  // 2: weight loads issued
     // ---- row tables in LDS (one division per ROW instead of two per staging item and pixel block):
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     uint16_t *const inv_tab = reinterpret_cast<uint16_t *>(smem + 2 * bufb + PT_TRASH + 3072);     // <= 256 rows
     int32_t *const inv_cnt = reinterpret_cast<int32_t *>(smem + 2 * bufb + PT_TRASH + 3584);
     // epilogue tables of the four waves (written after the row tables are dead): 32 multipliers + 32 biases each
-    float *const epi_tab = reinterpret_cast<float *>(smem + 2 * bufb + PT_TRASH) + wave * 96;
+    float *const epi_tab = reinterpret_cast<float *>(smem + 2 * bufb + PT_TRASH) + wv * 96;
     // requested now, used at the very end
     const float t_mult = a.mult[ocb * 32 + frow], t_bias = a.bias[ocb * 32 + frow];
     const int32_t t_acc = a.acc_init[ocb * 32 + frow];
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         }
         if (lane == 0) *inv_cnt = ninv;
     } else {
-        for (int r = tid - 64; r < TR; r += 192) {
+        for (int r = tid - 64; r < TR; r += NT - 64) {
             const uint32_t g = (uint32_t)row0 + r;
             trow_tab[r] = (uint16_t)(g + pt_div(g, H, rH) - (uint32_t)v0);
         }
@@ -191,47 +207,51 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
 
     // ---- staging items of this lane (the same for every stage) -------------------------------------------
     // NHWC: item = (patch pixel, 16-byte slot); NCHW: item = (image run, 16-channel group, 16-pixel segment)
-    constexpr int NSRC = kNchw ? 2 : PT_NIT;
-    constexpr int NDST = kNchw ? 32 : PT_NIT;
+    constexpr int NSRC = kNchw ? (kTwo ? 2 : 1) : NIT;
+    constexpr int NDST = kNchw ? (kTwo ? 32 : 16) : NIT;
     uint32_t s_src[NSRC], s_dst[NDST];
     const uint32_t trash = 2 * bufb + lane * 16 + (wave & 3) * 1024;
     if constexpr (!kNchw) {
-        constexpr int PS = 256 / SLOTS;  // pixels between a lane's consecutive items
+        constexpr int PS = NT / SLOTS;  // pixels between a lane's consecutive items
         const uint32_t slot = tid % SLOTS;
         uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - m24(pr, W);
         const uint32_t dpr = pt_div(PS, W, rW), dx = PS - m24(dpr, W);
         const uint32_t last = (uint32_t)a.pt_prows - 1;
         // all sixteen table reads first (one LDS round trip instead of sixteen), no branches: rows past the patch read
         // the table's last entry and are dropped by the comparison
-        int32_t row[PT_NIT];
-        uint32_t prs[PT_NIT], xs[PT_NIT];
+        int32_t row[NIT];
+        uint32_t prs[NIT], xs[NIT];
 #pragma unroll
-        for (int it = 0; it < PT_NIT; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             prs[it] = pr, xs[it] = x;
             row[it] = prow_tab[pr < last ? pr : last];
             x += dx, pr += dpr;
             if (x >= (uint32_t)W) x -= W, ++pr;
         }
 #pragma unroll
-        for (int it = 0; it < PT_NIT; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const bool ok = row[it] >= 0 && prs[it] <= last;
             s_src[it] = ok ? (uint32_t)row[it] + m24(xs[it], a.C) + slot * 16 : 0;
             s_dst[it] = ok ? m24(m24(prs[it], W1) + xs[it] + 1, PITCH) + slot * 16 : trash;
         }
     } else {
-        const uint32_t nf = v0 < 0 ? 0 : pt_div((uint32_t)v0, H1, rH1);  // first image the patch touches
+        // first image with rows in the patch: virtual row v0 is image v0 / (H + 1)'s -- unless it is that image's
+        // padding row, then the next one's
+        const uint32_t nf = pt_div((uint32_t)(v0 + 1), H1, rH1);
         const uint32_t spr = (uint32_t)a.pt_spr;
         const float rspr = a.pt_rspr;
         const int total = a.N * a.C * HW;  // < 2^31 (checked on the host)
+        if constexpr (kTwo) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s_dst[16 + q] = trash;
-        s_src[1] = 0;
+            for (int q = 0; q < 16; ++q) s_dst[16 + q] = trash;
+            s_src[1] = 0;
+        }
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < (kTwo ? 2 : 1); ++it) {
             if (it == 1 && a.pt_nitc < 2) break;  // wave-uniform: the second round exists for few shapes only
             // consecutive lanes = consecutive 16-byte segments of one channel's run: a wave-level load touches a few
             // whole lines (with the channel group fastest every lane had a line of its own: 350 cycles per instruction)
-            const uint32_t item = it * 256 + tid;
+            const uint32_t item = it * NT + tid;
             const uint32_t rest = pt_div(item, spr, rspr), seg = item - rest * spr;
             const uint32_t cg = rest % CG, run = rest / CG;
             const uint32_t n = nf + run;
@@ -244,8 +264,8 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             // byte offset of (image n, channel cg * 16, row ya, pixel k0) in the NCHW tensor; the window of the LAST
             // channel of the LAST stage must end inside the tensor: slide the window back (its first bytes then
             // belong to pixels in front of the segment and are dropped)
-            int off = (int)m24(m24(n, a.C) + cg * 16, HW) + (int)m24(ya, W) + k0;
-            const int over = run_ok ? off + (a.C - KC + 15) * HW + 16 - total : 0;
+            int off = (int)m24(m24(n, a.C) + cg * CI, HW) + (int)m24(ya, W) + k0;
+            const int over = run_ok ? off + (a.C - KC + CI - 1) * HW + 16 - total : 0;
             if (over > 0) {
                 off -= over;
                 k0 -= over;
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             for (int b = 0; b < 16; ++b) {
                 const int k = k0 + b;
                 const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
-                s_dst[it * 16 + b] = ok ? m24(m24(pr0 + yy, W1) + x + 1, PITCH) + cg * 16 : trash;
+                s_dst[it * 16 + b] = ok ? m24(m24(pr0 + yy, W1) + x + 1, PITCH) + cg * CI : trash;
                 if (k >= 0) {
                     if (++x == (uint32_t)W) x = 0, ++yy;
                 }
@@ -268,20 +288,20 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         }
     }
 
-    // ---- staging of one stage, cut into sixteen pieces so that the K loop can place one piece per MFMA slot:
-    // NHWC sd[q] = item q's 16 bytes; NCHW sd[c] = 16 pixels of channel c of the lane's 16-channel group
-    v4i sd[16];
+    // ---- staging of one stage, cut into NP pieces so that the K loop can place them one per MFMA slot:
+    // NHWC sd[q] = item q's 16 bytes; NCHW sd[c] = 16 pixels of channel c of the lane's channel group
+    v4i sd[NP];
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.in), 0, 0x7fffffff, 0x00020000);
-    uint32_t tr_o[4][4];  // NCHW: the four pixels of one dword column, transposed
+    uint32_t tr_o[4][CI / 4];  // NCHW: the four pixels of one dword column, transposed
     auto stage_load_one = [&](int stage, int it, auto qc) {
         constexpr int q = decltype(qc)::value;
         // NHWC: buffer loads (descriptor + 32-bit lane offset + scalar stage offset): as plain global loads the
-        // optimiser turns the sixteen loop-invariant lane offsets into 64-bit pointers held across the K loop
+        // optimiser turns the loop-invariant lane offsets into 64-bit pointers held across the K loop
         if constexpr (!kNchw) {
             sd[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)s_src[q], stage * KC, 0));
         } else {
             const char *base = static_cast<const char *>(a.in) + (size_t)stage * KC * HW;
-            const uint32_t o = it == 0 ? s_src[0] : s_src[1];
+            const uint32_t o = (!kTwo || it == 0) ? s_src[0] : s_src[NSRC - 1];
             sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * HW))));
         }
     };
@@ -291,28 +311,34 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
             const uint32_t d = s_dst[q];
             *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = sd[q];
         } else {
-            // piece q = (dword column jd = q / 4, channel quad ca = q % 4): one 4 x 4 byte block of the 16 channels x
-            // 16 pixels -> 16 pixels x 16 channels transposition; after the fourth quad the column's four pixels go out
-            constexpr int jd = q / 4, ca = q % 4;
+            // piece q = (dword column jd, channel quad ca): one 4 x 4 byte block of the CI channels x 16 pixels ->
+            // 16 pixels x CI channels transposition; after the last quad the column's four pixels go out
+            constexpr int QC = CI / 4;
+            constexpr int jd = q / QC, ca = q % QC;
             const uint32_t in4[4] = {(uint32_t)sd[4 * ca + 0][jd], (uint32_t)sd[4 * ca + 1][jd], (uint32_t)sd[4 * ca + 2][jd],
                                      (uint32_t)sd[4 * ca + 3][jd]};
             uint32_t out4[4];
             transpose4x4_bytes(in4, out4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) tr_o[e][ca] = out4[e];
-            if constexpr (ca == 3) {
+            if constexpr (ca == QC - 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const uint32_t d = it == 0 ? s_dst[4 * jd + e] : s_dst[16 + 4 * jd + e];
-                    const v4i v = {(int)tr_o[e][0], (int)tr_o[e][1], (int)tr_o[e][2], (int)tr_o[e][3]};
-                    *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = v;
+                    const uint32_t d = (!kTwo || it == 0) ? s_dst[4 * jd + e] : s_dst[NDST - 16 + 4 * jd + e];
+                    char *dp = smem + (d >= 2 * bufb ? d : d + bufoff);
+                    if constexpr (CI == 16) {
+                        const v4i v = {(int)tr_o[e][0], (int)tr_o[e][1], (int)tr_o[e][2], (int)tr_o[e][3]};
+                        *reinterpret_cast<v4i *>(dp) = v;
+                    } else {
+                        *reinterpret_cast<uint2 *>(dp) = make_uint2(tr_o[e][0], tr_o[e][1]);
+                    }
                 }
             }
         }
     };
 
     mark();  // 5: staging items computed
-    static_for<16>([&](auto qc) { stage_load_one(0, 0, qc); });
+    static_for<NP>([&](auto qc) { stage_load_one(0, 0, qc); });
 
     // ---- padding: column 0 of every patch row (= right padding of the row before) and the rows outside an image get
     // the input zero point, in both buffers, once (staging never writes there).  One 16-byte write per unit =
@@ -323,14 +349,14 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         const v4i zv = {(int)zp4, (int)zp4, (int)zp4, (int)zp4};
         constexpr int S2 = 2 * SLOTS;
         const uint32_t n0 = ((uint32_t)a.pt_prows + 1) * S2;
-        for (uint32_t u = tid; u < n0; u += 256) {
+        for (uint32_t u = tid; u < n0; u += NT) {
             const uint32_t pr = u / S2, sb = u % S2;
             *reinterpret_cast<v4i *>(smem + (sb / SLOTS ? bufb : 0u) + m24(m24(pr, W1), PITCH) + (sb % SLOTS) * 16) = zv;
         }
         const uint32_t per_row = (uint32_t)W * S2;
         const uint32_t n1 = (uint32_t)*inv_cnt * per_row;
         const float rper = a.pt_rW * (1.0f / S2);  // exact: S2 is a power of two
-        for (uint32_t u = tid; u < n1; u += 256) {
+        for (uint32_t u = tid; u < n1; u += NT) {
             const uint32_t i = pt_div(u, per_row, rper), r2 = u - m24(i, per_row);
             const uint32_t x = r2 / S2, sb = r2 % S2;
             const uint32_t q = m24(inv_tab[i], W1) + x + 1;
@@ -342,12 +368,13 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     // ---- this lane's pixel of each MFMA block: LDS offset of patch pixel (row - 1, x - 1), i.e. of tap (0, 0)
     uint32_t pbase[NB];
     {
-        uint32_t r = pt_div(frow, W, rW), x = frow - m24(r, W);
+        const uint32_t p0 = (uint32_t)(hb * 32 + frow);
+        uint32_t r = pt_div(p0, W, rW), x = p0 - m24(r, W);
         const uint32_t d32r = pt_div(32, W, rW), d32x = 32 - m24(d32r, W);
         uint32_t prow[NB], xs[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {  // thirteen table reads, then the arithmetic
-            const bool ok = (uint32_t)(j * 32 + frow) < (uint32_t)RW && row0 + pg * R + (int)r < total_rows;
+            const bool ok = (uint32_t)((hb + j) * 32 + frow) < (uint32_t)RW && row0 + pg * R + (int)r < total_rows;
             prow[j] = trow_tab[ok ? pg * R + r : 0];  // patch row of the pixel's own input row (>= 1)
             xs[j] = ok ? x : 0;
             x += d32x, r += d32r;
@@ -371,20 +398,22 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     }
 
     mark();  // 7: pixel offsets computed
-    static_for<16>([&](auto qc) { stage_write_one(0, 0, qc); });
-    if constexpr (kNchw) {
+    static_for<NP>([&](auto qc) { stage_write_one(0, 0, qc); });
+    if constexpr (kTwo) {
         if (a.pt_nitc > 1) {
-            static_for<16>([&](auto qc) { stage_load_one(0, 1, qc); });
-            static_for<16>([&](auto qc) { stage_write_one(0, 1, qc); });
+            static_for<NP>([&](auto qc) { stage_load_one(0, 1, qc); });
+            static_for<NP>([&](auto qc) { stage_write_one(0, 1, qc); });
         }
     }
-    if (nstg > 1) static_for<16>([&](auto qc) { stage_load_one(1, 0, qc); });  // stage 1: written at step 4 of stage 0
+    if (nstg > 1) static_for<NP>([&](auto qc) { stage_load_one(1, 0, qc); });  // stage 1: written at step 4 of stage 0
     mark();  // 8: stage 0 written
     pt_barrier();
     mark();  // 9: barrier passed
-    if constexpr (!kNchw) {  // the row tables are dead: this wave's multipliers and biases take their place
-        if (fhalf == 0) epi_tab[frow] = t_mult, epi_tab[64 + frow] = __int_as_float(t_acc);
-        else epi_tab[32 + frow] = t_bias;
+    if constexpr (!kNchw) {  // the row tables are dead: this role's multipliers and biases take their place
+        if (h == 0) {
+            if (fhalf == 0) epi_tab[frow] = t_mult, epi_tab[64 + frow] = __int_as_float(t_acc);
+            else epi_tab[32 + frow] = t_bias;
+        }
     }
 
     // ---- K loop ----------------------------------------------------------------------------------------------
@@ -408,11 +437,11 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         constexpr int F = decltype(fc)::value;
         const uint32_t cur = bufoff + tap_off(step), nxt = bufoff + tap_off(step + 1);
         const uint32_t nbufoff = bufb - bufoff;
-        // the weights of eight steps ahead (the plan pads the copy: no tail test)
-        fa[(F + 8) % 9] = *reinterpret_cast<const v4i *>(wsb + ((size_t)(s * NSTEP + step + 8)) * 1024 + wl);
+        // the weights of FR - 1 steps ahead (the plan pads the copy: no tail test)
+        fa[(F + FR - 1) % FR] = *reinterpret_cast<const v4i *>(wsb + ((size_t)(s * NSTEP + step + FR - 1)) * 1024 + wl);
         // the data of stage s + 1 was requested a whole stage ago (at step 5 / 8 of stage s - 1, or in the prologue):
         // requested only four steps ahead, the LDS writes of step 4 waited ~3 000 cycles for HBM in every stage
-        const bool two = kNchw && a.pt_nitc > 1;
+        const bool two = kTwo && a.pt_nitc > 1;
         const bool do_write0 = F == 4 && more && step == 4;
         const bool do_write1 = F == 7 && more && step == 7 && two;
         const bool do_load = (two ? F == 8 && step == 8 : F == 5 && step == 5) && s + 2 < nstg;
@@ -423,11 +452,12 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
                 rb[j + D] = *reinterpret_cast<const v4i *>(smem + (pbase[j + D] + cur));
             else
                 rb[j + D - NB] = *reinterpret_cast<const v4i *>(smem + (pbase[j + D - NB] + nxt));
-            // sixteen staging pieces on thirteen slots, IN ORDER (the NCHW transposition finishes a dword column with
-            // its fourth piece): slots 0 .. 9 take one piece, slots 10 .. 12 two
-            constexpr int P0 = j < 10 ? j : 10 + 2 * (j - 10);
-            constexpr int P1 = j < 10 ? -1 : P0 + 1;
-            if constexpr (F == 5 || (kNchw && F == 8)) {
+            // the NP staging pieces on the NB slots, IN ORDER (the NCHW transposition finishes a dword column with its
+            // last channel quad): slot j takes pieces [j NP / NB, (j + 1) NP / NB)
+            constexpr int P0 = j * NP / NB;
+            constexpr int P1 = (j + 1) * NP / NB - P0 > 1 ? P0 + 1 : -1;
+            static_assert((j + 1) * NP / NB - P0 <= 2 && (j + 1) * NP / NB - P0 >= 1, "one or two pieces per slot");
+            if constexpr (F == 5 || (kTwo && F == 8)) {
                 if (do_load) {
                     stage_load_one(s + 2, 0, std::integral_constant<int, P0>{});
                     if constexpr (P1 >= 0) stage_load_one(s + 2, 0, std::integral_constant<int, P1>{});
@@ -439,20 +469,20 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
                     if constexpr (P1 >= 0) stage_write_one(nbufoff, 0, std::integral_constant<int, P1>{});
                 }
             }
-            if constexpr (kNchw && F == 7) {
+            if constexpr (kTwo && F == 7) {
                 if (do_write1) {
                     stage_write_one(nbufoff, 1, std::integral_constant<int, P0>{});
                     if constexpr (P1 >= 0) stage_write_one(nbufoff, 1, std::integral_constant<int, P1>{});
                 }
             }
             if constexpr (kNchw)
-                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[j], fa[F], acc[j], 0, 0, 0);  // rows = pixels
+                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[j], fa[F % FR], acc[j], 0, 0, 0);  // rows = pixels
             else
-                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[F], rb[j], acc[j], 0, 0, 0);  // rows = channels
+                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[F % FR], rb[j], acc[j], 0, 0, 0);  // rows = channels
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (kNchw && F == 4) {
-            if (do_write0 && a.pt_nitc > 1) static_for<16>([&](auto qc) { stage_load_one(s + 1, 1, qc); });
+        if constexpr (kTwo && F == 4) {
+            if (do_write0 && a.pt_nitc > 1) static_for<NP>([&](auto qc) { stage_load_one(s + 1, 1, qc); });
         }
     };
     for (int s = 0; s < nstg; ++s) {
@@ -494,12 +524,12 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     // advanced by 32 pixels per block
     uint32_t e_n = 0, e_rem = 0;
     if constexpr (kNchw) {
-        const uint32_t m00 = (uint32_t)(pixbase + fhalf * 16);
+        const uint32_t m00 = (uint32_t)(pixbase + hb * 32 + fhalf * 16);
         e_n = pt_div(m00, HW, a.pt_rHW);
         e_rem = m00 - m24(e_n, HW);
     }
     char *e_ptr = out;  // NHWC: address of the lane's 16 channels of its pixel of block 0, advanced by 32 pixels per block
-    if constexpr (!kNchw) e_ptr = out + (int64_t)(pixbase + frow) * a.Co + (ocb * 32 + fhalf * 16);
+    if constexpr (!kNchw) e_ptr = out + (int64_t)(pixbase + hb * 32 + frow) * a.Co + (ocb * 32 + fhalf * 16);
     const int64_t e_step = (int64_t)32 * a.Co;
     auto advance = [&]() {
         if constexpr (kNchw) {
@@ -524,13 +554,13 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         const uint4 v = tile_channels_16(pk);  // 16 consecutive rows 16 fhalf .. + 15 of the lane's column
         if (a.debug & 2) return;
         if constexpr (!kNchw) {
-            const int pl = j * 32 + frow;
+            const int pl = (hb + j) * 32 + frow;
             const int m = pixbase + pl;
             const int oc = ocb * 32 + fhalf * 16;
             if (ocb_ok && pl < RW && m < a.M && oc < a.Co) *reinterpret_cast<uint4 *>(e_ptr) = v;
         } else {
             const int oc = ocb * 32 + frow;
-            const int pl0 = j * 32 + fhalf * 16;
+            const int pl0 = (hb + j) * 32 + fhalf * 16;
             const int m0 = pixbase + pl0;
             if (!ocb_ok || oc >= a.Co || pl0 >= RW || m0 >= a.M) return;
             char *dst = out + ((int64_t)(m24(e_n, a.Co) + oc) * HW + e_rem);
@@ -587,12 +617,17 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
         }
     } else {
         // K parts: block j is finished by the wave with kp == j % KP; the others hand their partial sums over
-        // through LDS (exact int32 adds), eight blocks per round (8 x 4 KiB per wave)
-        static_assert(4 * 8 * 4096 <= PT_LDS_MAX, "exchange area");
-        char *const mine = smem + wave * (8 * 4096);
+        // through LDS (exact int32 adds), CH blocks per round (CH x 4 KiB per wave, 128 KiB in all)
+        constexpr int CH = NW == 8 ? 4 : 8;
+        static_assert(NW * CH * 4096 <= 128 * 1024, "exchange area");
+        char *const mine = smem + wave * (CH * 4096);
+        // small patches: the epilogue tables (behind the two buffers) lie inside the exchange area -- every wave has
+        // read its tables before anybody writes partial sums
+        if constexpr (!kNchw) pt_barrier();
         static_for<2>([&](auto rc) {
-            constexpr int rb = decltype(rc)::value * 8;
-            constexpr int re = rb + 8 < NB ? rb + 8 : NB;
+            constexpr int rb = decltype(rc)::value * CH;
+            constexpr int re = rb + CH < NB ? rb + CH : NB;
+            static_assert(2 * CH >= NB, "two rounds");
             static_for<re - rb>([&](auto jc) {
                 constexpr int j = rb + decltype(jc)::value;
                 if (j % KP != kp) {
@@ -610,8 +645,8 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
                     v16i c = acc[j];
 #pragma unroll
                     for (int o = 1; o < KP; ++o) {
-                        const int other = wave - kp + (kp + o) % KP;
-                        const char *src = smem + other * (8 * 4096) + (j - rb) * 4096 + lane * 16;
+                        const int other = wave + ((kp + o) % KP - kp) * (NW / 4);  // same role and half, another K part
+                        const char *src = smem + other * (CH * 4096) + (j - rb) * 4096 + lane * 16;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const v4i v = *reinterpret_cast<const v4i *>(src + g * 1024);
@@ -633,6 +668,22 @@ __global__ __launch_bounds__(256) void conv_igemm_patch_kernel(ConvArgs a)
     if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
+template <int EPI, bool kNchw, int KC, int PG, int OB, int KP, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_patch_kernel(ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (NW == 4) {
+        patch_body<EPI, kNchw, KC, PG, OB, KP, 4, PT_NB>(a, smem, 0);
+    } else {
+        // the two halves are two straight-line bodies (7 and 6 pixel blocks) behind ONE wave-uniform branch; both pass
+        // the same sequence of workgroup barriers
+        if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) == 0)
+            patch_body<EPI, kNchw, KC, PG, OB, KP, 8, 7>(a, smem, 0);
+        else
+            patch_body<EPI, kNchw, KC, PG, OB, KP, 8, 6>(a, smem, 1);
+    }
+}
+
 // =================================================================================================== host side
 bool patch_supports(const shl_mi355x_conv_desc &d)
 {
@@ -652,53 +703,86 @@ struct PatchShape {
 };
 
 // geometry of a forward pass with batch n; false when the patch does not fit LDS / the staging item budget
-bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchShape *ps)
+// shape for a given number of rows per pixel group: 1 fits, 0 too large for LDS / the staging item budget (try fewer
+// rows), -1 the NCHW item rounds do not fit (eight waves: retry with four)
+int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, int rows, PatchShape *ps)
 {
     const int kc = PT_KC(geom), pg = PT_PG(geom), ob = PT_OB(geom), kp = PT_KP(geom);
+    const int64_t total_rows = (int64_t)n * H;
+    const int pitch = kc + 16, slots = kc / 16;
+    const int tr = rows * pg;
+    const int nt_m = (int)((total_rows + tr - 1) / tr);
+    int prows = 0, runs = 0;
+    for (int tm = 0; tm < nt_m; ++tm) {  // exact capacity over the tiles of this batch
+        const int64_t r0 = (int64_t)tm * tr, rl = (r0 + tr < total_rows ? r0 + tr : total_rows) - 1;
+        const int64_t v0 = r0 + r0 / H - 1;
+        const int p = (int)(rl + rl / H - v0 + 2);
+        prows = p > prows ? p : prows;
+        const int64_t nf = (v0 + 1) / (H + 1), nl = (v0 + p - 1) / (H + 1);  // first / last image with rows in the patch
+        const int ru = (int)(nl - nf + 1);
+        runs = ru > runs ? ru : runs;
+    }
+    const int px = prows * (W + 1) + 1;
+    const int bufb = (px * pitch + 255) & ~255;
+    int lds = 2 * bufb + PT_TRASH + PT_TABLES;
+    if (prows > 512 || tr > 512 || runs > 250) return 0;  // row tables of the prologue
+    if (kp > 1 && lds < 4 * 8 * 4096) lds = 4 * 8 * 4096;
+    if (lds > PT_LDS_MAX) return 0;
+    if (!nchw && (int64_t)prows * W * slots > PT_NIT * 256) return 0;
+    int nitc = 1, spr = 1;
+    if (nchw) {
+        const int maxrun = (rows * pg + 2 < H ? rows * pg + 2 : H) * W;
+        spr = (maxrun + 15) / 16;
+        const int nw8 = PT_NW8(geom);
+        const int items = runs * spr * (kc / (nw8 ? 8 : 16));
+        nitc = (items + (nw8 ? 511 : 255)) / (nw8 ? 512 : 256);
+        if (nitc > (nw8 ? 1 : 2)) return -1;
+    }
+    ps->rows = rows, ps->prows = prows, ps->bufb = bufb, ps->lds = lds, ps->nt_m = nt_m;
+    ps->nt_n = (((Co + 31) / 32) + ob - 1) / ob;
+    ps->nitc = nitc, ps->spr = spr;
+    return 1;
+}
+
+// geometry of a forward pass with batch n; false when the patch does not fit LDS / the staging item budget
+bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchShape *ps)
+{
+    const int kc = PT_KC(geom), pg = PT_PG(geom);
     if (!kc || C % kc != 0) return false;
     const int64_t total_rows = (int64_t)n * H;
     if (total_rows + n >= (1 << 22) || (int64_t)n * H * W >= (1 << 24) || (int64_t)n * C >= (1 << 24)) return false;  // 24-bit multiplies
     if ((int64_t)n * H * W * C >= (1ll << 31) - 65536) return false;  // 32-bit source offsets
     int rows = PT_PIX / W;
     if ((int64_t)rows * pg > total_rows) rows = (int)((total_rows + pg - 1) / pg);
-    const int pitch = kc + 16, slots = kc / 16;
-    for (; rows >= 1; --rows) {
-        const int tr = rows * pg;
-        const int nt_m = (int)((total_rows + tr - 1) / tr);
-        int prows = 0, runs = 0;
-        for (int tm = 0; tm < nt_m; ++tm) {  // exact capacity over the tiles of this batch
-            const int64_t r0 = (int64_t)tm * tr, rl = (r0 + tr < total_rows ? r0 + tr : total_rows) - 1;
-            const int64_t v0 = r0 + r0 / H - 1;
-            const int p = (int)(rl + rl / H - v0 + 2);
-            prows = p > prows ? p : prows;
-            const int64_t nf = v0 < 0 ? 0 : v0 / (H + 1), nl = (v0 + p - 1) / (H + 1);
-            const int ru = (int)(nl - nf + 1);
-            runs = ru > runs ? ru : runs;
-        }
-        const int px = prows * (W + 1) + 1;
-        const int bufb = (px * pitch + 255) & ~255;
-        int lds = 2 * bufb + PT_TRASH + PT_TABLES;
-        if (prows > 512 || tr > 512 || runs > 250) continue;  // row tables of the prologue
-        if (kp > 1 && lds < 4 * 8 * 4096) lds = 4 * 8 * 4096;
-        if (lds > PT_LDS_MAX) continue;
-        if (!nchw && (int64_t)prows * W * slots > PT_NIT * 256) continue;
-        int nitc = 1, spr = 1;
-        if (nchw) {
-            const int maxrun = (rows * pg + 2 < H ? rows * pg + 2 : H) * W;
-            spr = (maxrun + 15) / 16;
-            const int items = runs * spr * (kc / 16);
-            nitc = (items + 255) / 256;
-            if (nitc > 2) continue;
-        }
-        ps->rows = rows, ps->prows = prows, ps->bufb = bufb, ps->lds = lds, ps->nt_m = nt_m;
-        ps->nt_n = (((Co + 31) / 32) + ob - 1) / ob;
-        ps->nitc = nitc, ps->spr = spr;
-        return true;
+    int top = 0;  // the most rows that fit
+    for (; rows >= 1 && !top; --rows) {
+        const int rc = patch_shape_rows(n, H, W, C, Co, nchw, geom, rows, ps);
+        if (rc == 1) top = rows;
     }
-    return false;
+    if (!top) return false;
+    // prefer tiles that start on image boundaries (whole images per tile, or a whole number of tiles per image) when
+    // that costs no extra round of tiles on the 256 CUs: fewer padding rows and NCHW runs (512 -> 512 @7: 56 rows = 8
+    // images instead of 57)
+    PatchShape best = *ps;
+    const int64_t rounds_top = ((int64_t)best.nt_m * best.nt_n + 255) / 256;
+    for (int r = top; r >= 1 && 8 * r >= 7 * top; --r) {
+        const int tr = r * pg;
+        if (tr % H != 0 && H % tr != 0) continue;
+        PatchShape t;
+        if (patch_shape_rows(n, H, W, C, Co, nchw, geom, r, &t) != 1) continue;
+        if (((int64_t)t.nt_m * t.nt_n + 255) / 256 <= rounds_top) best = t;
+        break;
+    }
+    *ps = best;
+    return true;
 }
 
-int make_geom(int kc, int pg, int ob, int kp) { return kc | pg << 8 | ob << 12 | kp << 16; }
+int make_geom(int kc, int pg, int ob, int kp)
+{
+    static const char *env = getenv("SHL_MI355X_PATCH_WAVES");  // "4": one wave per SIMD (A/B, tests)
+    const int nw8 = !(env && env[0] == '4');
+    return kc | pg << 8 | ob << 12 | kp << 16 | nw8 << 20;
+}
 
 }  // namespace
 
@@ -715,7 +799,8 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         int pg = 0, ob = 0, kp = 0;
         if (sscanf(env, "%d,%d,%d", &pg, &ob, &kp) == 3 && pg * ob * kp == 4 && u % kp == 0 && pg != 4 && !(pg == 2 && kp == 2)) {
             PatchShape ps;
-            const int g = make_geom(kc, pg, ob, kp);
+            int g = make_geom(kc, pg, ob, kp);
+            if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) g &= ~(1 << 20);  // four waves take two NCHW rounds
             return patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps) ? g : 0;
         }
     }
@@ -728,13 +813,19 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         if (u % kp != 0) continue;
         if (ob > 1 && ob / 2 >= ocblks) continue;  // half of the channel blocks of a tile would be empty
         PatchShape ps;
-        const int g = make_geom(kc, pg, ob, kp);
-        if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) continue;
+        int g = make_geom(kc, pg, ob, kp);
+        if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) {
+            g &= ~(1 << 20);  // four waves take two NCHW staging rounds
+            if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) continue;
+        }
         const int64_t tiles = (int64_t)ps.nt_m * ps.nt_n;
         const double rounds = (double)((tiles + 255) / 256);
         // per tile and wave: a K loop over K / kp for 13 pixel blocks + fixed costs (prologue, epilogue; the exchange
         // of partial sums for K parts)
         const double total = rounds * (1.0 / kp + 0.12 + (kp > 1 ? 0.04 : 0.0));
+        static const char *dbg = getenv("SHL_MI355X_DEBUG_GEOM");
+        if (dbg) fprintf(stderr, "patch geom %d,%d,%d nw%d: rows %d prows %d tiles %d x %d lds %d nitc %d cost %.3f\n", pg, ob, kp, PT_NW8(g) ? 8 : 4,
+                         ps.rows, ps.prows, ps.nt_m, ps.nt_n, ps.lds, ps.nitc, total);
         if (!best || total < best_cost - 1e-9) best = g, best_cost = total;
     }
     return best;
@@ -813,16 +904,23 @@ bool patch_auto(const ConvArgs &a)
     return true;
 }
 
-template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
-static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
+template <int EPI, bool kNchw, int KC, int PG, int OB, int KP, int NW>
+static void patch_launch_nw(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
-    auto kernel = conv_igemm_patch_kernel<EPI, kNchw, KC, PG, OB, KP>;
+    auto kernel = conv_igemm_patch_kernel<EPI, kNchw, KC, PG, OB, KP, NW>;
     static bool opted = false;
     if (!opted) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
         opted = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(NW * 64), lds, s, a);
+}
+
+template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
+static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
+{
+    if (PT_NW8(a.pt_geom)) patch_launch_nw<EPI, kNchw, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+    else patch_launch_nw<EPI, kNchw, KC, PG, OB, KP, 4>(a, tiles, lds, s);
 }
 
 template <int KC, int PG, int OB, int KP>
