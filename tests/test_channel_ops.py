@@ -95,7 +95,7 @@ def gpu():
     return fe, hip, opt, cases.HipDevice(hip)
 
 
-DEVICE_NAMES = [n for n in NAMES if n not in ("conv_kernel_zp", "dw_multiplier2")]
+DEVICE_NAMES = [n for n in NAMES if n != "conv_kernel_zp"]   # asymmetric weights on the float path are refused (below)
 
 
 @pytest.mark.gpu
@@ -128,6 +128,7 @@ def test_backend_random_cases_against_the_oracle(gpu):
             kw["co"] = int(rng.choice([8, 24, 64, 130]))
         else:
             kw["kernel_zp"] = bool(rng.random() < 0.5)
+            kw["multiplier"] = int(rng.choice([1, 1, 2, 3]))   # depth multipliers: the reference's kernel-index quirk on the device
         case = cases.make_channel_case(3000 + i, kind, **kw)
         kept = []
         got = cases.csinn_channel_run(fe, pkg.API_MI355X, case, device=dev if i % 3 else None, keep_params=kept)
@@ -135,6 +136,23 @@ def test_backend_random_cases_against_the_oracle(gpu):
             pass
         _compare(case, got, cases.oracle_channel_run(case), "random case %d %s %r" % (i, kind, kw))
         opt.shl_mi355x_release_params(kept[0][0])
+
+
+@pytest.mark.gpu
+def test_depthwise_channel_batch128_512_channels(gpu):
+    """65 536 planes (MobileNetV1's 512-channel depthwise layer at batch 128): more than a grid's y extent; sampled
+    images against the oracle, every image against the poison the output buffer is filled with"""
+    fe, hip, opt, dev = gpu
+    case = cases.make_channel_case(4242, "dw", c=512, h=14, w=14, n=128, act=1)
+    kept = []
+    got = cases.csinn_channel_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+    opt.shl_mi355x_release_params(kept[0][0])
+    for i in (0, 63, 127):
+        one = dict(case, n=1, input=np.ascontiguousarray(case["input"][i:i + 1]), in_shape=(1,) + tuple(case["in_shape"][1:]),
+                   out_shape=(1,) + tuple(case["out_shape"][1:]))
+        _compare(one, got[i:i + 1], cases.oracle_channel_run(one), "batch-128 depthwise image %d" % i)
+    flat = got.reshape(128, -1)
+    assert np.all(flat.max(axis=1) != flat.min(axis=1))
 
 
 @pytest.mark.gpu
