@@ -200,6 +200,7 @@ def load_hip():
         "shl_mi355x_conv_plan_kernel_name": (C.c_char_p, [vp]),
         "shl_mi355x_conv_plan_bytes": (sz, [vp]),
         "shl_mi355x_conv_plan_const_block": (vp, [vp, C.POINTER(sz)]),
+        "shl_mi355x_conv_plan_adopt_block": (C.c_int, [vp, vp]),
         "shl_mi355x_conv_forward": (C.c_int, [vp, vp, vp, i32, vp]),
         "shl_mi355x_dwpw_fusable": (C.c_int, [vp, vp, i32]),
         "shl_mi355x_dwpw_forward": (C.c_int, [vp, vp, vp, vp, i32, vp]),
@@ -309,6 +310,7 @@ def load_backend(frontend):
         opt.shl_mi355x_session_set_stream.restype = None
         opt.shl_mi355x_bcast_const_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                                       C.POINTER(Session)]
+        opt.shl_mi355x_params_adopt_blocks.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Session)]
         opt._typed = True
     # the dispatch tables exist after the first csinn_alloc_session (source/nn2/setup.c:77-84)
     s = frontend.csinn_alloc_session()

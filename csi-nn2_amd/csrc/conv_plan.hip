@@ -20,6 +20,7 @@ struct shl_mi355x_conv_plan {
     size_t off_w, off_acc, off_mult, off_bias, off_pad;
     size_t off_wfrag;  // 0: absent; pointwise int8 weights in MFMA fragment order (conv1x1_stream.hip)
     size_t off_wpatch; // 0: absent; 3x3 weights as the per-wave fragment streams of conv_igemm_patch.hip
+    size_t off_flags;  // 64-byte record of the plan's host-derived epilogue choices (PlanFlags): travels with a broadcast
     int32_t pt_geom;   // wave roles of that kernel, chosen for desc.batch (the packing depends on them)
     // int8 epilogue shortcuts (see ConvArgs)
     int32_t div_exact, div_fma, act_clamp;
@@ -37,6 +38,19 @@ struct shl_mi355x_conv_plan {
 };
 
 namespace shl {
+
+// What the host derived from the tables of the rank that packed the block and the kernels depend on.  Stored at the end
+// of the constant block so that a receiver of a weight broadcast adopts the ROOT's choices together with the root's
+// tables (a rank initialised with placeholder tables may have derived other ones): shl_mi355x_conv_plan_adopt_block.
+struct PlanFlags {
+    uint32_t magic;
+    int32_t div_exact, div_fma, act_clamp;
+    float clamp_lo, clamp_hi, inv_out_scale;
+    int32_t pt_geom;
+    uint32_t reserved[8];
+};
+static_assert(sizeof(PlanFlags) == 64, "flags record");
+constexpr uint32_t PLAN_FLAGS_MAGIC = 0x53484c46u;  // "SHLF"
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -317,6 +331,8 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         p->off_wpatch = align_up(p->block_bytes, 256);
         p->block_bytes = p->off_wpatch + patch_weight_bytes(d, p->pt_geom);
     }
+    p->off_flags = align_up(p->block_bytes, 256);
+    p->block_bytes = p->off_flags + sizeof(PlanFlags);
     p->inv_out_scale = 1.0f / d.out_scale;
     if (d.dtype == SHL_MI355X_I8) {
         p->div_exact = i8_div_exact;
@@ -333,6 +349,14 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     }
 
     std::vector<char> host(p->block_bytes, 0);
+    {
+        PlanFlags f = {};
+        f.magic = PLAN_FLAGS_MAGIC;
+        f.div_exact = p->div_exact, f.div_fma = p->div_fma, f.act_clamp = p->act_clamp;
+        f.clamp_lo = p->clamp_lo, f.clamp_hi = p->clamp_hi, f.inv_out_scale = p->inv_out_scale;
+        f.pt_geom = p->pt_geom;
+        memcpy(host.data() + p->off_flags, &f, sizeof(f));
+    }
     // padding value: the input zero point (int8) / 0.0 (f16)
     memset(host.data() + p->off_pad, d.dtype == SHL_MI355X_I8 ? (d.in_zp & 0xFF) : 0, PAD_PAGE_BYTES);
     if (kernel_host) {
@@ -545,6 +569,29 @@ void *shl_mi355x_conv_plan_const_block(shl_mi355x_conv_plan *plan, size_t *bytes
     if (!plan) return nullptr;
     if (bytes) *bytes = plan->block_bytes;
     return plan->block;
+}
+
+/* after the constant block was overwritten by a broadcast: take the sender's epilogue choices from its flags record */
+int shl_mi355x_conv_plan_adopt_block(shl_mi355x_conv_plan *plan, void *stream)
+{
+    if (!plan) return SHL_MI355X_EINVAL;
+    if (!plan->off_flags) return SHL_MI355X_OK;  // plans without a record (depthwise channel ids) carry no host-derived choices
+    PlanFlags f;
+    hipError_t e = hipMemcpyAsync(&f, plan->block + plan->off_flags, sizeof(f), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "read back the flags record");
+    if (f.magic != PLAN_FLAGS_MAGIC) {
+        set_error("conv_plan_adopt_block: the block carries no flags record (sender built from another library version?)");
+        return SHL_MI355X_EINVAL;
+    }
+    if ((f.pt_geom != 0) != (plan->off_wpatch != 0)) {
+        set_error("conv_plan_adopt_block: sender and receiver disagree about the row-patch weight copy");
+        return SHL_MI355X_EINVAL;
+    }
+    plan->div_exact = f.div_exact, plan->div_fma = f.div_fma, plan->act_clamp = f.act_clamp;
+    plan->clamp_lo = f.clamp_lo, plan->clamp_hi = f.clamp_hi, plan->inv_out_scale = f.inv_out_scale;
+    plan->pt_geom = f.pt_geom;
+    return SHL_MI355X_OK;
 }
 
 }  // extern "C"

@@ -130,6 +130,11 @@ def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c
                 hip.shl_mi355x_comm_destroy(comm)
             why = "ncclCommInitRank failed on some rank: " + hip.shl_mi355x_last_error().decode()
     n = broadcast_plan_blocks(chain, torch, dist, hip, src=src)
+    # tables and the code path chosen for them come from the same rank: adopt the root's flags records
+    cnt = len(chain.entries)
+    params = (C.c_void_p * cnt)(*[C.cast(e["params"], C.c_void_p) for e in chain.entries])
+    if opt.shl_mi355x_params_adopt_blocks(params, cnt, chain.sess) != 1:
+        raise RuntimeError("shl_mi355x_params_adopt_blocks failed: " + hip.shl_mi355x_last_error().decode())
     return "torch.distributed broadcast, %d buckets (%s)" % (n, why)
 
 

@@ -18,6 +18,7 @@
  */
 #include <math.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 
 #include "mi355x_internal.h"
@@ -492,10 +493,63 @@ static int dwconv_channel_init_act(CSINN_CONV_ARGS, int act)
     return CSINN_TRUE;
 }
 
+/* The reference's protocol for these ids has no init: its exec re-reads kernel, bias and quantisation records on every
+ * call.  The backend plans on the first exec and keeps the plan under the params block -- with a fingerprint of what
+ * it was built from (tensor data pointers, record pointers, first record, geometry), so that a caller who swaps
+ * weights or records between calls gets a new plan instead of the stale one.  (Weights rewritten IN PLACE behind the
+ * same pointers are not seen: the plan snapshots them at first exec; call shl_mi355x_release_params to force a rebuild.) */
+struct channel_key {
+    void *params;
+    const void *kdata, *bdata, *kq, *iq, *oq;
+    float kscale0, iscale, oscale;
+    int32_t kzp0, izp, ozp, omult, oshift;
+    int32_t dims[12];
+};
+static struct channel_key g_channel_keys[64];
+static pthread_mutex_t g_channel_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void channel_key_of(struct channel_key *k, CSINN_CONV_ARGS)
+{
+    memset(k, 0, sizeof(*k));
+    k->params = params;
+    k->kdata = kernel->data, k->kq = kernel->qinfo;
+    k->bdata = bias ? bias->data : NULL;
+    k->iq = input->qinfo, k->oq = output->qinfo;
+    k->kscale0 = kernel->qinfo->scale, k->kzp0 = kernel->qinfo->zero_point;
+    k->iscale = input->qinfo->scale, k->izp = input->qinfo->zero_point;
+    k->oscale = output->qinfo->scale, k->ozp = output->qinfo->zero_point;
+    k->omult = output->qinfo->multiplier, k->oshift = output->qinfo->shift;
+    for (int i = 0; i < 4; i++) k->dims[i] = input->dim[i], k->dims[4 + i] = kernel->dim[i], k->dims[8 + i] = output->dim[i];
+}
+
+/* 1: the plan under `params` was built from exactly this; 0: first sight or something changed (key updated) */
+static int channel_key_matches(const struct channel_key *k)
+{
+    int hit = 0;
+    pthread_mutex_lock(&g_channel_lock);
+    size_t h = ((uintptr_t)k->params >> 4) % 64;
+    for (int probe = 0; probe < 64; probe++, h = (h + 1) % 64) {
+        if (g_channel_keys[h].params == k->params) {
+            hit = memcmp(&g_channel_keys[h], k, sizeof(*k)) == 0;
+            g_channel_keys[h] = *k;
+            break;
+        }
+        if (g_channel_keys[h].params == NULL) {
+            g_channel_keys[h] = *k;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&g_channel_lock);
+    return hit;
+}
+
 static int channel_exec(CSINN_CONV_ARGS, int (*init_act)(CSINN_CONV_ARGS, int), int act, const char *what)
 {
-    if (shl_mi355x_registry_get(params) == NULL) { /* the reference's protocol for these ids has no init */
-        int rc = init_act(input, output, kernel, bias, params, act);
+    struct channel_key key;
+    channel_key_of(&key, input, output, kernel, bias, params);
+    const int same = channel_key_matches(&key);
+    if (shl_mi355x_registry_get(params) == NULL || !same) {
+        int rc = init_act(input, output, kernel, bias, params, act); /* registry_put releases a previous plan */
         if (rc != CSINN_TRUE) return rc;
     }
     return run_plan(&params->base, input, output, input->dim[0], what);

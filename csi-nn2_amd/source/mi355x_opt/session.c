@@ -40,6 +40,7 @@ struct dev_session {
     int nt;
     void *stream;
     void *prev_stream; /* the session's stream before it became device resident */
+    int prev_own;      /* ... and whether that was a stream of its own (else: the process default) */
     void *graph_exec;
     unsigned char *fused; /* per layer: 1 = runs fused with the next layer (depthwise + pointwise) */
     int nfused;
@@ -62,7 +63,10 @@ static void free_session(struct dev_session *ds)
         if (ds->t[i].dev && !ds->t[i].borrowed) shl_mi355x_free(ds->t[i].dev);
     if (ds->stream) {
         shl_mi355x_stream_sync(ds->stream);
-        shl_mi355x_session_set_stream(ds->sess, ds->prev_stream); /* the host path keeps working */
+        /* the host path keeps working: back to the stream the session had -- or to "whatever the process default
+         * is" when it had none of its own (a snapshot of the default would stop following shl_mi355x_set_stream) */
+        if (ds->prev_own) shl_mi355x_session_set_stream(ds->sess, ds->prev_stream);
+        else shl_mi355x_session_inherit_stream(ds->sess);
         shl_mi355x_stream_destroy(ds->stream);
     }
     free(ds->t);
@@ -303,6 +307,7 @@ int shl_mi355x_session_setup(struct csinn_session *sess)
     ds->t = calloc((size_t)tensors + 1, sizeof(struct dev_tensor));
     ds->stream = shl_mi355x_stream_create();
     int ok = ds->stream != NULL;
+    ds->prev_own = shl_mi355x_session_has_own_stream(sess);
     ds->prev_stream = shl_mi355x_session_stream(sess);
     if (ok) shl_mi355x_session_set_stream(sess, ds->stream); /* every exec callback of this session enqueues here */
     for (int i = 0; ok && i < g->input_num; i++) ok = adopt(ds, g->input[i]) != NULL;

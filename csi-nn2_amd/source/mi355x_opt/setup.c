@@ -117,6 +117,22 @@ void shl_mi355x_session_set_stream(struct csinn_session *sess, void *stream)
     c->own_stream = 1;
 }
 
+/* back to the process default stream (shl_mi355x_set_stream), followed from now on */
+void shl_mi355x_session_inherit_stream(struct csinn_session *sess)
+{
+    struct shl_mi355x_ctx *c = shl_mi355x_ctx_of(sess);
+    if (c == NULL) return;
+    if (ctx_has_staging(c)) shl_mi355x_stream_sync(shl_mi355x_ctx_stream(c));
+    c->stream = NULL;
+    c->own_stream = 0;
+}
+
+int shl_mi355x_session_has_own_stream(struct csinn_session *sess)
+{
+    struct shl_mi355x_ctx *c = shl_mi355x_ctx_of(sess);
+    return c && c->own_stream;
+}
+
 void *shl_mi355x_session_stream(struct csinn_session *sess)
 {
     return shl_mi355x_ctx_stream(shl_mi355x_ctx_of(sess));
@@ -314,25 +330,71 @@ const char *shl_mi355x_params_kernel_name(void *params)
 int shl_mi355x_bcast_const_blocks(void *comm, void **params, int32_t n, int32_t root, struct csinn_session *sess)
 {
     if (n <= 0) return CSINN_TRUE;
-    void **blocks = calloc((size_t)n, sizeof(void *));
-    size_t *bytes = calloc((size_t)n, sizeof(size_t));
-    int rc = CSINN_TRUE;
+    /* a grouped convolution keeps one plan per group: every one of them travels */
+    int total = 0;
+    for (int i = 0; i < n; i++) {
+        int g = 0;
+        while (shl_mi355x_registry_get_group(params[i], g)) g++;
+        total += g ? g : 1;
+    }
+    shl_mi355x_conv_plan **plans = calloc((size_t)total, sizeof(*plans));
+    void **blocks = calloc((size_t)total, sizeof(void *));
+    size_t *bytes = calloc((size_t)total, sizeof(size_t));
+    int rc = CSINN_TRUE, k = 0;
     for (int i = 0; i < n && rc == CSINN_TRUE; i++) {
-        blocks[i] = shl_mi355x_params_const_block(params[i], &bytes[i]);
-        if (blocks[i] == NULL) {
-            shl_debug_error("mi355x: bcast_const_blocks: layer %d has no device plan\n", i);
-            rc = CSINN_FALSE;
+        shl_mi355x_conv_plan *p = shl_mi355x_registry_get(params[i]);
+        if (p) {
+            plans[k++] = p;
+        } else {
+            int g = 0;
+            while ((p = shl_mi355x_registry_get_group(params[i], g)) != NULL) plans[k++] = p, g++;
+            if (g == 0) {
+                shl_debug_error("mi355x: bcast_const_blocks: layer %d has no device plan\n", i);
+                rc = CSINN_FALSE;
+            }
         }
     }
+    for (int i = 0; i < k; i++) blocks[i] = shl_mi355x_conv_plan_const_block(plans[i], &bytes[i]);
     void *stream = shl_mi355x_session_stream(sess);
-    if (rc == CSINN_TRUE && (shl_mi355x_comm_bcast(comm, blocks, bytes, n, root, stream) != SHL_MI355X_OK ||
+    if (rc == CSINN_TRUE && (shl_mi355x_comm_bcast(comm, blocks, bytes, k, root, stream) != SHL_MI355X_OK ||
                              shl_mi355x_stream_sync(stream) != SHL_MI355X_OK)) {
         shl_debug_error("mi355x: weight broadcast failed: %s\n", shl_mi355x_last_error());
         rc = CSINN_FALSE;
     }
+    /* tables and the code path chosen for them come from the same rank: the root's flags record is in the block */
+    for (int i = 0; i < k && rc == CSINN_TRUE; i++)
+        if (shl_mi355x_conv_plan_adopt_block(plans[i], stream) != SHL_MI355X_OK) {
+            shl_debug_error("mi355x: bcast_const_blocks: %s\n", shl_mi355x_last_error());
+            rc = CSINN_FALSE;
+        }
+    free(plans);
     free(blocks);
     free(bytes);
     return rc;
+}
+
+/* the same adoption for a caller that moved the constant blocks itself (any transport): every plan of
+ * `params[0..n)` takes the epilogue choices of the flags record now in its block */
+int shl_mi355x_params_adopt_blocks(void **params, int32_t n, struct csinn_session *sess)
+{
+    void *stream = shl_mi355x_session_stream(sess);
+    for (int i = 0; i < n; i++) {
+        shl_mi355x_conv_plan *p = shl_mi355x_registry_get(params[i]);
+        int g = 0;
+        if (p == NULL) p = shl_mi355x_registry_get_group(params[i], g++);
+        if (p == NULL) {
+            shl_debug_error("mi355x: params_adopt_blocks: layer %d has no device plan\n", i);
+            return CSINN_FALSE;
+        }
+        while (p) {
+            if (shl_mi355x_conv_plan_adopt_block(p, stream) != SHL_MI355X_OK) {
+                shl_debug_error("mi355x: params_adopt_blocks: %s\n", shl_mi355x_last_error());
+                return CSINN_FALSE;
+            }
+            p = g ? shl_mi355x_registry_get_group(params[i], g++) : NULL;
+        }
+    }
+    return CSINN_TRUE;
 }
 
 /* ------------------------------------------------------------------------ staging */

@@ -281,7 +281,16 @@ struct csinn_session *csinn_alloc_session()
     return shl_mem_alloc(sizeof(struct csinn_session));
 }
 
-void csinn_free_session(struct csinn_session *sess) { shl_mem_free(sess); }
+/* the same weak hook for sessions: the MI355X backend keeps an execution context (stream binding, HBM staging
+ * buffers) per session, layer-mode sessions included; it dies with the session even when no deinit callback ran (a
+ * later session allocated at the same address would otherwise inherit it) */
+void shl_mi355x_ctx_release(struct csinn_session *sess) __attribute__((weak));
+
+void csinn_free_session(struct csinn_session *sess)
+{
+    if (sess && shl_mi355x_ctx_release) shl_mi355x_ctx_release(sess);
+    shl_mem_free(sess);
+}
 
 void csinn_session_init(struct csinn_session *sess)
 {

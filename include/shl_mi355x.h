@@ -216,6 +216,10 @@ size_t shl_mi355x_conv_plan_bytes(const shl_mi355x_conv_plan *plan);
  * caller can ncclBroadcast it from rank 0; contents are position-independent.
  */
 void *shl_mi355x_conv_plan_const_block(shl_mi355x_conv_plan *plan, size_t *bytes);
+/* After the block was overwritten by a weight broadcast: adopt the sender's host-derived epilogue choices (exact
+ * power-of-two fold, multiply-and-correct division, activation-as-clamp bounds, row-patch wave roles) from the 64-byte
+ * record at the end of the block, so that tables and code path always come from the same rank. */
+int shl_mi355x_conv_plan_adopt_block(shl_mi355x_conv_plan *plan, void *stream);
 
 /*
  * Enqueue one forward pass: out = act(requant(conv(in))).

@@ -36,6 +36,9 @@ void *shl_mi355x_runtime_callback(int runtime_op);
 void shl_mi355x_set_stream(void *stream);
 void *shl_mi355x_get_stream(void);
 void shl_mi355x_session_set_stream(struct csinn_session *sess, void *stream);
+/* undo it: the session follows the process default (shl_mi355x_set_stream) again; 1 when it has a stream of its own */
+void shl_mi355x_session_inherit_stream(struct csinn_session *sess);
+int shl_mi355x_session_has_own_stream(struct csinn_session *sess);
 
 /* release the device plan attached to a params block by an init callback (the reference's
  * optimised backends leak theirs: "XXX: memory leak", thead_rvv/int8/convolution.c:177) */
@@ -47,6 +50,9 @@ void *shl_mi355x_params_const_block(void *params, size_t *bytes);
 /* multi-GPU setup: RCCL broadcast of the layers' constant blocks from rank `root` over the
  * communicator of shl_mi355x_comm_create (include/shl_mi355x.h); CSINN_TRUE once they have landed */
 int shl_mi355x_bcast_const_blocks(void *comm, void **params, int32_t n, int32_t root, struct csinn_session *sess);
+/* for a caller that moved the constant blocks with a transport of its own: every plan of params[0..n) adopts the
+ * epilogue choices recorded in the block it now holds (shl_mi355x_conv_plan_adopt_block) */
+int shl_mi355x_params_adopt_blocks(void **params, int32_t n, struct csinn_session *sess);
 /* name of the HIP kernel the plan attached to `params` launches ("" if none) */
 const char *shl_mi355x_params_kernel_name(void *params);
 

@@ -403,8 +403,9 @@ def oracle_channel_run(case):
     return out
 
 
-def csinn_channel_run(fe, api, case, device=None, call_init=True, keep_params=None):
-    """shl_op_callback_map(CSINN_OP_*_CHANNEL*) + cb->init (if any) + cb->exec through front-end `fe`."""
+def csinn_channel_run(fe, api, case, device=None, call_init=True, keep_params=None, reuse_params=None):
+    """shl_op_callback_map(CSINN_OP_*_CHANNEL*) + cb->init (if any) + cb->exec through front-end `fe`.
+    reuse_params: an entry a previous call left in `keep_params` -- the SAME params block is called with this case's tensors."""
     keep = pkg.Keep()
     sess = pkg.layer_session(fe, api, keep)
     dw = case["chan_kind"] == "dw"
@@ -430,8 +431,11 @@ def csinn_channel_run(fe, api, case, device=None, call_init=True, keep_params=No
                               scales=tuple(case["b_scale"]), zps=(0,), is_const=1, name=b"bias", sess=sess)
     else:
         t_b = pkg.make_tensor(fe, keep, (), pkg.DTYPE_INT32, pkg.LAYOUT_O, name=b"bias", sess=sess)
-    params = pkg.conv_params(fe, keep, api, pkg.LAYOUT_NCHW, case["stride"], case["pad"], case["dilation"],
-                             case["c"] if dw else 1, 0, sess)
+    if reuse_params is not None:
+        params = reuse_params[0]
+    else:
+        params = pkg.conv_params(fe, keep, api, pkg.LAYOUT_NCHW, case["stride"], case["pad"], case["dilation"],
+                                 case["c"] if dw else 1, 0, sess)
     op = (OP_DEPTHWISE_CONV2D_CHANNEL if dw else OP_CONV2D_CHANNEL) + case["act"]
     fe.shl_op_callback_map.restype = C.c_int
     fe.shl_op_callback_map.argtypes = [C.c_void_p, C.c_int, C.c_int]

@@ -156,6 +156,23 @@ def test_depthwise_channel_batch128_512_channels(gpu):
 
 
 @pytest.mark.gpu
+def test_channel_exec_replans_when_the_weights_are_swapped(gpu):
+    """The reference's *_channel ops have no init and re-read kernel / bias / records on every call; the backend plans on
+    first exec.  A caller that points the SAME params block at other weights must not get the stale plan (advisor,
+    round 2): the plan is keyed on a fingerprint of what it was built from."""
+    fe, hip, opt, dev = gpu
+    a = cases.make_channel_case(501, "dw", c=32, h=9, w=9)
+    b = cases.make_channel_case(502, "dw", c=32, h=9, w=9)
+    b["input"] = a["input"]
+    kept = []
+    got_a = cases.csinn_channel_run(fe, pkg.API_MI355X, a, device=None, call_init=False, keep_params=kept)
+    _compare(a, got_a, cases.oracle_channel_run(a), "first weights")
+    got_b = cases.csinn_channel_run(fe, pkg.API_MI355X, b, device=None, call_init=False, keep_params=kept, reuse_params=kept[0])
+    _compare(b, got_b, cases.oracle_channel_run(b), "swapped weights under the same params block")
+    opt.shl_mi355x_release_params(kept[0][0])
+
+
+@pytest.mark.gpu
 def test_unsupported_channel_requests_are_refused(gpu):
     fe, hip, opt, dev = gpu
     case, _ = golden("conv_kernel_zp")           # asymmetric weights on the float path

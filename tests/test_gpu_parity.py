@@ -201,6 +201,93 @@ def _plan_forward(hip, dev, case, algo):
     return got, name
 
 
+def _desc_of(case, algo=None):
+    d = pkg.ConvDesc()
+    d.layout = pkg.SHL_NHWC if case["layout"] == NHWC else pkg.SHL_NCHW
+    d.dtype = pkg.SHL_I8
+    d.act, d.algo = case["act"], pkg.ALGO_AUTO if algo is None else algo
+    d.batch, d.in_h, d.in_w, d.in_c = case["n"], case["h"], case["w"], case["c"]
+    d.out_h, d.out_w, d.out_c = case["ho"], case["wo"], case["co"]
+    d.kernel_h, d.kernel_w = case["kh"], case["kw"]
+    d.stride_h, d.stride_w = case["stride"]
+    d.pad_top, d.pad_left = case["pad"][0], case["pad"][1]
+    d.dilation_h, d.dilation_w = case["dilation"]
+    d.group = case["group"]
+    d.in_zp, d.out_zp, d.out_scale = case["in_zp"], case["out_zp"], case["out_scale"]
+    return d
+
+
+def test_a_received_block_brings_its_epilogue_choices(gpu):
+    """Weight broadcast between ranks whose placeholder tables differ (advisor, round 2): the receiver's plan was built
+    from multipliers so small that the power-of-two fold of 1 / s_out is refused (div_exact = 0), the sender's tables
+    are pre-scaled (div_exact = 1).  The bytes alone would be divided twice; shl_mi355x_conv_plan_adopt_block takes the
+    sender's choices from the flags record at the end of the block."""
+    fe, hip, opt, dev = gpu
+    case = cases.make_case(4321, c=64, co=64, h=12, w=12, n=2, act=1)
+    mult = (np.float32(case["in_scale"]) * np.broadcast_to(case["k_scale"], (case["co"],))).astype(np.float32)
+    bias = (case["bias"].astype(np.float32) * np.broadcast_to(case["b_scale"], (case["co"],))).astype(np.float32)
+    ker = np.ascontiguousarray(case["kernel"])
+    tiny = np.full_like(mult, 2.0 ** -70)                      # placeholder quantisation of a rank that waits for the root
+    zeros = np.zeros_like(ker)
+    d = _desc_of(case)
+    root, recv = C.c_void_p(), C.c_void_p()
+    pkg.check(hip.shl_mi355x_conv_plan_create(C.byref(d), ker.ctypes.data, mult.ctypes.data, bias.ctypes.data, None, C.byref(root)), hip, "root plan")
+    pkg.check(hip.shl_mi355x_conv_plan_create(C.byref(d), zeros.ctypes.data, tiny.ctypes.data, bias.ctypes.data, None, C.byref(recv)), hip, "receiver plan")
+    out = np.zeros(case["out_shape"], dtype=np.int8)
+    din, dout = dev.alloc(case["input"].nbytes), dev.alloc(out.nbytes)
+    dev.upload(din, case["input"])
+
+    def run(plan):
+        pkg.check(hip.shl_mi355x_conv_forward(plan, din, dout, 0, None), hip, "forward")
+        return dev.download(dout, out.shape, out.dtype)
+
+    want = run(root)
+    assert cases.mismatch_report(want, cases.oracle_run(case, "exact"))[0] == 0
+    n0, n1 = C.c_size_t(), C.c_size_t()
+    b0 = hip.shl_mi355x_conv_plan_const_block(root, C.byref(n0))
+    b1 = hip.shl_mi355x_conv_plan_const_block(recv, C.byref(n1))
+    assert n0.value == n1.value
+    pkg.check(hip.shl_mi355x_copy(b1, b0, n0.value, None), hip, "copy")      # "the broadcast"
+    hip.shl_mi355x_stream_sync(None)
+    assert not np.array_equal(run(recv), want), "the receiver's own flags happen to fit the sender's tables: the test shows nothing"
+    pkg.check(hip.shl_mi355x_conv_plan_adopt_block(recv, None), hip, "adopt_block")
+    assert np.array_equal(run(recv), want)
+    dev.free(din)
+    dev.free(dout)
+    for p in (root, recv):
+        pkg.check(hip.shl_mi355x_conv_plan_destroy(p), hip, "destroy")
+
+
+def test_forward_with_a_larger_batch_than_the_plan_was_created_for(gpu):
+    """include/shl_mi355x.h: a plan is batch independent (NHWC).  The per-pixel address table of the producer / consumer
+    kernels covers desc.batch images only (advisor, round 2): a larger batch must run on kernels that do their own index
+    arithmetic, not read past the table."""
+    fe, hip, opt, dev = gpu
+    small = cases.make_case(99, c=256, co=128, h=14, w=14, n=2, act=1)        # plan: batch 2
+    rng = np.random.default_rng(5)
+    big = dict(small, n=96, in_shape=(96,) + tuple(small["in_shape"][1:]), out_shape=(96,) + tuple(small["out_shape"][1:]))
+    big["input"] = rng.integers(-64, 64, big["in_shape"], dtype=np.int8)     # forward: batch 96, same weights and records
+    mult = (np.float32(big["in_scale"]) * np.broadcast_to(big["k_scale"], (big["co"],))).astype(np.float32)
+    bias = (big["bias"].astype(np.float32) * np.broadcast_to(big["b_scale"], (big["co"],))).astype(np.float32)
+    ker = np.ascontiguousarray(big["kernel"])
+    for env_batch, case in ((2, small),):
+        d = _desc_of(case)
+        plan = C.c_void_p()
+        pkg.check(hip.shl_mi355x_conv_plan_create(C.byref(d), ker.ctypes.data, mult.ctypes.data, bias.ctypes.data, None, C.byref(plan)), hip, "plan")
+        out = np.zeros(big["out_shape"], dtype=np.int8)
+        din, dout = dev.alloc(big["input"].nbytes), dev.alloc(out.nbytes)
+        dev.upload(din, big["input"])
+        pkg.check(hip.shl_mi355x_conv_forward(plan, din, dout, 96, None), hip, "forward batch 96")
+        got = dev.download(dout, out.shape, out.dtype)
+        for i in (0, 1, 50, 95):
+            one = dict(big, n=1, input=np.ascontiguousarray(big["input"][i:i + 1]), in_shape=(1,) + tuple(big["in_shape"][1:]),
+                       out_shape=(1,) + tuple(big["out_shape"][1:]))
+            assert cases.mismatch_report(got[i:i + 1], cases.oracle_run(one, "exact"))[0] == 0, "image %d" % i
+        dev.free(din)
+        dev.free(dout)
+        pkg.check(hip.shl_mi355x_conv_plan_destroy(plan), hip, "destroy")
+
+
 @pytest.mark.parametrize("kw", [dict(c=64, co=96, h=17, w=9, n=2, stride=(2, 1)), dict(c=32, co=32, k=(1, 1), pad=(0, 0, 0, 0)),
                                 dict(depthwise=True, c=48, h=11, w=11)])
 def test_kernels_agree_with_each_other(gpu, kw):
