@@ -130,6 +130,9 @@ def build_oracle(force=False):
     if os.path.isdir(os.path.join(REFERENCE, "source", "reference")):
         if force or not os.path.exists(ref_so):
             _run(["make", "-s", "-C", odir, "ref", "-j8"])
+        # the reference's own layer tests against the backend (oracle/Makefile.layer_tests): after build_host
+        if os.path.exists(ref_so) and os.path.exists(os.path.join(LIB, "libshl_mi355x_opt.so")):
+            _run(["make", "-s", "-f", os.path.join(odir, "Makefile.layer_tests")] + (["-B"] if force else []))
     return ref_so if os.path.exists(ref_so) else None
 
 

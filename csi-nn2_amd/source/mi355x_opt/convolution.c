@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "mi355x_internal.h"
@@ -347,6 +348,16 @@ static int run_plan(struct csinn_params_base *base, struct csinn_tensor *input, 
     if (st != SHL_MI355X_OK) {
         shl_debug_error("mi355x: %s launch failed (%d): %s\n", what, st, shl_mi355x_last_error());
         return CSINN_FALSE;
+    }
+    {
+        /* SHL_MI355X_TRACE_EXEC=1: one line per executed layer on stderr -- lets a caller that cannot look inside the
+         * process (the reference's layer tests, tests/test_ref_layer_tests.py) see that the GPU plan ran */
+        static int trace = -1;
+        if (trace < 0) {
+            const char *e = getenv("SHL_MI355X_TRACE_EXEC");
+            trace = e && e[0] == '1';
+        }
+        if (trace) fprintf(stderr, "mi355x: exec %s batch %d via %s\n", what, batch, shl_mi355x_conv_plan_kernel_name(plan));
     }
     return shl_mi355x_stage_out_end(ctx, output, out_dev);
 }
