@@ -26,13 +26,19 @@ The JSON line also carries
   cpu_baseline -- the reference C backend (kind "reference": the genuine library built by
                   oracle/Makefile.ref, or kind "port": this repo's oracle) timed on the host cores
                   on a bounded sample of the same network;
-  configs      -- (N = 1 runs) the other single-GPU configurations of BASELINE.json, each with its own
-                  roofline: configs[2] ResNet-50 3x3 set int8 batch 128 in NCHW (as BASELINE names it)
-                  and in NHWC, against the int8 MFMA peak; configs[3] MobileNetV1 binary16 NCHW batch 1
-                  (c906_mobilenetv1_f16 shapes).  --no-configs skips them; --extra adds serving views.
+  configs      -- the other configurations of BASELINE.json, each timed as ONE captured pass of its layers (median of
+                  windows of replays) with its own roofline.  N = 1: configs[2] ResNet-50 3x3 set int8 batch 128 in
+                  NCHW (as BASELINE names it) and in NHWC against the int8 MFMA peak (`kernel_only` = the dominant
+                  kernel's launches alone, `relayout_us` = what layers that still go through a re-layout pass cost),
+                  configs[3] MobileNetV1 binary16 NCHW batch 1 (c906_mobilenetv1_f16 shapes), and MobileNetV1 int8 at
+                  batch 128 (throughput view of configs[1]).  N > 1: configs[4] -- the ResNet-50 3x3 set with a total
+                  batch of 128 N SHARDED over the ranks (128 images per GPU), rank 0's packed weights broadcast once
+                  with RCCL behind the C-ABI.  --no-configs skips them; --extra adds serving views.
 
---workload resnet50_3x3 --total-batch 1024 is BASELINE configs[4]: the batch is SHARDED over the ranks
-(sharding.shard_batch: 128 images per GPU at N = 8), weights broadcast once from rank 0.
+--workload resnet50_3x3 --total-batch 1024 runs configs[4] as the headline instead.
+Process group: torch.distributed is bootstrap only (gloo: the 128-byte ncclUniqueId, agreement flags, barriers and
+the MAX over ranks of the window times, all on CPU tensors); the weights move through RCCL behind the C-ABI
+(shl_mi355x_comm_* / shl_mi355x_bcast_const_blocks).  Device memory comes from the C-ABI allocator, not from torch.
 """
 import argparse
 import ctypes as C
@@ -70,7 +76,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true", help="every layer its own launch (no pointwise+depthwise fusion)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--detail", action="store_true", help="print the per-layer table to stderr")
     ap.add_argument("--steps-only", action="store_true",
                     help="run warmup + timed steps and stop (for rocprofv3 --pmc passes: only step launches are seen)")
@@ -118,7 +124,49 @@ def cpu_baseline_worker(args):
         images += 1
         if t_used > budget:
             done = True
-    print(json.dumps({"value": ops_done / t_used / 1e9, "unit": "GOPS", "cores": cores, "kind": kind,
+    extra = []
+    if kind == "reference":
+        # configs[2]'s own reference path: NCHW -> shl_ref_conv2d_nchw_f32 -> conv_im2col_sgemm_avx (conv_avx.h, its
+        # pragmas say omp num_threads(8)); ONE image per call (the x86 path computes image 0 of a batch only)
+        t2, ops2, calls2 = 0.0, 0, 0
+        seen = set()
+        for L in wl.RESNET50_3X3:
+            key = (L["cin"], L["h"], L["stride"])
+            if key in seen:
+                continue
+            seen.add(key)
+            case = cases.make_case(70 + calls2, layout=cases.NCHW, n=1, h=L["h"], w=L["w"], c=L["cin"], co=L["cout"],
+                                   k=(3, 3), stride=(L["stride"],) * 2, pad=(1,) * 4, act=1)
+            cases.csinn_run(fe, pkg.API_REF, case)  # warm (thread team, page faults)
+            reps = 0
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.7:
+                cases.csinn_run(fe, pkg.API_REF, case)
+                reps += 1
+            t2 += (time.perf_counter() - t0) / reps
+            ops2 += wl.layer_ops(L)
+            calls2 += 1
+        extra.append({"baseline_config": "configs[2]", "value": ops2 / t2 / 1e9, "unit": "GOPS", "cores": 8, "kind": "reference",
+                      "sample": "the 7 distinct ResNet-50 3x3 shapes, int8 NCHW, one image per csinn_conv2d call on CSINN_REF "
+                                "(im2col + 8x8 AVX2 sgemm, omp num_threads(8) in conv_avx.h; tensor set-up of the call included), %.1f ms per image of the seven" % (t2 * 1e3)})
+        # configs[3]: binary16 NCHW, the first layers of MobileNetV1 (c906 example shapes)
+        t3, ops3, calls3 = 0.0, 0, 0
+        for i, L in enumerate(wl.MOBILENETV1[:7]):
+            case = cases.make_case(90 + i, dtype="f16", layout=cases.NCHW, n=1, h=L["h"], w=L["w"], c=L["cin"], co=L["cout"],
+                                   k=(L["k"], L["k"]), stride=(L["stride"],) * 2, pad=(L["pad"],) * 4, depthwise=L["depthwise"],
+                                   act=1 if L["act"] else 0)
+            reps = 0
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.5:
+                cases.csinn_run(fe, pkg.API_REF, case)
+                reps += 1
+            t3 += (time.perf_counter() - t0) / reps
+            ops3 += wl.layer_ops(L)
+            calls3 += 1
+        extra.append({"baseline_config": "configs[3]", "value": ops3 / t3 / 1e9, "unit": "GFLOPS", "cores": 8, "kind": "reference",
+                      "sample": "the first %d layers of MobileNetV1 in binary16 NCHW via csinn_conv2d / csinn_depthwise_conv2d on CSINN_REF "
+                                "(dense layers on the AVX sgemm with 8 threads, depthwise serial), %.1f ms for the %d layers" % (calls3, t3 * 1e3, calls3)})
+    print(json.dumps({"value": ops_done / t_used / 1e9, "unit": "GOPS", "cores": cores, "kind": kind, "configs": extra,
                       "imgs_per_sec": (ops_done / sum(wl.layer_ops(l) for l in layers)) / t_used,
                       "sample": "%d MobileNetV1 int8 NHWC layer calls (%.2f images) via csinn_conv2d on %s, %.1f s"
                                 % (layers_done, ops_done / sum(wl.layer_ops(l) for l in layers),
@@ -137,22 +185,54 @@ def run_cpu_baseline(args):
 
 
 # ------------------------------------------------------------------------------------ GPU side
-class TorchHBM:
-    """Device memory from torch (plumbing only): raw pointers go into csinn_tensor.data."""
+class CHbm:
+    """Device memory from the C-ABI (shl_mi355x_malloc / _upload): raw pointers go into csinn_tensor.data."""
 
-    def __init__(self, torch, device):
-        self.torch, self.device, self.live = torch, device, []
+    def __init__(self, hip):
+        self.hip, self.live = hip, []
 
     def alloc(self, nbytes):
-        t = self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
-        self.live.append(t)
-        return t.data_ptr()
+        p = self.hip.shl_mi355x_malloc(max(int(nbytes), 16))
+        if not p:
+            raise RuntimeError("shl_mi355x_malloc(%d): %s" % (nbytes, self.hip.shl_mi355x_last_error().decode()))
+        self.live.append(p)
+        return p
 
     def upload(self, ptr, host):
-        t = next(x for x in self.live if x.data_ptr() == ptr)
-        flat = self.torch.from_numpy(np.ascontiguousarray(host).view(np.uint8).reshape(-1))
-        t[:flat.numel()].copy_(flat)
-        self.torch.cuda.synchronize()
+        a = np.ascontiguousarray(host)
+        if self.hip.shl_mi355x_upload(ptr, a.ctypes.data, a.nbytes, None) != 0 or self.hip.shl_mi355x_stream_sync(None) != 0:
+            raise RuntimeError("upload: " + self.hip.shl_mi355x_last_error().decode())
+
+    def free_all(self):
+        self.hip.shl_mi355x_stream_sync(None)
+        for p in self.live:
+            self.hip.shl_mi355x_free(p)
+        self.live = []
+
+
+def timed_windows(replay, sync, steps, warmup, windows, dist=None, torch=None):
+    """W warm-up steps, then `windows` windows of exactly `steps` steps, each bracketed by barrier + synchronisation on
+    both sides and reduced with MAX over ranks (CPU tensors: the process group is bootstrap only)."""
+    for _ in range(warmup):
+        replay()
+    sync()
+    out = []
+    for _ in range(max(1, windows)):
+        sync()
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            replay()
+        sync()
+        w = time.perf_counter() - t0
+        if dist:
+            dist.barrier()
+            t = torch.tensor([w], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+        out.append(w)
+    return out
 
 
 def time_groups(chain, hip, opt, stream, reps=20):
@@ -223,43 +303,112 @@ def attach_traffic(roof, path):
             path, os.path.dirname(os.path.abspath(__file__)))
 
 
+def measure_config(tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, chained_x, env, steps=20, warmup=3, windows=5,
+                   dist=None, seed=4321, bcast_from=None, total_batch=None):
+    """One configuration of BASELINE.json as ONE captured pass of its layers: median of `windows` windows of `steps`
+    replays, plus the per-launch table (HIP events around 20 back-to-back launches of every layer) behind the roofline
+    of its dominant kernel.  With a process group: every rank runs its shard, rank 0's weights are broadcast first."""
+    torch, fe, hip, opt, wl, par, stream, detail = (env[k] for k in ("torch", "fe", "hip", "opt", "wl", "par", "stream", "detail"))
+    hbm = CHbm(hip)
+    fuse = chained_x and dtype_x == "int8" and layout_x == "NHWC" and batch_x <= 8
+    rc = wl.LayerChain(fe, hip, opt, layers_x, batch_x, hbm.alloc, hbm.upload, dtype=dtype_x, layout=layout_x, seed=seed,
+                       chained=chained_x, fuse=fuse)
+    how = None
+    if dist is not None:
+        how = par.broadcast_weights(rc, torch, dist, hip, opt, env["rank"], env["world"], src=0, prefer_c=bcast_from)
+        par.assert_replicas_agree(rc, torch, dist, hip)
+    rc.capture(stream)
+    wins = timed_windows(rc.replay, lambda: hip.shl_mi355x_stream_sync(stream), steps, warmup, windows, dist, torch)
+    t_pass = float(np.median(wins)) / steps
+    world = env["world"] if dist is not None else 1
+    images = total_batch if total_batch else batch_x * world
+    ops_total = rc.total_ops() // batch_x * images
+    unit = "GOPS" if dtype_x == "int8" else "GFLOPS"
+    peak = I8_MFMA_PEAK_TOPS if dtype_x == "int8" else F16_MFMA_PEAK_TFLOPS
+    entry = {"baseline_config": tag, "workload": name, "metric": "conv_" + unit.lower(), "value": ops_total / t_pass / 1e9,
+             "unit": unit, "images_per_sec": images / t_pass, "ms_per_pass": t_pass * 1e3, "n_gpus": world,
+             "windows_ms": [w / steps * 1e3 for w in wins],
+             "timing": "one captured pass of the %d launches, median of %d windows of %d replays%s" % (
+                 len(rc.units), len(wins), steps, ", barrier + MAX over ranks" if dist is not None else ""),
+             "dtype": "i8" if dtype_x == "int8" else "f16", "layers": len(layers_x), "launches": len(rc.units),
+             "mfma_frac_whole_set": ops_total / world / t_pass / 1e12 / peak}
+    if how:
+        entry["parallelism"] = "batch shard x%d, %d images per GPU (weights broadcast once: %s)" % (world, batch_x, how)
+    if env["rank"] == 0:
+        rt = time_groups(rc, hip, opt, stream, reps=20)
+        rroof, rgroups = summarise_kernels(rc, wl, rt, bound_x)
+        wname = "resnet50_3x3" if layers_x is wl.RESNET50_3X3 else "mobilenetv1"
+        attach_traffic(rroof, os.path.join(ROOT, "profiles", "traffic_%s_%s_%s_b%d.json" % (wname, dtype_x, layout_x, batch_x)))
+        entry["roofline"] = rroof
+        # the dominant kernel alone, and what the layers that still go through a re-layout pass cost (NCHW: the
+        # stride-2 layers; their launch = [C][HW] -> [HW][C] copy + NHWC kernel with an NCHW-writing epilogue)
+        entry["kernel_only"] = {"kernel": rroof["kernel"], "launches": rroof["launches_per_step"], "us_per_launch": rroof["avg_launch_us"],
+                                "achieved": rroof["achieved"], "unit": rroof["unit"]}
+        if layout_x == "NCHW" and dtype_x == "int8":
+            rel = [(rc.unit_name(u), t) for u, t in enumerate(rt) if "patch" not in rc.unit_kernel_name(u) and "nchw" not in rc.unit_kernel_name(u)]
+            entry["relayout_layers"] = {"count": len(rel), "us_total_with_relayout": sum(t for _, t in rel) * 1e6,
+                                        "note": "launches of layers the NCHW-native kernels do not take (re-layout pass + NHWC kernel)"}
+        entry["sum_launch_us"] = sum(rt) * 1e6
+        entry["kernels"] = {k: {"launches": v["launches"], "us_total": v["time"] * 1e6, "TOPs": v["ops"] / v["time"] / 1e12,
+                                "GBps": v["bytes"] / v["time"] / 1e9} for k, v in rgroups.items()}
+        if detail:
+            sys.stderr.write("---- %s\n" % name)
+            for u, t in enumerate(rt):
+                sys.stderr.write("%-52s %-32s %8.2f us %8.1f GB/s %8.2f TOP/s\n" % (
+                    rc.unit_name(u), rc.unit_kernel_name(u), t * 1e6, rc.unit_bytes(u) / t / 1e9, rc.unit_ops(u) / t / 1e12))
+    rc.release()
+    hbm.free_all()
+    return entry
+
+
+def emit(result):
+    """the ONE JSON line, after everything native code may have left in C stdio buffers (librccl prints a version banner
+    to stdout when it is first used) and as the last thing written"""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(result), flush=True)
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hook: run every rank on ONE device over gloo (a 1-GPU box can then exercise the N > 1 code
-    # path: weight broadcast, replica agreement, barriers, max-over-ranks); never set by the driver
+    # test hook: run every rank on ONE device (a 1-GPU box can then exercise the N > 1 code path: weight broadcast
+    # through the fallback transport, replica agreement, barriers, max-over-ranks); never set by the driver
     single_dev = os.environ.get("SHL_BENCH_SINGLE_DEVICE") == "1"
     if single_dev:
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
-    torch.cuda.set_device(local_rank)
-    dist = None
+    dist = torch = None
     if world > 1:
+        # bootstrap only (gloo, CPU tensors): the ncclUniqueId, agreement flags, barriers, MAX of the window times.
+        # The weights travel through RCCL behind the C-ABI (csrc/comm_rccl.hip), not through this group.
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if single_dev:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
 
     pkg = importlib.import_module("csi-nn2_amd")
     wl = importlib.import_module("csi-nn2_amd.workloads")
     par = importlib.import_module("csi-nn2_amd.sharding")
     fe = pkg.load_frontend("standalone")
     hip, opt = pkg.load_backend(fe)
+    if hip.shl_mi355x_device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: " + hip.shl_mi355x_last_error().decode())
     pkg.check(hip.shl_mi355x_set_device(local_rank), hip, "set_device")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)  # the fallback transport of the weight broadcast stages through torch buffers
     arch = C.create_string_buffer(64)
     cus = C.c_int32()
     hip.shl_mi355x_device_info(arch, 64, C.byref(cus), None)
 
-    hbm = TorchHBM(torch, torch.device("cuda", local_rank))
+    hbm = CHbm(hip)
     if args.workload == "mobilenetv1":
         layers, batch, chained, bound = wl.MOBILENETV1, args.batch or 1, True, "hbm"
         layout = args.layout or "NHWC"
@@ -283,29 +432,12 @@ def main():
     if world > 1:
         bcast = par.broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c=not single_dev)
         par.assert_replicas_agree(chain, torch, dist, hip)
+    elif sharded:
+        bcast = par.broadcast_weights_one_rank(chain, hip, opt)  # the same C entry points with a communicator of one
 
     stream = hip.shl_mi355x_stream_create()
     chain.capture(stream)
-    for _ in range(args.warmup):
-        chain.replay()
-    hip.shl_mi355x_stream_sync(stream)
-    windows = []
-    for _ in range(max(1, args.windows)):
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            chain.replay()
-        hip.shl_mi355x_stream_sync(stream)
-        torch.cuda.synchronize()
-        w = time.perf_counter() - t0
-        if dist:
-            dist.barrier()
-            t = torch.tensor([w], dtype=torch.float64, device="cpu" if single_dev else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            w = float(t.item())
-        windows.append(w)
+    windows = timed_windows(chain.replay, lambda: hip.shl_mi355x_stream_sync(stream), args.steps, args.warmup, args.windows, dist, torch)
     elapsed = float(np.median(windows))
 
     total_images = (args.total_batch if sharded else world * batch) * args.steps
@@ -331,26 +463,30 @@ def main():
                    "per_gpu_batch": batch,
                    "parallelism": ("batch shard x%d" % world if sharded else "replicas x%d" % world) +
                                   (" (weights broadcast once: %s)" % bcast if bcast else ""),
+                   "process_group": "none" if world == 1 else "gloo (bootstrap only: RCCL id, flags, barriers, MAX of window times)",
+                   "device_memory": "C-ABI allocator (shl_mi355x_malloc)",
                    "ops_per_image": ops_per_image, "algorithmic_bytes_per_image": chain.total_bytes() // batch,
                    "device": arch.value.decode(), "compute_units": cus.value},
     }
 
-    if args.steps_only:
-        if rank == 0:
-            print(json.dumps(result))
+    def finish():
         chain.release()
         if dist:
             dist.barrier()
             dist.destroy_process_group()
-        return
+
+    if args.steps_only:
+        if rank == 0:
+            emit(result)
+        return finish()
+    env = dict(torch=torch, fe=fe, hip=hip, opt=opt, wl=wl, par=par, stream=stream, detail=args.detail, rank=rank, world=world)
     if rank == 0:
         per_layer = time_groups(chain, hip, opt, stream)
         roof, groups = summarise_kernels(chain, wl, per_layer, bound)
         roof["mfma_frac_info"] = (chain.total_ops() / sum(per_layer) / 1e12) / (
             I8_MFMA_PEAK_TOPS if args.dtype == "int8" else F16_MFMA_PEAK_TFLOPS)
         attach_traffic(roof, args.traffic_file or os.path.join(
-            os.path.dirname(os.path.abspath(__file__)), "profiles",
-            "traffic_%s_%s_%s_b%d.json" % (args.workload, args.dtype, layout, batch)))
+            ROOT, "profiles", "traffic_%s_%s_%s_b%d.json" % (args.workload, args.dtype, layout, batch)))
         result["roofline"] = roof
         result["kernels"] = {k: {"launches": v["launches"], "us_total": v["time"] * 1e6,
                                  "GBps": v["bytes"] / v["time"] / 1e9, "TOPs": v["ops"] / v["time"] / 1e12}
@@ -361,128 +497,112 @@ def main():
                 sys.stderr.write("%-52s %-32s %8.2f us %8.1f GB/s %8.2f TOP/s\n" % (
                     chain.unit_name(u), chain.unit_kernel_name(u), t * 1e6,
                     chain.unit_bytes(u) / t / 1e9, chain.unit_ops(u) / t / 1e12))
-        if world == 1 and args.workload == "mobilenetv1" and not args.no_configs:
-            # the other single-GPU configurations of BASELINE.json: per-layer graph timing (independent layers,
-            # every layer its own launch), each with the roofline of its dominant kernel
-            others = [
-                ("configs[2]", "resnet50 3x3 set int8 NCHW batch 128", wl.RESNET50_3X3, 128, "int8", "NCHW", "mfma", 3),
-                ("configs[2] (NHWC view)", "resnet50 3x3 set int8 NHWC batch 128", wl.RESNET50_3X3, 128, "int8", "NHWC", "mfma", 3),
-                ("configs[3]", "mobilenetv1 fp16 NCHW batch 1 (c906_mobilenetv1_f16 shapes)", wl.MOBILENETV1, 1, "f16", "NCHW", "hbm", 20),
-            ]
-            if args.extra:
-                others.append(("configs[1] (throughput view)", "mobilenetv1 int8 NHWC batch 128, every layer its own launch",
-                               wl.MOBILENETV1, 128, "int8", "NHWC", "hbm", 3))
-            result["configs"] = []
-            prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            for tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, reps_x in others:
-                hbm2 = TorchHBM(torch, torch.device("cuda", local_rank))
-                rc = wl.LayerChain(fe, hip, opt, layers_x, batch_x, hbm2.alloc, hbm2.upload, dtype=dtype_x,
-                                   layout=layout_x, seed=4321, chained=False)
-                rt = time_groups(rc, hip, opt, stream, reps=reps_x)
-                rroof, rgroups = summarise_kernels(rc, wl, rt, bound_x)
-                wname = "resnet50_3x3" if layers_x is wl.RESNET50_3X3 else "mobilenetv1"
-                attach_traffic(rroof, os.path.join(prof, "traffic_%s_%s_%s_b%d.json" % (wname, dtype_x, layout_x, batch_x)))
-                unit = "GOPS" if dtype_x == "int8" else "GFLOPS"
-                peak = I8_MFMA_PEAK_TOPS if dtype_x == "int8" else F16_MFMA_PEAK_TFLOPS
-                entry = {"baseline_config": tag, "workload": name, "metric": "conv_" + unit.lower(),
-                         "value": rc.total_ops() / sum(rt) / 1e9, "unit": unit,
-                         "images_per_sec": batch_x / sum(rt), "ms_per_pass": sum(rt) * 1e3,
-                         "dtype": "i8" if dtype_x == "int8" else "f16", "layers": len(layers_x),
-                         "mfma_frac_whole_set": rc.total_ops() / sum(rt) / 1e12 / peak,
-                         "roofline": rroof,
-                         "kernels": {k: {"launches": v["launches"], "us_total": v["time"] * 1e6,
-                                         "TOPs": v["ops"] / v["time"] / 1e12, "GBps": v["bytes"] / v["time"] / 1e9}
-                                     for k, v in rgroups.items()}}
-                result["configs"].append(entry)
-                if args.detail:
-                    sys.stderr.write("---- %s\n" % name)
-                    for u, t in enumerate(rt):
-                        sys.stderr.write("%-52s %-32s %8.2f us %8.1f GB/s %8.2f TOP/s\n" % (
-                            rc.unit_name(u), rc.unit_kernel_name(u), t * 1e6, rc.unit_bytes(u) / t / 1e9,
-                            rc.unit_ops(u) / t / 1e12))
-                rc.release()
-                del hbm2
-        if args.extra and args.workload == "mobilenetv1":
-            # serving view: independent batch-1 requests in flight on several streams of ONE GPU (the
-            # headline `value` is strictly one request at a time; a single chain leaves most CUs idle)
-            nstreams = 4
-            chains, streams = [], []
-            for k in range(nstreams):
-                hk = TorchHBM(torch, torch.device("cuda", local_rank))
-                ck = wl.LayerChain(fe, hip, opt, layers, batch, hk.alloc, hk.upload, dtype=args.dtype, layout=layout,
-                                   seed=1234, chained=chained, fuse=fuse)
-                sk = hip.shl_mi355x_stream_create()
-                ck.capture(sk)
-                chains.append((ck, hk))
-                streams.append(sk)
+    if args.workload == "mobilenetv1" and not args.no_configs and not sharded:
+        result["configs"] = []
+        if world == 1:
+            # the other single-GPU configurations of BASELINE.json
+            for tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, chained_x, steps_x in (
+                    ("configs[2]", "resnet50 3x3 set int8 NCHW batch 128", wl.RESNET50_3X3, 128, "int8", "NCHW", "mfma", False, 20),
+                    ("configs[2] (NHWC view)", "resnet50 3x3 set int8 NHWC batch 128", wl.RESNET50_3X3, 128, "int8", "NHWC", "mfma", False, 20),
+                    ("configs[3]", "mobilenetv1 fp16 NCHW batch 1 (c906_mobilenetv1_f16 shapes)", wl.MOBILENETV1, 1, "f16", "NCHW", "hbm", True, 50),
+                    ("configs[1] (throughput view)", "mobilenetv1 int8 NHWC batch 128, every layer its own launch", wl.MOBILENETV1, 128,
+                     "int8", "NHWC", "hbm", True, 20)):
+                try:
+                    result["configs"].append(measure_config(tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, chained_x, env, steps=steps_x))
+                except Exception as e:  # an entry that fails must not take the headline with it
+                    result["configs"].append({"baseline_config": tag, "workload": name, "error": repr(e)})
+        else:
+            # BASELINE configs[4] at this N: the ResNet-50 3x3 set (NCHW, as BASELINE names configs[2]) with a total batch
+            # of 128 N sharded over the ranks, rank 0's packed weights broadcast once (RCCL behind the C-ABI)
+            try:
+                e4 = measure_config("configs[4]", "resnet50 3x3 set int8 NCHW, total batch %d sharded over %d GPUs" % (128 * world, world),
+                                    wl.RESNET50_3X3, 128, "int8", "NCHW", "mfma", False, env, steps=20, dist=dist,
+                                    seed=4321 if rank == 0 else 777 + rank, bcast_from=not single_dev, total_batch=128 * world)
+                e4["scaling"] = "weak (128 images per GPU; batch 1024 at N = 8)"
+                result["configs"].append(e4)
+            except Exception as e:
+                result["configs"].append({"baseline_config": "configs[4]", "error": repr(e)})
+    if rank != 0:
+        return finish()
+    if args.extra and args.workload == "mobilenetv1":
+        # serving view: independent batch-1 requests in flight on several streams of ONE GPU (the
+        # headline `value` is strictly one request at a time; a single chain leaves most CUs idle)
+        nstreams = 4
+        chains, streams = [], []
+        for k in range(nstreams):
+            hk = CHbm(hip)
+            ck = wl.LayerChain(fe, hip, opt, layers, batch, hk.alloc, hk.upload, dtype=args.dtype, layout=layout,
+                               seed=1234, chained=chained, fuse=fuse)
+            sk = hip.shl_mi355x_stream_create()
+            ck.capture(sk)
+            chains.append((ck, hk))
+            streams.append(sk)
+        for ck, _ in chains:
+            ck.replay()
+        for sk in streams:
+            hip.shl_mi355x_stream_sync(sk)
+        reps = 100
+        t0 = time.perf_counter()
+        for _ in range(reps):
             for ck, _ in chains:
                 ck.replay()
-            for sk in streams:
-                hip.shl_mi355x_stream_sync(sk)
-            reps = 100
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                for ck, _ in chains:
-                    ck.replay()
-            for sk in streams:
-                hip.shl_mi355x_stream_sync(sk)
-            dt_c = time.perf_counter() - t0
-            result["concurrent_streams"] = {"streams": nstreams, "images_per_sec": nstreams * reps * batch / dt_c,
-                                            "note": "independent batch-1 chains on separate HIP streams of one GPU"}
-            for ck, _ in chains:
-                ck.release()
-            del chains
-            # whole model through csinn_session_run with HOST input / output tensors: H2D + one
-            # hipGraph replay (28 convs + avgpool + softmax) + D2H + sync per image
-            ms = wl.ModelSession(fe, pkg.API_MI355X, args.dtype, layout)
-            mode = opt.shl_mi355x_session_is_device_resident(ms.sess)
-            x = ms.synthetic_input(0)
-            for _ in range(10):
-                ms.run(x)
-            t0 = time.perf_counter()
-            reps = 200
-            for _ in range(reps):
-                ms.run(x)
-            dt_s = (time.perf_counter() - t0) / reps
-            result["end_to_end_session"] = {
-                "workload": "mobilenetv1 %s %s whole model via csinn_session_run, host tensors (PCIe-inclusive)" % (args.dtype, layout),
-                "images_per_sec": 1.0 / dt_s, "ms_per_image": dt_s * 1e3, "layers": ms.n_layers,
-                "device_mode": {0: "host-staged", 1: "device eager", 2: "device hipGraph"}[mode]}
-            ms.close()
-            # the same session with its input and output tensors in HBM (csinn_update_input / _output with
-            # device buffers): csinn_session_run only enqueues the captured graph; one sync at the end
-            hio = TorchHBM(torch, torch.device("cuda", local_rank))
-            d_in = hio.alloc(224 * 224 * 3 * (1 if args.dtype == "int8" else 2))
-            d_out = hio.alloc(1000 * (1 if args.dtype == "int8" else 2))
-            hio.upload(d_in, x)
-            msd = wl.ModelSession(fe, pkg.API_MI355X, args.dtype, layout, dev_in=d_in, dev_out=d_out)
-            sst = opt.shl_mi355x_session_stream(msd.sess)
-            for _ in range(10):
-                msd.run_async()
-            hip.shl_mi355x_stream_sync(sst)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                msd.run_async()
-            hip.shl_mi355x_stream_sync(sst)
-            dt_d = (time.perf_counter() - t0) / reps
-            result["session_device_io"] = {
-                "workload": "mobilenetv1 %s %s whole model via csinn_session_run, input/output tensors in HBM" % (args.dtype, layout),
-                "images_per_sec": 1.0 / dt_d, "ms_per_image": dt_d * 1e3, "layers": msd.n_layers,
-                "fused_pairs": opt.shl_mi355x_session_fused_pairs(msd.sess)}
-            msd.close()
-            del hio
-        if world > 1:  # the CPU baseline is a property of the node: measured by the N=1 run only
-            result["cpu_baseline"] = {"value": None, "unit": "GOPS", "cores": 0, "kind": "reference",
-                                      "sample": "measured by the N=1 run only"}
-        elif not args.no_cpu_baseline:
-            result["cpu_baseline"] = run_cpu_baseline(args)
-        else:
-            result["cpu_baseline"] = {"value": None, "unit": "GOPS", "cores": 0, "kind": "port", "sample": "skipped"}
-        print(json.dumps(result))
-    chain.release()
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        for sk in streams:
+            hip.shl_mi355x_stream_sync(sk)
+        dt_c = time.perf_counter() - t0
+        result["concurrent_streams"] = {"streams": nstreams, "images_per_sec": nstreams * reps * batch / dt_c,
+                                        "note": "independent batch-1 chains on separate HIP streams of one GPU"}
+        for ck, hk in chains:
+            ck.release()
+            hk.free_all()
+        del chains
+        # whole model through csinn_session_run with HOST input / output tensors: H2D + one
+        # hipGraph replay (28 convs + avgpool + softmax) + D2H + sync per image
+        ms = wl.ModelSession(fe, pkg.API_MI355X, args.dtype, layout)
+        mode = opt.shl_mi355x_session_is_device_resident(ms.sess)
+        x = ms.synthetic_input(0)
+        for _ in range(10):
+            ms.run(x)
+        t0 = time.perf_counter()
+        reps = 200
+        for _ in range(reps):
+            ms.run(x)
+        dt_s = (time.perf_counter() - t0) / reps
+        result["end_to_end_session"] = {
+            "workload": "mobilenetv1 %s %s whole model via csinn_session_run, host tensors (PCIe-inclusive)" % (args.dtype, layout),
+            "images_per_sec": 1.0 / dt_s, "ms_per_image": dt_s * 1e3, "layers": ms.n_layers,
+            "device_mode": {0: "host-staged", 1: "device eager", 2: "device hipGraph"}[mode]}
+        ms.close()
+        # the same session with its input and output tensors in HBM (csinn_update_input / _output with
+        # device buffers): csinn_session_run only enqueues the captured graph; one sync at the end
+        hio = CHbm(hip)
+        d_in = hio.alloc(224 * 224 * 3 * (1 if args.dtype == "int8" else 2))
+        d_out = hio.alloc(1000 * (1 if args.dtype == "int8" else 2))
+        hio.upload(d_in, x)
+        msd = wl.ModelSession(fe, pkg.API_MI355X, args.dtype, layout, dev_in=d_in, dev_out=d_out)
+        sst = opt.shl_mi355x_session_stream(msd.sess)
+        for _ in range(10):
+            msd.run_async()
+        hip.shl_mi355x_stream_sync(sst)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            msd.run_async()
+        hip.shl_mi355x_stream_sync(sst)
+        dt_d = (time.perf_counter() - t0) / reps
+        result["session_device_io"] = {
+            "workload": "mobilenetv1 %s %s whole model via csinn_session_run, input/output tensors in HBM" % (args.dtype, layout),
+            "images_per_sec": 1.0 / dt_d, "ms_per_image": dt_d * 1e3, "layers": msd.n_layers,
+            "fused_pairs": opt.shl_mi355x_session_fused_pairs(msd.sess)}
+        msd.close()
+        hio.free_all()
+    if world > 1:  # the CPU baseline is a property of the node: measured by the N=1 run only
+        result["cpu_baseline"] = {"value": None, "unit": "GOPS", "cores": 0, "kind": "reference",
+                                  "sample": "measured by the N=1 run only"}
+    elif not args.no_cpu_baseline:
+        result["cpu_baseline"] = run_cpu_baseline(args)
+    else:
+        result["cpu_baseline"] = {"value": None, "unit": "GOPS", "cores": 0, "kind": "port", "sample": "skipped"}
+    emit(result)
+    finish()
 
 
 if __name__ == "__main__":

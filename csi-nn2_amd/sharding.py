@@ -69,6 +69,14 @@ def broadcast_blocks(sizes, read_block, write_block, new_buffer, dist, src=0, bu
     return issued
 
 
+def _control_device(dist):
+    """where the small control tensors of a collective live: the GPU for an nccl group, the host for gloo"""
+    try:
+        return "cuda" if dist.get_backend() == "nccl" else "cpu"
+    except Exception:
+        return "cpu"
+
+
 def broadcast_plan_blocks(chain, torch, dist, hip, src=0):
     """RCCL broadcast of every layer's constant block of `chain` (workloads.LayerChain)."""
     blocks = chain.const_blocks()
@@ -103,20 +111,21 @@ def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c
     description of the path taken."""
     import ctypes as C
     why = "disabled"
+    ctl = _control_device(dist)  # the process group is bootstrap only: small CPU tensors under gloo
     if prefer_c:
-        ok = torch.tensor([int(hip.shl_mi355x_comm_available())], dtype=torch.int32, device="cuda")
+        ok = torch.tensor([int(hip.shl_mi355x_comm_available())], dtype=torch.int32, device=ctl)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         why = "librccl not found on every rank"
         if int(ok.item()) == 1:
             uid = (C.c_ubyte * 128)()
             if rank == src and hip.shl_mi355x_comm_unique_id(uid) != 0:
                 raise RuntimeError("ncclGetUniqueId failed: " + hip.shl_mi355x_last_error().decode())
-            t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=ctl)
             dist.broadcast(t, src=src)
             uid = (C.c_ubyte * 128)(*t.cpu().tolist())
             comm = C.c_void_p()
             rc = hip.shl_mi355x_comm_create(uid, rank, world, C.byref(comm))
-            good = torch.tensor([int(rc == 0)], dtype=torch.int32, device="cuda")
+            good = torch.tensor([int(rc == 0)], dtype=torch.int32, device=ctl)
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
             if int(good.item()) == 1:
                 n = len(chain.entries)
@@ -125,7 +134,7 @@ def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c
                 hip.shl_mi355x_comm_destroy(comm)
                 if rc != 1:
                     raise RuntimeError("shl_mi355x_bcast_const_blocks failed: " + hip.shl_mi355x_last_error().decode())
-                return "RCCL ncclBroadcast behind the C-ABI (shl_mi355x_bcast_const_blocks), %d blocks in one group" % n
+                return "RCCL ncclBroadcast behind the C-ABI (shl_mi355x_bcast_const_blocks), %d blocks in one group, communicator of ranks 0..%d" % (n, world - 1)
             if comm:
                 hip.shl_mi355x_comm_destroy(comm)
             why = "ncclCommInitRank failed on some rank: " + hip.shl_mi355x_last_error().decode()
@@ -136,6 +145,29 @@ def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c
     if opt.shl_mi355x_params_adopt_blocks(params, cnt, chain.sess) != 1:
         raise RuntimeError("shl_mi355x_params_adopt_blocks failed: " + hip.shl_mi355x_last_error().decode())
     return "torch.distributed broadcast, %d buckets (%s)" % (n, why)
+
+
+def broadcast_weights_one_rank(chain, hip, opt):
+    """All of the C / RCCL path that ONE process can exercise: ncclGetUniqueId -> ncclCommInitRank(world 1) ->
+    shl_mi355x_bcast_const_blocks over the chain's plans -> adoption of the flags records -> destroy.  Used by
+    `bench.py --total-batch B` on a single GPU, so that the sharded configuration runs through the same entry points a
+    multi-GPU launch takes."""
+    import ctypes as C
+    if hip.shl_mi355x_comm_available() != 1:
+        return "no librccl on this box: " + hip.shl_mi355x_last_error().decode()
+    uid = (C.c_ubyte * 128)()
+    if hip.shl_mi355x_comm_unique_id(uid) != 0:
+        raise RuntimeError("ncclGetUniqueId failed: " + hip.shl_mi355x_last_error().decode())
+    comm = C.c_void_p()
+    if hip.shl_mi355x_comm_create(uid, 0, 1, C.byref(comm)) != 0:
+        raise RuntimeError("ncclCommInitRank failed: " + hip.shl_mi355x_last_error().decode())
+    n = len(chain.entries)
+    params = (C.c_void_p * n)(*[C.cast(e["params"], C.c_void_p) for e in chain.entries])
+    rc = opt.shl_mi355x_bcast_const_blocks(comm, params, n, 0, chain.sess)
+    hip.shl_mi355x_comm_destroy(comm)
+    if rc != 1:
+        raise RuntimeError("shl_mi355x_bcast_const_blocks failed: " + hip.shl_mi355x_last_error().decode())
+    return "RCCL ncclBroadcast behind the C-ABI (shl_mi355x_bcast_const_blocks), %d blocks in one group, communicator of rank 0 alone" % n
 
 
 def checksum_bytes(arr):
@@ -161,7 +193,7 @@ def assert_replicas_agree(chain, torch, dist, hip):
         hip.shl_mi355x_download(out.ctypes.data, e["d_out"], out.nbytes, None)
         hip.shl_mi355x_stream_sync(None)
         sums.append(checksum_bytes(out))
-    mine = torch.tensor(sums, dtype=torch.int64, device="cuda")
+    mine = torch.tensor(sums, dtype=torch.int64, device=_control_device(dist))
     lo, hi = mine.clone(), mine.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
