@@ -522,25 +522,29 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     }
     // NCHW: (image, offset inside its plane) of the lane's first pixel of block 0 -- one exact division, then
     // advanced by 32 pixels per block
-    uint32_t e_n = 0, e_rem = 0;
+    uint32_t e_rem = 0;
+    // address of the lane's first output of block 0, advanced by 32 pixels per block.  NHWC: its 16 channels of a pixel.
+    // NCHW: its 16 pixels of a channel plane; an image boundary adds the other Co - 1 planes of the image
+    char *e_ptr = out;
     if constexpr (kNchw) {
         const uint32_t m00 = (uint32_t)(pixbase + hb * 32 + fhalf * 16);
-        e_n = pt_div(m00, HW, a.pt_rHW);
+        const uint32_t e_n = pt_div(m00, HW, a.pt_rHW);
         e_rem = m00 - m24(e_n, HW);
+        e_ptr = out + ((int64_t)(m24(e_n, a.Co) + (uint32_t)(ocb * 32 + frow)) * HW + e_rem);
+    } else {
+        e_ptr = out + (int64_t)(pixbase + hb * 32 + frow) * a.Co + (ocb * 32 + fhalf * 16);
     }
-    char *e_ptr = out;  // NHWC: address of the lane's 16 channels of its pixel of block 0, advanced by 32 pixels per block
-    if constexpr (!kNchw) e_ptr = out + (int64_t)(pixbase + hb * 32 + frow) * a.Co + (ocb * 32 + fhalf * 16);
-    const int64_t e_step = (int64_t)32 * a.Co;
+    const int64_t e_step = kNchw ? 32 : (int64_t)32 * a.Co;
+    const int64_t e_wrap = (int64_t)(a.Co - 1) * HW;
     auto advance = [&]() {
+        e_ptr += e_step;
         if constexpr (kNchw) {
             e_rem += 32;
             if (HW >= 32) {  // wave-uniform: one image boundary at most
-                if (e_rem >= (uint32_t)HW) e_rem -= HW, ++e_n;
+                if (e_rem >= (uint32_t)HW) e_rem -= HW, e_ptr += e_wrap;
             } else {
-                while (e_rem >= (uint32_t)HW) e_rem -= HW, ++e_n;
+                while (e_rem >= (uint32_t)HW) e_rem -= HW, e_ptr += e_wrap;
             }
-        } else {
-            e_ptr += e_step;
         }
     };
     auto finalize = [&](int j, const v16i &c) {
@@ -562,9 +566,18 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             const int oc = ocb * 32 + frow;
             const int pl0 = (hb + j) * 32 + fhalf * 16;
             const int m0 = pixbase + pl0;
-            if (!ocb_ok || oc >= a.Co || pl0 >= RW || m0 >= a.M) return;
-            char *dst = out + ((int64_t)(m24(e_n, a.Co) + oc) * HW + e_rem);
+            const bool live = ocb_ok && oc < a.Co && pl0 < RW && m0 < a.M;
             const bool full = pl0 + 16 <= RW && m0 + 16 <= a.M;
+            char *dst = e_ptr;
+            // the common case decided ONCE per wave: every lane stores 16 pixels of one plane (whatever the byte address).
+            // The general code below is ~220 instructions per block, with its dozen lane-mask branches even when no
+            // lane takes them -- three times the requantisation itself
+            if (__builtin_amdgcn_ballot_w64(!(live && full && e_rem + 16 <= (uint32_t)HW)) == 0) {
+                const pt_u4 t4 = {v.x, v.y, v.z, v.w};
+                *reinterpret_cast<pt_u4 *>(dst) = t4;
+                return;
+            }
+            if (!live) return;
             const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
             if (full && e_rem + 16 <= (uint32_t)HW) {  // 16 pixels of one plane
                 const pt_u4 t4 = {v.x, v.y, v.z, v.w};
