@@ -12,7 +12,7 @@ timeout 600 python bench.py --detail > "$OUT/bench_line.json" 2> "$OUT/bench_det
 timeout 900 python bench.py --extra --no-cpu-baseline > "$OUT/bench_line_extra.json" 2> /dev/null
 cd /tmp
 # ---- headline
-timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o t -- python "$REPO/bench.py" --no-cpu-baseline --no-configs > "$OUT/prof.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o t -- python "$REPO/bench.py" --no-cpu-baseline > "$OUT/prof.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o t -- python "$REPO/bench.py" --steps-only --steps 20 --warmup 2 --windows 1 > "$OUT/pmc_fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o t -- python "$REPO/bench.py" --steps-only --steps 20 --warmup 2 --windows 1 > "$OUT/pmc_write.log" 2>&1
 # ---- configs[2]: ResNet-50 3x3, batch 128, both layouts

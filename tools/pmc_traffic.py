@@ -20,6 +20,7 @@ import sys
 FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kernel name)
     ("conv_igemm_wave_kernel<true", "conv_igemm_wave_i8_mfma32x32x32"),
     ("conv_igemm_wave_kernel<false", "conv_igemm_wave_f16_mfma32x32x16"),
+    ("conv_igemm_patch_kernel", "conv_igemm_patch_i8_mfma32x32x32"),
     ("conv_igemm_pc_kernel<true", "conv_igemm_pc_i8_mfma32x32x32"),
     ("conv_igemm_pc_kernel<false", "conv_igemm_pc_f16_mfma32x32x16"),
     ("conv_igemm_pcx_kernel<true", "conv_igemm_pc_i8_mfma32x32x32"),
