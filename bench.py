@@ -83,14 +83,9 @@ def parse_args():
     ap.add_argument("--traffic-file", default="",
                     help="JSON from tools/pmc_traffic.py (default profiles/traffic_<workload>_<dtype>_<layout>_b<batch>.json)")
     args = ap.parse_args()
-    # ROCm 7.2: `rocprofv3 --kernel-trace` dies in hipGraphLaunch once ~4 MiB of graph kernel arguments have been
-    # replayed (tools/probes/graph_replay.hip: 15 kernels x 400 B, 500 replays fine, 1000 SIGSEGV).  With a profiler
-    # attached the timed windows are cut so that the whole run stays below that; the profile is after per-kernel
-    # durations, not after the throughput of the profiled run
-    args.profiler = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
-    if args.profiler and args.workload == "mobilenetv1" and not args.steps_only:
-        while args.windows > 1 and args.warmup + args.windows * args.steps > 450:
-            args.windows -= 1
+    # with a profiler attached every pass is launched kernel by kernel instead of as a graph replay
+    # (workloads.PROFILER_ATTACHED: rocprofv3 --kernel-trace of ROCm 7.2 crashes in hipGraphLaunch)
+    args.profiler = any(k.startswith(("ROCPROF_", "ROCP_TOOL")) for k in os.environ)
     return args
 
 
@@ -244,6 +239,9 @@ def timed_windows(replay, sync, steps, warmup, windows, dist=None, torch=None):
     return out
 
 
+PROFILER = any(k.startswith(("ROCPROF_", "ROCP_TOOL")) for k in os.environ)
+
+
 def time_groups(chain, hip, opt, stream, reps=20):
     """Average duration of every launch of one pass (a layer, or a fused pointwise + depthwise pair),
     measured with HIP events recorded on the launch stream around `reps` back-to-back launches of it
@@ -253,6 +251,17 @@ def time_groups(chain, hip, opt, stream, reps=20):
     ms = C.c_float()
     for u in range(len(chain.units)):
         opt.shl_mi355x_set_stream(stream)
+        if PROFILER:  # no graphs under rocprofv3 (workloads.PROFILER_ATTACHED)
+            best = []
+            for _ in range(2):
+                hip.shl_mi355x_event_record(ev0, stream)
+                for _ in range(reps):
+                    chain.run_unit(u)
+                hip.shl_mi355x_event_record(ev1, stream)
+                hip.shl_mi355x_event_elapsed_ms(ev0, ev1, C.byref(ms))
+                best.append(ms.value / reps)
+            out.append(min(best) * 1e-3)
+            continue
         hip.shl_mi355x_graph_begin(stream)
         for _ in range(reps):
             chain.run_unit(u)
@@ -519,7 +528,7 @@ def main():
                      "int8", "NHWC", "hbm", True, 20)):
                 try:
                     result["configs"].append(measure_config(tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, chained_x, env, steps=steps_x,
-                                                            windows=1 if args.profiler else 5))
+                                                            windows=5))
                 except Exception as e:  # an entry that fails must not take the headline with it
                     result["configs"].append({"baseline_config": tag, "workload": name, "error": repr(e)})
         else:

@@ -14,7 +14,6 @@ CSINN_MI355X), runs them with csinn_* calls, and can capture the whole chain in 
 the C-ABI so that a replay contains no host work.
 """
 import ctypes as C
-
 import os
 
 import numpy as np
@@ -22,6 +21,14 @@ import numpy as np
 from . import (ACT_NONE, ACT_RELU, API_MI355X, CSINN_TRUE, DTYPE_FLOAT16, DTYPE_INT8, DTYPE_INT32,
                LAYOUT_1HWO, LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_O, LAYOUT_O1HW, LAYOUT_OHWI,
                LAYOUT_OIHW, Keep, MI355XError, check, conv_params, layer_session, make_tensor)
+
+
+# ROCm 7.2: `rocprofv3 --kernel-trace` dies inside hipGraphLaunch once ~4 MiB of graph kernel arguments have been
+# replayed in a process (tools/probes/graph_replay.hip: 15 kernels x 400 B -- 500 replays pass, 1 000 SIGSEGV; the
+# bundled ROCm 7.0 runtime of the torch wheel does not).  With a profiler attached the passes are therefore launched
+# kernel by kernel on the same stream: the same kernels with the same arguments, only the host gaps differ -- a profile
+# is after per-kernel durations, not after the throughput of the profiled run.
+PROFILER_ATTACHED = any(k.startswith(("ROCPROF_", "ROCP_TOOL")) for k in os.environ)
 
 
 def _conv(cin, cout, hw, k, s, dw=False, act=ACT_RELU):
@@ -245,6 +252,9 @@ class LayerChain:
         return g
 
     def replay(self):
+        if PROFILER_ATTACHED:  # the same launches without the graph (see PROFILER_ATTACHED)
+            self.opt.shl_mi355x_set_stream(self.stream)
+            return self.run_eager()
         check(self.hip.shl_mi355x_graph_launch(self.graph, self.stream), self.hip, "graph_launch")
 
     # ---- accounting ---------------------------------------------------------------------------
