@@ -76,6 +76,8 @@ struct ConvArgs {
     int32_t pt_rows;      // output rows per pixel group (rows * Wo <= 416)
     int32_t pt_prows;     // patch rows per buffer (capacity over all tiles)
     int32_t pt_bufb;      // bytes per patch buffer
+    int32_t pt_pair_in;   // pair mode (single-stage layers, two rounds of tiles): byte offset of the second tile's input ...
+    int32_t pt_pair_pix;  // ... and of its output pixels (whole images further on); 0 = one tile per workgroup
     int32_t pt_nitc;      // NCHW staging: iterations of 256 (run segment, 16-channel group) items per stage
     int32_t pt_spr;       // NCHW staging: 16-byte segments per image run
     int32_t pt_ntm;       // row tiles

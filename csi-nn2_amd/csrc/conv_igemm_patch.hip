@@ -37,665 +37,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <type_traits>
-
-#include "dw_mfma.h"
-#include "igemm_common.h"
+#include "conv_igemm_patch_kernel.h"
 
 namespace shl {
-
-constexpr int PT_NB = 13;                // MFMA pixel blocks (32 pixels) per wave
-constexpr int PT_PIX = PT_NB * 32;       // 416
-constexpr int PT_D = 7;                  // B fragments are read this many MFMAs ahead (ring of 8)
-constexpr int PT_TRASH = 4096;           // LDS bytes that swallow the writes of invalid staging items (16 B per lane)
-constexpr int PT_NIT = 16;               // NHWC staging: 16-byte items per lane per stage
-constexpr int PT_TABLES = 4096;          // row tables of the prologue (behind the trash area)
-constexpr int PT_LDS_MAX = 160 * 1024;
-
-#define PT_KC(g) ((g) & 0xff)
-#define PT_PG(g) (((g) >> 8) & 0xf)
-#define PT_OB(g) (((g) >> 12) & 0xf)
-#define PT_KP(g) (((g) >> 16) & 0xf)
-#define PT_NW8(g) (((g) >> 20) & 1)  // eight waves (two per SIMD) instead of four
-
-// x / d for x < 2^22 (q is within one of the quotient after the float multiply)
-__device__ __forceinline__ uint32_t pt_div(uint32_t x, uint32_t d, float rcp)
-{
-    uint32_t q = (uint32_t)(__uint2float_rn(x) * rcp);
-    const int32_t r = (int32_t)(x - __umul24(q, d));  // operands < 2^22
-    if (r < 0)
-        --q;
-    else if ((uint32_t)r >= d)
-        ++q;
-    return q;
-}
-
-__device__ __forceinline__ uint32_t m24(uint32_t x, uint32_t y) { return __umul24(x, y); }  // full-rate multiply (v_mul_lo_u32 is quarter rate)
-
-__device__ __forceinline__ void pt_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-typedef uint32_t pt_u4 __attribute__((ext_vector_type(4), aligned(1)));  // 16 bytes at any byte address
-
-// SHL_MI355X_DEBUG=32: wave 0 of workgroup 0 stamps s_memtime at its phase boundaries (tools/pp_trace.py --patch)
-__device__ unsigned long long g_pt_trace[64];
-__device__ unsigned long long g_pt_span[2 * 1024];  // SHL_MI355X_DEBUG=32: [start, end] of wave 0 of every workgroup (s_memrealtime, 100 MHz)
-
-// NW = 4: four waves of 13 pixel blocks, one per SIMD.  NW = 8: two waves per SIMD, the 13 blocks of a (pixel group,
-// channel block, K part) split 7 + 6 between them (half h; NBW = this wave's blocks): the prologue and the epilogue are
-// long dependent scalar / VALU chains that a wave alone on its SIMD runs at ~6 cycles per instruction, and they are
-// half as long per wave and interleave with the partner's.  At most 256 registers per wave then: 7 x 16 accumulators.
-template <int EPI, bool kNchw, int KC, int PG, int OB, int KP, int NW, int NBW>
-__device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, const int h)
-{
-    int trace_k = 0;
-    auto mark = [&]() {
-        if ((a.debug & 32) && blockIdx.x == 0 && threadIdx.x == 0 && trace_k < 64) g_pt_trace[trace_k++] = __builtin_amdgcn_s_memtime();
-    };
-    mark();
-    if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-    static_assert(PG * OB * KP == 4, "four wave roles");
-    static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
-    constexpr int NB = NBW;                  // MFMA pixel blocks of this wave
-    constexpr int HB = NW == 8 ? 7 : 0;      // blocks of half 0 in front of half 1's
-    constexpr int D = NB >= 13 ? PT_D : 4;   // B fragments are read this many MFMAs ahead
-    constexpr int NT = NW * 64;              // threads
-    constexpr int NIT = PT_NIT * 4 / NW;     // NHWC staging items per lane and stage
-    constexpr int CI = NW == 8 ? 8 : 16;     // NCHW staging: channels per item
-    constexpr int NP = kNchw ? CI : NIT;     // staging pieces per round (loads, and again writes)
-    constexpr bool kTwo = kNchw && NW == 4;  // NCHW staging may take a second round of items (eight waves: the host
-                                             // falls back to four when one round does not cover a stage)
-    constexpr int FR = (NW == 8 && kNchw) ? 3 : 9;  // weight fragment ring (256 registers per wave: NCHW staging needs the rest)
-    constexpr int U = KC / 32;          // 32-byte K sub-steps per tap and stage
-    constexpr int UI = U / KP;          // ... of which this wave takes every KP-th
-    constexpr int NSTEP = 9 * UI;       // K steps (13 MFMAs each) per stage and wave
-    constexpr int NF = NSTEP * NB;      // MFMAs per stage and wave
-    constexpr int PITCH = KC + 16;
-    constexpr int SLOTS = KC / 16;
-    constexpr int CG = KC / CI;         // channel groups per stage (NCHW staging)
-    static_assert(U % KP == 0, "K parts split the sub-steps of a tap");
-    static_assert(NSTEP % 9 == 0, "weight fragment ring of nine");
-    // every kernel argument the kernel will ever read, requested NOW in one batch: left to the compiler the scalar
-    // loads are sunk to their first uses, and each of the half dozen groups then costs its own 500 - 1 000 cycles of
-    // argument-segment latency in a prologue that nothing overlaps
-#define PT_PIN(x) asm volatile("" ::"s"(x))
-    PT_PIN(a.in); PT_PIN(a.out); PT_PIN(a.w_patch); PT_PIN(a.acc_init); PT_PIN(a.mult); PT_PIN(a.bias);
-    PT_PIN(a.N); PT_PIN(a.H); PT_PIN(a.W); PT_PIN(a.C); PT_PIN(a.Co); PT_PIN(a.M); PT_PIN(a.in_zp);
-    PT_PIN(a.pt_rows); PT_PIN(a.pt_prows); PT_PIN(a.pt_bufb); PT_PIN(a.pt_nitc); PT_PIN(a.pt_spr); PT_PIN(a.pt_ntm);
-    PT_PIN(a.pt_rW); PT_PIN(a.pt_rH); PT_PIN(a.pt_rH1); PT_PIN(a.pt_rspr); PT_PIN(a.pt_rntn);
-    PT_PIN(a.out_scale); PT_PIN(a.inv_out_scale); PT_PIN(a.out_zp_f); PT_PIN(a.out_zp); PT_PIN(a.clamp_lo); PT_PIN(a.clamp_hi);
-#undef PT_PIN
-    const int tid = threadIdx.x, lane = tid & 63, frow = lane & 31, fhalf = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wv = NW == 8 ? wave >> 1 : wave;  // role: (pixel group, channel block, K part)
-    const int kp = wv % KP, ob = (wv / KP) % OB, pg = wv / (KP * OB);
-    const int hb = h * HB;                      // first pixel block of this wave inside the pixel group
-    const int W = a.W, H = a.H, W1 = W + 1, H1 = H + 1, HW = H * W;
-    const int R = a.pt_rows, TR = PG * R, RW = R * W;
-    const int total_rows = a.N * H;
-    const int ocblks = (a.Co + 31) >> 5;
-    const int nt_n = (ocblks + OB - 1) / OB;
-    const int nt_m = a.pt_ntm;  // (total_rows + TR - 1) / TR, from the host: every integer division here is ~40 instructions
-    // XCD-aware order: one XCD walks all channel tiles of a run of row tiles -- its L2 fetches every input row
-    // once, the (small) weight tensor once per XCD
-    const int t = xcd_contiguous_block(blockIdx.x, nt_n * nt_m);
-    const int tile_m = (int)pt_div((uint32_t)t, nt_n, a.pt_rntn), tile_n = t - tile_m * nt_n;
-    const int row0 = tile_m * TR;  // first output row (n * H + y) of the tile
-    int ocb = tile_n * OB + ob;
-    const bool ocb_ok = ocb < ocblks;
-    if (!ocb_ok) ocb = ocblks - 1;
-    const int nstg = a.C / KC;
-    const uint32_t bufb = (uint32_t)a.pt_bufb;
-    const float rW = a.pt_rW, rH = a.pt_rH, rH1 = a.pt_rH1;  // reciprocals from the host (a division is ~12 instructions)
-    // "virtual" rows: every image is followed by ONE padding row (bottom halo of its last row = top halo of the
-    // next image's first row): v(g) = g + g / H.  Patch row pr holds virtual row v0 + pr.
-    const int v0 = row0 + (int)pt_div((uint32_t)row0, H, rH) - 1;
-    const int last_row = (row0 + TR < total_rows ? row0 + TR : total_rows) - 1;
-    const int prows = last_row + (int)pt_div((uint32_t)last_row, H, rH) - v0 + 2;
-
-    mark();  // 1: tile decoded
-    // ---- weights: this wave's fragment stream, 1 KiB per K step; a ring of nine fragments = eight steps
-    // (~3 300 cycles) of look-ahead: vector loads return in order, so a weight load issued behind the next stage's
-    // staging loads (HBM latency) or behind a first touch of the weights is late by that much
-    const char *wsb = static_cast<const char *>(a.w_patch) + ((size_t)(ocb * KP + kp) * nstg * NSTEP) * 1024;
-    const int wl = lane * 16;
-    v4i fa[FR];
-#pragma unroll
-    for (int q = 0; q < FR - 1; ++q) fa[q] = *reinterpret_cast<const v4i *>(wsb + q * 1024 + wl);
-
-    mark();  // 2: weight loads issued
-    // ---- row tables in LDS (one division per ROW instead of two per staging item and pixel block):
-    //   prow_tab[pr]  patch row pr  -> byte offset of input row (n, y) in an NHWC tensor, or -1 (a padding row)
-    //   trow_tab[r]   tile row r    -> its patch row
-    //   inv_tab[i]    the padding rows of the patch, compacted (count in inv_cnt)
-    int32_t *const prow_tab = reinterpret_cast<int32_t *>(smem + 2 * bufb + PT_TRASH);             // <= 512 rows
-    uint16_t *const trow_tab = reinterpret_cast<uint16_t *>(smem + 2 * bufb + PT_TRASH + 2048);    // <= 512 rows
-    uint16_t *const inv_tab = reinterpret_cast<uint16_t *>(smem + 2 * bufb + PT_TRASH + 3072);     // <= 256 rows
-    int32_t *const inv_cnt = reinterpret_cast<int32_t *>(smem + 2 * bufb + PT_TRASH + 3584);
-    // epilogue tables of the four waves (written after the row tables are dead): 32 multipliers + 32 biases each
-    float *const epi_tab = reinterpret_cast<float *>(smem + 2 * bufb + PT_TRASH) + wv * 96;
-    // requested now, used at the very end
-    const float t_mult = a.mult[ocb * 32 + frow], t_bias = a.bias[ocb * 32 + frow];
-    const int32_t t_acc = a.acc_init[ocb * 32 + frow];
-    if (wave == 0) {
-        int ninv = 0;
-        for (int pr = lane; pr < ((a.pt_prows + 63) & ~63); pr += 64) {
-            const int v = v0 + pr;
-            const uint32_t vv = v < 0 ? 0 : (uint32_t)v;
-            const uint32_t n = pt_div(vv, H1, rH1), y = vv - n * H1;
-            const bool in_patch = pr < a.pt_prows;
-            const bool ok = pr < prows && v >= 0 && y < (uint32_t)H && n < (uint32_t)a.N;
-            if (in_patch) prow_tab[pr] = ok ? (int32_t)(m24(m24(n, H) + y, W) * (kNchw ? 1 : a.C)) : -1;
-            const uint64_t bad = __ballot(in_patch && !ok);
-            if (in_patch && !ok) inv_tab[ninv + __popcll(bad & ((1ull << lane) - 1))] = (uint16_t)pr;
-            ninv += __popcll(bad);
-        }
-        if (lane == 0) *inv_cnt = ninv;
-    } else {
-        for (int r = tid - 64; r < TR; r += NT - 64) {
-            const uint32_t g = (uint32_t)row0 + r;
-            trow_tab[r] = (uint16_t)(g + pt_div(g, H, rH) - (uint32_t)v0);
-        }
-    }
-    mark();  // 3: row tables written
-    pt_barrier();
-    mark();  // 4: barrier
-
-    // ---- staging items of this lane (the same for every stage) -------------------------------------------
-    // NHWC: item = (patch pixel, 16-byte slot); NCHW: item = (image run, 16-channel group, 16-pixel segment)
-    constexpr int NSRC = kNchw ? (kTwo ? 2 : 1) : NIT;
-    constexpr int NDST = kNchw ? (kTwo ? 32 : 16) : NIT;
-    uint32_t s_src[NSRC], s_dst[NDST];
-    const uint32_t trash = 2 * bufb + lane * 16 + (wave & 3) * 1024;
-    if constexpr (!kNchw) {
-        constexpr int PS = NT / SLOTS;  // pixels between a lane's consecutive items
-        const uint32_t slot = tid % SLOTS;
-        uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - m24(pr, W);
-        const uint32_t dpr = pt_div(PS, W, rW), dx = PS - m24(dpr, W);
-        const uint32_t last = (uint32_t)a.pt_prows - 1;
-        // all sixteen table reads first (one LDS round trip instead of sixteen), no branches: rows past the patch read
-        // the table's last entry and are dropped by the comparison
-        int32_t row[NIT];
-        uint32_t prs[NIT], xs[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            prs[it] = pr, xs[it] = x;
-            row[it] = prow_tab[pr < last ? pr : last];
-            x += dx, pr += dpr;
-            if (x >= (uint32_t)W) x -= W, ++pr;
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const bool ok = row[it] >= 0 && prs[it] <= last;
-            s_src[it] = ok ? (uint32_t)row[it] + m24(xs[it], a.C) + slot * 16 : 0;
-            s_dst[it] = ok ? m24(m24(prs[it], W1) + xs[it] + 1, PITCH) + slot * 16 : trash;
-        }
-    } else {
-        // first image with rows in the patch: virtual row v0 is image v0 / (H + 1)'s -- unless it is that image's
-        // padding row, then the next one's
-        const uint32_t nf = pt_div((uint32_t)(v0 + 1), H1, rH1);
-        const uint32_t spr = (uint32_t)a.pt_spr;
-        const float rspr = a.pt_rspr;
-        const int total = a.N * a.C * HW;  // < 2^31 (checked on the host)
-        if constexpr (kTwo) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s_dst[16 + q] = trash;
-            s_src[1] = 0;
-        }
-#pragma unroll
-        for (int it = 0; it < (kTwo ? 2 : 1); ++it) {
-            if (it == 1 && a.pt_nitc < 2) break;  // wave-uniform: the second round exists for few shapes only
-            // consecutive lanes = consecutive 16-byte segments of one channel's run: a wave-level load touches a few
-            // whole lines (with the channel group fastest every lane had a line of its own: 350 cycles per instruction)
-            const uint32_t item = it * NT + tid;
-            const uint32_t rest = pt_div(item, spr, rspr), seg = item - rest * spr;
-            const uint32_t cg = rest % CG, run = rest / CG;
-            const uint32_t n = nf + run;
-            // rows [ya, yb] of image n inside the patch's virtual rows [v0, v0 + prows - 1]
-            const int lo = (int)m24(n, H1), hi = lo + H - 1;
-            const int va = v0 > lo ? v0 : lo, vb = v0 + prows - 1 < hi ? v0 + prows - 1 : hi;
-            const bool run_ok = it < a.pt_nitc && n < (uint32_t)a.N && vb >= va;
-            const int ya = va - lo, runlen = run_ok ? (int)m24(vb - va + 1, W) : 0;
-            int k0 = (int)seg * 16;
-            // byte offset of (image n, channel cg * 16, row ya, pixel k0) in the NCHW tensor; the window of the LAST
-            // channel of the LAST stage must end inside the tensor: slide the window back (its first bytes then
-            // belong to pixels in front of the segment and are dropped)
-            int off = (int)m24(m24(n, a.C) + cg * CI, HW) + (int)m24(ya, W) + k0;
-            const int over = run_ok ? off + (a.C - KC + CI - 1) * HW + 16 - total : 0;
-            if (over > 0) {
-                off -= over;
-                k0 -= over;
-            }
-            if (!run_ok || off < 0) off = 0;
-            s_src[it] = (uint32_t)off;
-            // pixel k of the run is patch pixel (row lo + ya + k / W - v0, k % W): one division, then increments
-            const uint32_t kf = k0 < 0 ? 0u : (uint32_t)k0;
-            uint32_t yy = pt_div(kf, W, rW), x = kf - yy * W;
-            const uint32_t pr0 = (uint32_t)(lo + ya - v0);
-#pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int k = k0 + b;
-                const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
-                s_dst[it * 16 + b] = ok ? m24(m24(pr0 + yy, W1) + x + 1, PITCH) + cg * CI : trash;
-                if (k >= 0) {
-                    if (++x == (uint32_t)W) x = 0, ++yy;
-                }
-            }
-        }
-    }
-
-    // ---- staging of one stage, cut into NP pieces so that the K loop can place them one per MFMA slot:
-    // NHWC sd[q] = item q's 16 bytes; NCHW sd[c] = 16 pixels of channel c of the lane's channel group
-    v4i sd[NP];
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.in), 0, 0x7fffffff, 0x00020000);
-    uint32_t tr_o[4][CI / 4];  // NCHW: the four pixels of one dword column, transposed
-    auto stage_load_one = [&](int stage, int it, auto qc) {
-        constexpr int q = decltype(qc)::value;
-        // NHWC: buffer loads (descriptor + 32-bit lane offset + scalar stage offset): as plain global loads the
-        // optimiser turns the loop-invariant lane offsets into 64-bit pointers held across the K loop
-        if constexpr (!kNchw) {
-            sd[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)s_src[q], stage * KC, 0));
-        } else {
-            const char *base = static_cast<const char *>(a.in) + (size_t)stage * KC * HW;
-            const uint32_t o = (!kTwo || it == 0) ? s_src[0] : s_src[NSRC - 1];
-            sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * HW))));
-        }
-    };
-    auto stage_write_one = [&](uint32_t bufoff, int it, auto qc) {
-        constexpr int q = decltype(qc)::value;
-        if constexpr (!kNchw) {
-            const uint32_t d = s_dst[q];
-            *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = sd[q];
-        } else {
-            // piece q = (dword column jd, channel quad ca): one 4 x 4 byte block of the CI channels x 16 pixels ->
-            // 16 pixels x CI channels transposition; after the last quad the column's four pixels go out
-            constexpr int QC = CI / 4;
-            constexpr int jd = q / QC, ca = q % QC;
-            const uint32_t in4[4] = {(uint32_t)sd[4 * ca + 0][jd], (uint32_t)sd[4 * ca + 1][jd], (uint32_t)sd[4 * ca + 2][jd],
-                                     (uint32_t)sd[4 * ca + 3][jd]};
-            uint32_t out4[4];
-            transpose4x4_bytes(in4, out4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tr_o[e][ca] = out4[e];
-            if constexpr (ca == QC - 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t d = (!kTwo || it == 0) ? s_dst[4 * jd + e] : s_dst[NDST - 16 + 4 * jd + e];
-                    char *dp = smem + (d >= 2 * bufb ? d : d + bufoff);
-                    if constexpr (CI == 16) {
-                        const v4i v = {(int)tr_o[e][0], (int)tr_o[e][1], (int)tr_o[e][2], (int)tr_o[e][3]};
-                        *reinterpret_cast<v4i *>(dp) = v;
-                    } else {
-                        *reinterpret_cast<uint2 *>(dp) = make_uint2(tr_o[e][0], tr_o[e][1]);
-                    }
-                }
-            }
-        }
-    };
-
-    mark();  // 5: staging items computed
-    static_for<NP>([&](auto qc) { stage_load_one(0, 0, qc); });
-
-    // ---- padding: column 0 of every patch row (= right padding of the row before) and the rows outside an image get
-    // the input zero point, in both buffers, once (staging never writes there).  One 16-byte write per unit =
-    // (padding pixel, slot, buffer), units dealt out to the threads (a loop over all patch pixels kept 1 lane in W + 1
-    // busy per ds_write_b128: 3 000 cycles)
-    {
-        const uint32_t zp4 = (uint32_t)(a.in_zp & 0xff) * 0x01010101u;
-        const v4i zv = {(int)zp4, (int)zp4, (int)zp4, (int)zp4};
-        constexpr int S2 = 2 * SLOTS;
-        const uint32_t n0 = ((uint32_t)a.pt_prows + 1) * S2;
-        for (uint32_t u = tid; u < n0; u += NT) {
-            const uint32_t pr = u / S2, sb = u % S2;
-            *reinterpret_cast<v4i *>(smem + (sb / SLOTS ? bufb : 0u) + m24(m24(pr, W1), PITCH) + (sb % SLOTS) * 16) = zv;
-        }
-        const uint32_t per_row = (uint32_t)W * S2;
-        const uint32_t n1 = (uint32_t)*inv_cnt * per_row;
-        const float rper = a.pt_rW * (1.0f / S2);  // exact: S2 is a power of two
-        for (uint32_t u = tid; u < n1; u += NT) {
-            const uint32_t i = pt_div(u, per_row, rper), r2 = u - m24(i, per_row);
-            const uint32_t x = r2 / S2, sb = r2 % S2;
-            const uint32_t q = m24(inv_tab[i], W1) + x + 1;
-            *reinterpret_cast<v4i *>(smem + (sb / SLOTS ? bufb : 0u) + m24(q, PITCH) + (sb % SLOTS) * 16) = zv;
-        }
-    }
-
-    mark();  // 6: padding written
-    // ---- this lane's pixel of each MFMA block: LDS offset of patch pixel (row - 1, x - 1), i.e. of tap (0, 0)
-    uint32_t pbase[NB];
-    {
-        const uint32_t p0 = (uint32_t)(hb * 32 + frow);
-        uint32_t r = pt_div(p0, W, rW), x = p0 - m24(r, W);
-        const uint32_t d32r = pt_div(32, W, rW), d32x = 32 - m24(d32r, W);
-        uint32_t prow[NB], xs[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {  // thirteen table reads, then the arithmetic
-            const bool ok = (uint32_t)((hb + j) * 32 + frow) < (uint32_t)RW && row0 + pg * R + (int)r < total_rows;
-            prow[j] = trow_tab[ok ? pg * R + r : 0];  // patch row of the pixel's own input row (>= 1)
-            xs[j] = ok ? x : 0;
-            x += d32x, r += d32r;
-            if (x >= (uint32_t)W) x -= W, ++r;
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) pbase[j] = m24(m24(prow[j] - 1, W1) + xs[j], PITCH) + fhalf * 16 + kp * 32;
-    }
-
-    // ---- accumulators start at zero; the plan's acc_init (= -zp_in * sum(w)) is added in the epilogue, once, after
-    // the K parts have been summed (initial values held in registers made the allocator split accumulators into
-    // VGPRs and spill)
-    v16i acc[NB];
-    {
-        // 13 MFMAs on zero operands with the constant 0 as C instead of 208 register writes
-        v4i z = {0, 0, 0, 0};
-        asm volatile("" : "+v"(z));
-        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(z, z, zero16, 0, 0, 0);
-    }
-
-    mark();  // 7: pixel offsets computed
-    static_for<NP>([&](auto qc) { stage_write_one(0, 0, qc); });
-    if constexpr (kTwo) {
-        if (a.pt_nitc > 1) {
-            static_for<NP>([&](auto qc) { stage_load_one(0, 1, qc); });
-            static_for<NP>([&](auto qc) { stage_write_one(0, 1, qc); });
-        }
-    }
-    if (nstg > 1) static_for<NP>([&](auto qc) { stage_load_one(1, 0, qc); });  // stage 1: written at step 4 of stage 0
-    mark();  // 8: stage 0 written
-    pt_barrier();
-    mark();  // 9: barrier passed
-    if constexpr (!kNchw) {  // the row tables are dead: this role's multipliers and biases take their place
-        if (h == 0) {
-            if (fhalf == 0) epi_tab[frow] = t_mult, epi_tab[64 + frow] = __int_as_float(t_acc);
-            else epi_tab[32 + frow] = t_bias;
-        }
-    }
-
-    // ---- K loop ----------------------------------------------------------------------------------------------
-    // One K step = 13 MFMAs (one per pixel block) on one weight fragment.  The instruction order is pinned
-    // (sched_barrier after every MFMA: left to itself the scheduler hoists the LDS reads of a whole stage and
-    // spills): slot j issues the B read that is D MFMAs ahead -- block j + D of this step, or block j + D - 13 of
-    // the next one, into the register its own MFMA freed D - 13 slots ago -- then at most two staging pieces, then
-    // the MFMA.  Waits are the compiler's own counted s_waitcnt (plain loads; LDS and VMEM return in order).
-    v4i rb[NB];
-    auto tap_off = [&](int step) -> uint32_t {  // LDS offset of a K step's (tap, sub-step); wave-uniform
-        const int tap = step / UI, ui = step - tap * UI;
-        const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
-        return m24((uint32_t)(ty * W1 + tx), PITCH) + ui * (KP * 32);
-    };
-    // ONE loop body for every step (nine steps per iteration: the weight ring's index is static): the accumulators
-    // have a single chain of definitions through the loop, and the staging pieces of the next stage sit in small
-    // wave-uniform branches that contain no MFMA -- branches AROUND whole steps made the register allocator split
-    // accumulators into VGPRs and spill.  Staging rides on step 4 (LDS writes of the next stage, + the loads of the
-    // second NCHW round), step 7 (its writes) and step 5 / 8 (the loads of the stage after that).
-    auto kstep = [&](auto fc, int s, int step, uint32_t bufoff, bool more) {
-        constexpr int F = decltype(fc)::value;
-        const uint32_t cur = bufoff + tap_off(step), nxt = bufoff + tap_off(step + 1);
-        const uint32_t nbufoff = bufb - bufoff;
-        // the weights of FR - 1 steps ahead (the plan pads the copy: no tail test)
-        fa[(F + FR - 1) % FR] = *reinterpret_cast<const v4i *>(wsb + ((size_t)(s * NSTEP + step + FR - 1)) * 1024 + wl);
-        // the data of stage s + 1 was requested a whole stage ago (at step 5 / 8 of stage s - 1, or in the prologue):
-        // requested only four steps ahead, the LDS writes of step 4 waited ~3 000 cycles for HBM in every stage
-        const bool two = kTwo && a.pt_nitc > 1;
-        const bool do_write0 = F == 4 && more && step == 4;
-        const bool do_write1 = F == 7 && more && step == 7 && two;
-        const bool do_load = (two ? F == 8 && step == 8 : F == 5 && step == 5) && s + 2 < nstg;
-        static_for<NB>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            // the last step of a stage reads "next" fragments nobody uses (one code path; LDS reads cannot fault)
-            if constexpr (j + D < NB)
-                rb[j + D] = *reinterpret_cast<const v4i *>(smem + (pbase[j + D] + cur));
-            else
-                rb[j + D - NB] = *reinterpret_cast<const v4i *>(smem + (pbase[j + D - NB] + nxt));
-            // the NP staging pieces on the NB slots, IN ORDER (the NCHW transposition finishes a dword column with its
-            // last channel quad): slot j takes pieces [j NP / NB, (j + 1) NP / NB)
-            constexpr int P0 = j * NP / NB;
-            constexpr int P1 = (j + 1) * NP / NB - P0 > 1 ? P0 + 1 : -1;
-            static_assert((j + 1) * NP / NB - P0 <= 2 && (j + 1) * NP / NB - P0 >= 1, "one or two pieces per slot");
-            if constexpr (F == 5 || (kTwo && F == 8)) {
-                if (do_load) {
-                    stage_load_one(s + 2, 0, std::integral_constant<int, P0>{});
-                    if constexpr (P1 >= 0) stage_load_one(s + 2, 0, std::integral_constant<int, P1>{});
-                }
-            }
-            if constexpr (F == 4) {
-                if (do_write0) {
-                    stage_write_one(nbufoff, 0, std::integral_constant<int, P0>{});
-                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 0, std::integral_constant<int, P1>{});
-                }
-            }
-            if constexpr (kTwo && F == 7) {
-                if (do_write1) {
-                    stage_write_one(nbufoff, 1, std::integral_constant<int, P0>{});
-                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 1, std::integral_constant<int, P1>{});
-                }
-            }
-            if constexpr (kNchw)
-                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[j], fa[F % FR], acc[j], 0, 0, 0);  // rows = pixels
-            else
-                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[F % FR], rb[j], acc[j], 0, 0, 0);  // rows = channels
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if constexpr (kTwo && F == 4) {
-            if (do_write0 && a.pt_nitc > 1) static_for<NP>([&](auto qc) { stage_load_one(s + 1, 1, qc); });
-        }
-    };
-    for (int s = 0; s < nstg; ++s) {
-        const uint32_t bufoff = (s & 1) ? bufb : 0u;
-        const bool more = s + 1 < nstg;
-        {
-            const uint32_t cur = bufoff + tap_off(0);
-            static_for<D>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                rb[j] = *reinterpret_cast<const v4i *>(smem + (pbase[j] + cur));
-            });
-        }
-        for (int step = 0; step < NSTEP; step += 9)
-            static_for<9>([&](auto fc) { kstep(fc, s, step + decltype(fc)::value, bufoff, more); });
-        mark();        // 6 + 2 s: K steps of the stage done
-        pt_barrier();  // every wave is done with this buffer; the next one is complete
-        mark();        // 7 + 2 s
-    }
-
-    // ---- epilogue ----------------------------------------------------------------------------------------------
-    const int pixbase = (row0 + pg * R) * W;  // flat output pixel of the pixel group's first pixel
-    char *out = static_cast<char *>(a.out);
-    // per-channel tables: NCHW lane = channel (column), NHWC 16 channels per lane (rows 8 g + 4 fhalf + e)
-    float4 mu[4], bi[4];
-    int4 ai[4];
-    if constexpr (kNchw) {
-        mu[0] = make_float4(t_mult, t_mult, t_mult, t_mult);
-        bi[0] = make_float4(t_bias, t_bias, t_bias, t_bias);
-        ai[0] = make_int4(t_acc, t_acc, t_acc, t_acc);
-    } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            mu[g] = *reinterpret_cast<const float4 *>(epi_tab + 8 * g + 4 * fhalf);
-            bi[g] = *reinterpret_cast<const float4 *>(epi_tab + 32 + 8 * g + 4 * fhalf);
-            ai[g] = *reinterpret_cast<const int4 *>(epi_tab + 64 + 8 * g + 4 * fhalf);
-        }
-    }
-    // NCHW: (image, offset inside its plane) of the lane's first pixel of block 0 -- one exact division, then
-    // advanced by 32 pixels per block
-    uint32_t e_rem = 0;
-    // address of the lane's first output of block 0, advanced by 32 pixels per block.  NHWC: its 16 channels of a pixel.
-    // NCHW: its 16 pixels of a channel plane; an image boundary adds the other Co - 1 planes of the image
-    char *e_ptr = out;
-    if constexpr (kNchw) {
-        const uint32_t m00 = (uint32_t)(pixbase + hb * 32 + fhalf * 16);
-        const uint32_t e_n = pt_div(m00, HW, a.pt_rHW);
-        e_rem = m00 - m24(e_n, HW);
-        e_ptr = out + ((int64_t)(m24(e_n, a.Co) + (uint32_t)(ocb * 32 + frow)) * HW + e_rem);
-    } else {
-        e_ptr = out + (int64_t)(pixbase + hb * 32 + frow) * a.Co + (ocb * 32 + fhalf * 16);
-    }
-    const int64_t e_step = kNchw ? 32 : (int64_t)32 * a.Co;
-    const int64_t e_wrap = (int64_t)(a.Co - 1) * HW;
-    auto advance = [&]() {
-        e_ptr += e_step;
-        if constexpr (kNchw) {
-            e_rem += 32;
-            if (HW >= 32) {  // wave-uniform: one image boundary at most
-                if (e_rem >= (uint32_t)HW) e_rem -= HW, e_ptr += e_wrap;
-            } else {
-                while (e_rem >= (uint32_t)HW) e_rem -= HW, e_ptr += e_wrap;
-            }
-        }
-    };
-    auto finalize = [&](int j, const v16i &c) {
-        uint32_t pk[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int4 i4 = kNchw ? ai[0] : ai[g];
-            pk[g] = requant4_i8_t<EPI>(c[4 * g + 0] + i4.x, c[4 * g + 1] + i4.y, c[4 * g + 2] + i4.z, c[4 * g + 3] + i4.w, kNchw ? mu[0] : mu[g],
-                                       kNchw ? bi[0] : bi[g], a);
-        }
-        const uint4 v = tile_channels_16(pk);  // 16 consecutive rows 16 fhalf .. + 15 of the lane's column
-        if (a.debug & 2) return;
-        if constexpr (!kNchw) {
-            const int pl = (hb + j) * 32 + frow;
-            const int m = pixbase + pl;
-            const int oc = ocb * 32 + fhalf * 16;
-            if (ocb_ok && pl < RW && m < a.M && oc < a.Co) *reinterpret_cast<uint4 *>(e_ptr) = v;
-        } else {
-            const int oc = ocb * 32 + frow;
-            const int pl0 = (hb + j) * 32 + fhalf * 16;
-            const int m0 = pixbase + pl0;
-            const bool live = ocb_ok && oc < a.Co && pl0 < RW && m0 < a.M;
-            const bool full = pl0 + 16 <= RW && m0 + 16 <= a.M;
-            char *dst = e_ptr;
-            // the common case decided ONCE per wave: every lane stores 16 pixels of one plane (whatever the byte address).
-            // The general code below is ~220 instructions per block, with its dozen lane-mask branches even when no
-            // lane takes them -- three times the requantisation itself
-            if (__builtin_amdgcn_ballot_w64(!(live && full && e_rem + 16 <= (uint32_t)HW)) == 0) {
-                const pt_u4 t4 = {v.x, v.y, v.z, v.w};
-                *reinterpret_cast<pt_u4 *>(dst) = t4;
-                return;
-            }
-            if (!live) return;
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-            if (full && e_rem + 16 <= (uint32_t)HW) {  // 16 pixels of one plane
-                const pt_u4 t4 = {v.x, v.y, v.z, v.w};
-                *reinterpret_cast<pt_u4 *>(dst) = t4;
-            } else if (full && HW >= 16) {
-                // the run crosses into the next image once (planes of 49 or 196 bytes): dwords that lie inside one piece
-                // go out whole (at whatever byte address), the one that straddles the boundary byte by byte.  Kept small
-                // on purpose: this code sits in every one of the thirteen unrolled blocks
-                const int len1 = HW - (int)e_rem;                        // bytes that still belong to image n
-                char *dst2 = dst + (int64_t)(a.Co - 1) * HW;             // = plane (n + 1, oc) - len1: byte b >= len1 goes to dst2 + b
-                typedef uint32_t u1_a1 __attribute__((aligned(1)));
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    char *p = 4 * d >= len1 ? dst2 : dst;
-                    if (4 * d + 4 <= len1 || 4 * d >= len1) *reinterpret_cast<u1_a1 *>(p + 4 * d) = w4[d];
-                }
-                if (len1 & 3) {
-                    const int d = len1 >> 2;
-                    const uint32_t w = d == 0 ? w4[0] : d == 1 ? w4[1] : d == 2 ? w4[2] : w4[3];
-#pragma unroll 1
-                    for (int e = 0; e < 4; ++e) {
-                        char *p = 4 * d + e < len1 ? dst : dst2;
-                        p[4 * d + e] = (char)(w >> (8 * e));
-                    }
-                }
-            } else {
-                uint32_t r2 = e_rem;
-#pragma unroll 1
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t w = (e >> 2) == 0 ? w4[0] : (e >> 2) == 1 ? w4[1] : (e >> 2) == 2 ? w4[2] : w4[3];
-                    if (pl0 + e < RW && m0 + e < a.M) *dst = (char)(w >> (8 * (e & 3)));
-                    ++dst;
-                    if (++r2 == (uint32_t)HW) {  // next image: same channel plane, Co planes further
-                        r2 = 0;
-                        dst += (int64_t)(a.Co - 1) * HW;
-                    }
-                }
-            }
-        }
-    };
-
-    if constexpr (KP == 1) {
-        // two blocks at a time: their requantisation chains are independent (a wave alone on its SIMD runs one chain
-        // latency-bound), the pairs are kept apart so that the accumulators' copies do not pile up in registers
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            finalize(j, acc[j]);
-            advance();
-            if (j & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        // K parts: block j is finished by the wave with kp == j % KP; the others hand their partial sums over
-        // through LDS (exact int32 adds), CH blocks per round (CH x 4 KiB per wave, 128 KiB in all)
-        constexpr int CH = NW == 8 ? 4 : 8;
-        static_assert(NW * CH * 4096 <= 128 * 1024, "exchange area");
-        char *const mine = smem + wave * (CH * 4096);
-        // small patches: the epilogue tables (behind the two buffers) lie inside the exchange area -- every wave has
-        // read its tables before anybody writes partial sums
-        if constexpr (!kNchw) pt_barrier();
-        static_for<2>([&](auto rc) {
-            constexpr int rb = decltype(rc)::value * CH;
-            constexpr int re = rb + CH < NB ? rb + CH : NB;
-            static_assert(2 * CH >= NB, "two rounds");
-            static_for<re - rb>([&](auto jc) {
-                constexpr int j = rb + decltype(jc)::value;
-                if (j % KP != kp) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const v4i v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                        *reinterpret_cast<v4i *>(mine + ((j - rb) * 4 + g) * 1024 + lane * 16) = v;
-                    }
-                }
-            });
-            pt_barrier();
-            static_for<re - rb>([&](auto jc) {
-                constexpr int j = rb + decltype(jc)::value;
-                if (j % KP == kp) {
-                    v16i c = acc[j];
-#pragma unroll
-                    for (int o = 1; o < KP; ++o) {
-                        const int other = wave + ((kp + o) % KP - kp) * (NW / 4);  // same role and half, another K part
-                        const char *src = smem + other * (CH * 4096) + (j - rb) * 4096 + lane * 16;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const v4i v = *reinterpret_cast<const v4i *>(src + g * 1024);
-                            c[4 * g] += v[0];
-                            c[4 * g + 1] += v[1];
-                            c[4 * g + 2] += v[2];
-                            c[4 * g + 3] += v[3];
-                        }
-                    }
-                    finalize(j, c);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                advance();
-            });
-            if constexpr (rb == 0) pt_barrier();
-        });
-    }
-    mark();  // last: epilogue done
-    if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-}
-
-template <int EPI, bool kNchw, int KC, int PG, int OB, int KP, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_igemm_patch_kernel(ConvArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if constexpr (NW == 4) {
-        patch_body<EPI, kNchw, KC, PG, OB, KP, 4, PT_NB>(a, smem, 0);
-    } else {
-        // the two halves are two straight-line bodies (7 and 6 pixel blocks) behind ONE wave-uniform branch; both pass
-        // the same sequence of workgroup barriers
-        if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) == 0)
-            patch_body<EPI, kNchw, KC, PG, OB, KP, 8, 7>(a, smem, 0);
-        else
-            patch_body<EPI, kNchw, KC, PG, OB, KP, 8, 6>(a, smem, 1);
-    }
-}
 
 // =================================================================================================== host side
 bool patch_supports(const shl_mi355x_conv_desc &d)
@@ -713,6 +57,7 @@ namespace {
 
 struct PatchShape {
     int rows, prows, bufb, lds, nt_m, nt_n, nitc, spr;
+    int pair_dn;  // pair mode: the second tile of a workgroup lies this many images further on (0 = off)
 };
 
 // geometry of a forward pass with batch n; false when the patch does not fit LDS / the staging item budget
@@ -754,6 +99,15 @@ int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, in
     ps->rows = rows, ps->prows = prows, ps->bufb = bufb, ps->lds = lds, ps->nt_m = nt_m;
     ps->nt_n = (((Co + 31) / 32) + ob - 1) / ob;
     ps->nitc = nitc, ps->spr = spr;
+    // pair mode (eight waves, one K part): a single-stage layer whose tiles need more than one round on the 256 CUs;
+    // tile t and tile t + nt_m / 2 must be congruent (the same rows of another image) and no tile ragged.  One
+    // prologue for two tiles = ~1.7 tile times per workgroup
+    ps->pair_dn = 0;
+    static const char *pair_env = getenv("SHL_MI355X_PATCH_PAIR");  // "0": off (A/B)
+    const int64_t tiles = (int64_t)nt_m * ps->nt_n;
+    if (!(pair_env && pair_env[0] == '0') && PT_NW8(geom) && C == kc && kp == 1 && nt_m % 2 == 0 && total_rows % tr == 0 &&
+        ((int64_t)(nt_m / 2) * tr) % H == 0 && (double)((tiles + 511) / 512) * 1.7 < (double)((tiles + 255) / 256))
+        ps->pair_dn = (int)((int64_t)(nt_m / 2) * tr / H);
     return 1;
 }
 
@@ -889,7 +243,9 @@ bool patch_setup(ConvArgs &a)
     a.pt_bufb = ps.bufb;
     a.pt_nitc = ps.nitc;
     a.pt_spr = ps.spr;
-    a.pt_ntm = ps.nt_m;
+    a.pt_ntm = ps.pair_dn ? ps.nt_m / 2 : ps.nt_m;
+    a.pt_pair_in = ps.pair_dn * a.C * a.H * a.W;  // < 2^31: patch_shape
+    a.pt_pair_pix = ps.pair_dn * a.H * a.W;
     a.pt_rW = 1.0f / (float)a.W;
     a.pt_rH = 1.0f / (float)a.H;
     a.pt_rH1 = 1.0f / (float)(a.H + 1);
@@ -917,46 +273,14 @@ bool patch_auto(const ConvArgs &a)
     return true;
 }
 
-template <int EPI, bool kNchw, int KC, int PG, int OB, int KP, int NW>
-static void patch_launch_nw(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
-{
-    auto kernel = conv_igemm_patch_kernel<EPI, kNchw, KC, PG, OB, KP, NW>;
-    static bool opted = false;
-    if (!opted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
-        opted = true;
-    }
-    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(NW * 64), lds, s, a);
-}
+static bool g_last_nchw = false;  // layout of the last launch: its translation unit holds the trace
 
-template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
-static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
-{
-    if (PT_NW8(a.pt_geom)) patch_launch_nw<EPI, kNchw, KC, PG, OB, KP, 8>(a, tiles, lds, s);
-    else patch_launch_nw<EPI, kNchw, KC, PG, OB, KP, 4>(a, tiles, lds, s);
-}
-
-template <int KC, int PG, int OB, int KP>
-static void patch_launch_geom(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
-{
-    if constexpr ((KC / 32) % KP == 0) {
-        const bool pow2 = a.div_exact != 0;
-        if (a.in_nchw) {
-            if (pow2) patch_launch_one<3, true, KC, PG, OB, KP>(a, tiles, lds, s);
-            else patch_launch_one<0, true, KC, PG, OB, KP>(a, tiles, lds, s);
-        } else {
-            if (pow2) patch_launch_one<3, false, KC, PG, OB, KP>(a, tiles, lds, s);
-            else patch_launch_one<0, false, KC, PG, OB, KP>(a, tiles, lds, s);
-        }
-    }
-}
+int patch_launch_nhwc(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s) { return patch_launch_layout<false>(a, tiles, lds, s); }
+int patch_read_trace_nhwc(unsigned long long *host, int count) { return patch_read_trace_layout<false>(host, count); }
 
 int patch_read_trace(unsigned long long *host, int count)
 {
-    const int n0 = count > 64 ? 64 : count;
-    SHL_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pt_trace), (size_t)n0 * 8));
-    if (count >= 64 + 2048) SHL_HIP(hipMemcpyFromSymbol(host + 64, HIP_SYMBOL(g_pt_span), (size_t)2048 * 8));
-    return SHL_MI355X_OK;
+    return g_last_nchw ? patch_read_trace_nchw(host, count) : patch_read_trace_nhwc(host, count);
 }
 
 int launch_conv_igemm_patch(const ConvArgs &a0, hipStream_t s)
@@ -968,22 +292,10 @@ int launch_conv_igemm_patch(const ConvArgs &a0, hipStream_t s)
     }
     PatchShape ps;
     patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
-    const unsigned tiles = (unsigned)(ps.nt_m * ps.nt_n);
-    const int kc = PT_KC(a.pt_geom), key = PT_PG(a.pt_geom) * 100 + PT_OB(a.pt_geom) * 10 + PT_KP(a.pt_geom);
-#define SHL_PT(KCV)                                                          \
-    switch (key) {                                                           \
-        case 141: patch_launch_geom<KCV, 1, 4, 1>(a, tiles, ps.lds, s); break; \
-        case 221: patch_launch_geom<KCV, 2, 2, 1>(a, tiles, ps.lds, s); break; \
-        case 122: patch_launch_geom<KCV, 1, 2, 2>(a, tiles, ps.lds, s); break; \
-        case 114: patch_launch_geom<KCV, 1, 1, 4>(a, tiles, ps.lds, s); break; \
-        default: return SHL_MI355X_ENOTSUP;                                  \
-    }
-    if (kc == 128) {
-        SHL_PT(128)
-    } else {
-        SHL_PT(64)
-    }
-#undef SHL_PT
+    const unsigned tiles = (unsigned)((ps.pair_dn ? ps.nt_m / 2 : ps.nt_m) * ps.nt_n);
+    g_last_nchw = a.in_nchw != 0;
+    const int rc = a.in_nchw ? patch_launch_nchw(a, tiles, ps.lds, s) : patch_launch_nhwc(a, tiles, ps.lds, s);
+    if (rc != SHL_MI355X_OK) return rc;
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }
