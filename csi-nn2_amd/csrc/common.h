@@ -82,7 +82,8 @@ struct ConvArgs {
     int32_t pt_spr;       // NCHW staging: 16-byte segments per image run
     int32_t pt_ntm;       // row tiles
     float pt_rW, pt_rH, pt_rH1, pt_rspr, pt_rntn;  // 1 / W, 1 / H, 1 / (H + 1), 1 / pt_spr, 1 / channel tiles
-    float pt_rHW;         // 1 / (H W)
+    float pt_rHW;         // 1 / (Ho Wo)
+    float pt_rOW;         // 1 / Wo
 };
 
 // The pad page is 4 KiB so that concurrent readers can be spread over 32 cache lines instead of

@@ -45,8 +45,14 @@ namespace shl {
 bool patch_supports(const shl_mi355x_conv_desc &d)
 {
     if (d.dtype != SHL_MI355X_I8 || d.group != 1) return false;
-    if (d.kernel_h != 3 || d.kernel_w != 3 || d.stride_h != 1 || d.stride_w != 1 || d.dilation_h != 1 || d.dilation_w != 1) return false;
-    if (d.pad_top != 1 || d.pad_left != 1 || d.out_h != d.in_h || d.out_w != d.in_w) return false;
+    if (d.kernel_h != 3 || d.kernel_w != 3 || d.dilation_h != 1 || d.dilation_w != 1) return false;
+    if (d.pad_top != 1 || d.pad_left != 1) return false;
+    if (d.stride_h == 2 && d.stride_w == 2) {
+        // the stride-2 form: even planes, so that no tap reaches the bottom / right padding
+        if (d.in_h % 2 || d.in_w % 2 || d.out_h != d.in_h / 2 || d.out_w != d.in_w / 2) return false;
+    } else if (d.stride_h != 1 || d.stride_w != 1 || d.out_h != d.in_h || d.out_w != d.in_w) {
+        return false;
+    }
     if (d.in_c % 64 != 0 || d.in_w > PT_PIX) return false;
     if (d.layout == SHL_MI355X_NHWC && d.out_c % 16 != 0) return false;  // 16-byte stores of 16 channels
     if (d.in_zp < -128 || d.in_zp > 127) return false;
@@ -66,9 +72,30 @@ struct PatchShape {
 int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, int rows, PatchShape *ps)
 {
     const int kc = PT_KC(geom), pg = PT_PG(geom), ob = PT_OB(geom), kp = PT_KP(geom);
-    const int64_t total_rows = (int64_t)n * H;
     const int pitch = kc + 16, slots = kc / 16;
     const int tr = rows * pg;
+    if (PT_S2(geom)) {
+        // stride 2: rows are OUTPUT rows; the patch of a stage is one input row (W + 1 pixels) per tile row
+        const int64_t orows = (int64_t)n * (H / 2);
+        const int nt = (int)((orows + tr - 1) / tr);
+        const int prows = (int)(orows < tr ? orows : tr);
+        const int bufb = (((prows * (W + 1) + 1) * pitch) + 255) & ~255;
+        int lds = 2 * bufb + PT_TRASH + PT_TABLES;
+        if (prows > 512) return 0;
+        if (kp > 1 && lds < 4 * 8 * 4096) lds = 4 * 8 * 4096;
+        if (lds > PT_LDS_MAX) return 0;
+        if (!nchw && (int64_t)prows * W * slots > PT_NIT * 256) return 0;
+        int spr = 1;
+        if (nchw) {
+            spr = (W + 15) / 16;
+            if ((int64_t)prows * spr * (kc / 8) > 512) return 0;  // one round of items for the eight waves
+        }
+        ps->rows = rows, ps->prows = prows, ps->bufb = bufb, ps->lds = lds, ps->nt_m = nt;
+        ps->nt_n = (((Co + 31) / 32) + ob - 1) / ob;
+        ps->nitc = 1, ps->spr = spr, ps->pair_dn = 0;
+        return 1;
+    }
+    const int64_t total_rows = (int64_t)n * H;
     const int nt_m = (int)((total_rows + tr - 1) / tr);
     int prows = 0, runs = 0;
     for (int tm = 0; tm < nt_m; ++tm) {  // exact capacity over the tiles of this batch
@@ -116,10 +143,12 @@ bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchS
 {
     const int kc = PT_KC(geom), pg = PT_PG(geom);
     if (!kc || C % kc != 0) return false;
-    const int64_t total_rows = (int64_t)n * H;
-    if (total_rows + n >= (1 << 22) || (int64_t)n * H * W >= (1 << 24) || (int64_t)n * C >= (1 << 24)) return false;  // 24-bit multiplies
+    const bool s2 = PT_S2(geom);
+    const int HO = s2 ? H / 2 : H, WO = s2 ? W / 2 : W;  // output plane
+    const int64_t total_rows = (int64_t)n * HO;
+    if ((int64_t)n * H + n >= (1 << 22) || (int64_t)n * H * W >= (1 << 24) || (int64_t)n * C >= (1 << 24)) return false;  // 24-bit multiplies
     if ((int64_t)n * H * W * C >= (1ll << 31) - 65536) return false;  // 32-bit source offsets
-    int rows = PT_PIX / W;
+    int rows = PT_PIX / WO;
     if ((int64_t)rows * pg > total_rows) rows = (int)((total_rows + pg - 1) / pg);
     int top = 0;  // the most rows that fit
     for (; rows >= 1 && !top; --rows) {
@@ -134,7 +163,7 @@ bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchS
     const int64_t rounds_top = ((int64_t)best.nt_m * best.nt_n + 255) / 256;
     for (int r = top; r >= 1 && 8 * r >= 7 * top; --r) {
         const int tr = r * pg;
-        if (tr % H != 0 && H % tr != 0) continue;
+        if (tr % HO != 0 && HO % tr != 0) continue;
         PatchShape t;
         if (patch_shape_rows(n, H, W, C, Co, nchw, geom, r, &t) != 1) continue;
         if (((int64_t)t.nt_m * t.nt_n + 255) / 256 <= rounds_top) best = t;
@@ -159,15 +188,24 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
 {
     if (!patch_supports(d) || batch <= 0) return 0;
     static const char *env = getenv("SHL_MI355X_PATCH");  // "pg,ob,kp" forces the roles (tests, A/B)
-    const int kc = d.in_c % 128 == 0 ? 128 : 64;
+    const bool s2 = d.stride_h == 2;
+    const int kc = (d.in_c % 128 == 0 && !s2) ? 128 : 64;  // stride 2: two 64-channel patches of one input row per tile row fit LDS
     const int u = kc / 32;
     const bool nchw = d.layout == SHL_MI355X_NCHW;
+    static const char *s2_env = getenv("SHL_MI355X_PATCH_S2");  // "0": no stride-2 form (A/B)
+    if (s2 && s2_env && s2_env[0] == '0') return 0;
+    // NHWC keeps its stride-2 layers on the block-tile kernels (28 / 22 us against 32 / 32 for ResNet-50's at batch 128:
+    // a stage is only six K steps long and the staging loads of the next one do not arrive in that time); NCHW saves
+    // the re-layout pass in front of them (53 -> 36 us, 40 -> 38 us).  Forced (tests): both layouts
+    static const char *forced_env = getenv("SHL_MI355X_IGEMM");
+    if (s2 && !nchw && !(forced_env && !strcmp(forced_env, "patch"))) return 0;
     if (env && env[0] && env[0] != '0' && env[0] != '1') {
         int pg = 0, ob = 0, kp = 0;
         if (sscanf(env, "%d,%d,%d", &pg, &ob, &kp) == 3 && pg * ob * kp == 4 && u % kp == 0 && pg != 4 && !(pg == 2 && kp == 2)) {
             PatchShape ps;
-            int g = make_geom(kc, pg, ob, kp);
-            if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) g &= ~(1 << 20);  // four waves take two NCHW rounds
+            int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0);
+            if (s2 && !PT_NW8(g)) return 0;  // the stride-2 form has eight waves
+            if (!s2 && !patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) g &= ~(1 << 20);  // four waves take two NCHW rounds
             return patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps) ? g : 0;
         }
     }
@@ -180,8 +218,10 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         if (u % kp != 0) continue;
         if (ob > 1 && ob / 2 >= ocblks) continue;  // half of the channel blocks of a tile would be empty
         PatchShape ps;
-        int g = make_geom(kc, pg, ob, kp);
+        int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0);
+        if (s2 && !PT_NW8(g)) return 0;  // the stride-2 form has eight waves
         if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) {
+            if (s2) continue;
             g &= ~(1 << 20);  // four waves take two NCHW staging rounds
             if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) continue;
         }
@@ -189,7 +229,8 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         const double rounds = (double)((tiles + 255) / 256);
         // per tile and wave: a K loop over K / kp for 13 pixel blocks + fixed costs (prologue, epilogue; the exchange
         // of partial sums for K parts)
-        const double total = rounds * (1.0 / kp + 0.12 + (kp > 1 ? 0.04 : 0.0));
+        // (stride 2: a barrier per three K steps with two K parts, per six with one)
+        const double total = rounds * (1.0 / kp + 0.12 + (kp > 1 ? 0.04 : 0.0) + (s2 && kp > 1 ? 0.10 : 0.0));
         static const char *dbg = getenv("SHL_MI355X_DEBUG_GEOM");
         if (dbg) fprintf(stderr, "patch geom %d,%d,%d nw%d: rows %d prows %d tiles %d x %d lds %d nitc %d cost %.3f\n", pg, ob, kp, PT_NW8(g) ? 8 : 4,
                          ps.rows, ps.prows, ps.nt_m, ps.nt_n, ps.lds, ps.nitc, total);
@@ -246,12 +287,16 @@ bool patch_setup(ConvArgs &a)
     a.pt_ntm = ps.pair_dn ? ps.nt_m / 2 : ps.nt_m;
     a.pt_pair_in = ps.pair_dn * a.C * a.H * a.W;  // < 2^31: patch_shape
     a.pt_pair_pix = ps.pair_dn * a.H * a.W;
+    const bool s2 = PT_S2(a.pt_geom);
+    const int HO = s2 ? a.H / 2 : a.H, WO = s2 ? a.W / 2 : a.W;
+    if (s2 && (a.Ho != HO || a.Wo != WO)) return false;
     a.pt_rW = 1.0f / (float)a.W;
-    a.pt_rH = 1.0f / (float)a.H;
+    a.pt_rH = 1.0f / (float)HO;
+    a.pt_rOW = 1.0f / (float)WO;
     a.pt_rH1 = 1.0f / (float)(a.H + 1);
     a.pt_rspr = 1.0f / (float)ps.spr;
     a.pt_rntn = 1.0f / (float)ps.nt_n;
-    a.pt_rHW = 1.0f / (float)(a.H * a.W);
+    a.pt_rHW = 1.0f / (float)(HO * WO);
     return true;
 }
 
@@ -265,7 +310,7 @@ bool patch_auto(const ConvArgs &a)
     if (!patch_setup(t)) return false;
     PatchShape ps;
     patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
-    if ((int64_t)ps.nt_m * ps.nt_n < 96) return false;  // fewer tiles than that: the latency-oriented kernels
+    if ((int64_t)ps.nt_m * ps.nt_n < (PT_S2(a.pt_geom) ? 192 : 96)) return false;  // fewer tiles than that: the latency-oriented kernels
     // NHWC with four K parts (512 channels @7 at batch 128): nine K steps per stage and the exchange of partial sums
     // leave it behind the producer / consumer kernel (25.4 vs 22.4 us); NCHW takes it anyway -- the alternative there
     // is two re-layout passes around that kernel (39 vs 47 us)

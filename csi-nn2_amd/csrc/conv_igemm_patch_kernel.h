@@ -24,6 +24,7 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 #define PT_OB(g) (((g) >> 12) & 0xf)
 #define PT_KP(g) (((g) >> 16) & 0xf)
 #define PT_NW8(g) (((g) >> 20) & 1)  // eight waves (two per SIMD) instead of four
+#define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (stage = (channel group, filter row))
 
 // x / d for x < 2^22 (q is within one of the quotient after the float multiply)
 __device__ __forceinline__ uint32_t pt_div(uint32_t x, uint32_t d, float rcp)
@@ -56,7 +57,14 @@ static __device__ unsigned long long g_pt_span[2 * 1024];  // SHL_MI355X_DEBUG=3
 // channel block, K part) split 7 + 6 between them (half h; NBW = this wave's blocks): the prologue and the epilogue are
 // long dependent scalar / VALU chains that a wave alone on its SIMD runs at ~6 cycles per instruction, and they are
 // half as long per wave and interleave with the partner's.  At most 256 registers per wave then: 7 x 16 accumulators.
-template <int EPI, bool kNchw, bool kPair, int KC, int PG, int OB, int KP, int NW, int NBW>
+// kS2: 3x3 STRIDE-2 (pad 1 top / left, even H and W).  A full 3x3 patch of 13 pixel blocks would be four times the
+// stride-1 one; here a stage is (64 channels, ONE filter row ky): the patch holds, for every output row of the tile,
+// the single input row 2 oy + ky - 1, de-interleaved by column parity -- [left pad][odd columns][even columns] -- so
+// that the three taps of the row are again constant offsets (kx = 0: slot ox, kx = 2: slot ox + 1, kx = 1: slot
+// Wo + 1 + ox) and a block of 32 consecutive outputs reads consecutive slots.  Three K steps x U sub-steps per stage;
+// the top padding row (oy = 0, ky = 0) is the zero point selected at the LDS write (flag in bit 31 of the item's
+// destination), odd input rows are fetched twice (L2).  Weight stream order is the stride-1 one.
+template <int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW, int NBW>
 __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, const int h)
 {
     int trace_k = 0;
@@ -76,16 +84,20 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     constexpr int NP = kNchw ? CI : NIT;     // staging pieces per round (loads, and again writes)
     constexpr bool kTwo = kNchw && NW == 4;  // NCHW staging may take a second round of items (eight waves: the host
                                              // falls back to four when one round does not cover a stage)
-    constexpr int FR = (NW == 8 && kNchw) ? 3 : 9;  // weight fragment ring (256 registers per wave: NCHW staging needs the rest)
+    constexpr int FR = ((NW == 8 && kNchw) || kS2) ? 3 : 9;  // weight fragment ring (256 registers per wave: NCHW staging needs the rest)
     constexpr int U = KC / 32;          // 32-byte K sub-steps per tap and stage
     constexpr int UI = U / KP;          // ... of which this wave takes every KP-th
-    constexpr int NSTEP = 9 * UI;       // K steps (13 MFMAs each) per stage and wave
+    constexpr int TAPS = kS2 ? 3 : 9;   // filter taps per stage
+    constexpr int NSTEP = TAPS * UI;    // K steps (13 MFMAs each) per stage and wave
+    constexpr int SPI = kS2 ? NSTEP : 9;  // steps per iteration of the K loop (the weight ring's index is static)
+    constexpr int FW = kS2 ? 1 : 4, FL = kS2 ? 2 : 5;  // steps that carry the next stage's LDS writes / the loads of the one after
     constexpr int NF = NSTEP * NB;      // MFMAs per stage and wave
     constexpr int PITCH = KC + 16;
     constexpr int SLOTS = KC / 16;
     constexpr int CG = KC / CI;         // channel groups per stage (NCHW staging)
     static_assert(U % KP == 0, "K parts split the sub-steps of a tap");
-    static_assert(NSTEP % 9 == 0, "weight fragment ring of nine");
+    static_assert(NSTEP % SPI == 0 && SPI % FR == 0, "weight fragment ring");
+    static_assert(!kS2 || (NW == 8 && !kPair), "the stride-2 form: eight waves");
     // every kernel argument the kernel will ever read, requested NOW in one batch: left to the compiler the scalar
     // loads are sunk to their first uses, and each of the half dozen groups then costs its own 500 - 1 000 cycles of
     // argument-segment latency in a prologue that nothing overlaps
@@ -93,7 +105,8 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     PT_PIN(a.in); PT_PIN(a.out); PT_PIN(a.w_patch); PT_PIN(a.acc_init); PT_PIN(a.mult); PT_PIN(a.bias);
     PT_PIN(a.N); PT_PIN(a.H); PT_PIN(a.W); PT_PIN(a.C); PT_PIN(a.Co); PT_PIN(a.M); PT_PIN(a.in_zp);
     PT_PIN(a.pt_rows); PT_PIN(a.pt_prows); PT_PIN(a.pt_bufb); PT_PIN(a.pt_pair_in); PT_PIN(a.pt_pair_pix); PT_PIN(a.pt_nitc); PT_PIN(a.pt_spr); PT_PIN(a.pt_ntm);
-    PT_PIN(a.pt_rW); PT_PIN(a.pt_rH); PT_PIN(a.pt_rH1); PT_PIN(a.pt_rspr); PT_PIN(a.pt_rntn);
+    PT_PIN(a.pt_rW); PT_PIN(a.pt_rH); PT_PIN(a.pt_rH1); PT_PIN(a.pt_rspr); PT_PIN(a.pt_rntn); PT_PIN(a.pt_rOW); PT_PIN(a.pt_rHW);
+    if constexpr (kS2) { PT_PIN(a.Ho); PT_PIN(a.Wo); }
     PT_PIN(a.out_scale); PT_PIN(a.inv_out_scale); PT_PIN(a.out_zp_f); PT_PIN(a.out_zp); PT_PIN(a.clamp_lo); PT_PIN(a.clamp_hi);
 #undef PT_PIN
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 31, fhalf = lane >> 5;
@@ -102,8 +115,9 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     const int kp = wv % KP, ob = (wv / KP) % OB, pg = wv / (KP * OB);
     const int hb = h * HB;                      // first pixel block of this wave inside the pixel group
     const int W = a.W, H = a.H, W1 = W + 1, H1 = H + 1, HW = H * W;
-    const int R = a.pt_rows, TR = PG * R, RW = R * W;
-    const int total_rows = a.N * H;
+    const int OW = kS2 ? a.Wo : W, OH = kS2 ? a.Ho : H, OHW = OH * OW;  // output plane (= input plane at stride 1)
+    const int R = a.pt_rows, TR = PG * R, RW = R * OW;
+    const int total_rows = a.N * OH;  // output rows
     const int ocblks = (a.Co + 31) >> 5;
     const int nt_n = (ocblks + OB - 1) / OB;
     const int nt_m = a.pt_ntm;  // (total_rows + TR - 1) / TR, from the host: every integer division here is ~40 instructions
@@ -120,15 +134,16 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // same tables.  The second tile's patch is staged into the other buffer under the first one's K loop like a second
     // stage, and one prologue (~7 000 cycles that nothing overlaps) serves both.  The two passes are two copies of the
     // code: the staging registers are dead in the second one, and the epilogue needs them
-    const int nstg = kPair ? 1 : a.C / KC;
+    const int nstg = kPair ? 1 : (kS2 ? 3 : 1) * (a.C / KC);
     constexpr int NPASS = kPair ? 2 : 1;
     const uint32_t bufb = (uint32_t)a.pt_bufb;
-    const float rW = a.pt_rW, rH = a.pt_rH, rH1 = a.pt_rH1;  // reciprocals from the host (a division is ~12 instructions)
+    const float rW = a.pt_rW, rH = a.pt_rH, rH1 = a.pt_rH1, rOW = a.pt_rOW;  // reciprocals from the host (a division is ~12 instructions); rH = 1 / OH
     // "virtual" rows: every image is followed by ONE padding row (bottom halo of its last row = top halo of the
     // next image's first row): v(g) = g + g / H.  Patch row pr holds virtual row v0 + pr.
-    const int v0 = row0 + (int)pt_div((uint32_t)row0, H, rH) - 1;
+    // (kS2: no halo and no virtual rows -- patch row pr = tile row pr)
+    const int v0 = kS2 ? row0 : row0 + (int)pt_div((uint32_t)row0, H, rH) - 1;
     const int last_row = (row0 + TR < total_rows ? row0 + TR : total_rows) - 1;
-    const int prows = last_row + (int)pt_div((uint32_t)last_row, H, rH) - v0 + 2;
+    const int prows = kS2 ? last_row - row0 + 1 : last_row + (int)pt_div((uint32_t)last_row, H, rH) - v0 + 2;
 
     mark();  // 1: tile decoded
     // ---- weights: this wave's fragment stream, 1 KiB per K step; a ring of nine fragments = eight steps
@@ -154,7 +169,16 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // requested now, used at the very end
     const float t_mult = a.mult[ocb * 32 + frow], t_bias = a.bias[ocb * 32 + frow];
     const int32_t t_acc = a.acc_init[ocb * 32 + frow];
-    if (wave == 0) {
+    if constexpr (kS2) {
+        // prow_tab[pr] = offset of input row 2 oy (the ky = 1 row) of tile row pr | (oy == 0), or -1 past the last row
+        for (int pr = tid; pr < a.pt_prows; pr += NT) {
+            const uint32_t g = (uint32_t)(row0 + pr);
+            const uint32_t n = pt_div(g, OH, rH), oy = g - m24(n, OH);
+            const bool ok = (int)g < total_rows;
+            const uint32_t off = kNchw ? m24(m24(n, a.C), HW) + m24(2 * oy, W) : m24(m24(m24(n, H) + 2 * oy, W), a.C);
+            prow_tab[pr] = ok ? (int32_t)(off | (oy == 0 ? 1u : 0u)) : -1;
+        }
+    } else if (wave == 0) {
         int ninv = 0;
         for (int pr = lane; pr < ((a.pt_prows + 63) & ~63); pr += 64) {
             const int v = v0 + pr;
@@ -183,8 +207,60 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     constexpr int NSRC = kNchw ? (kTwo ? 2 : 1) : NIT;
     constexpr int NDST = kNchw ? (kTwo ? 32 : 16) : NIT;
     uint32_t s_src[NSRC], s_dst[NDST];
+    uint32_t s_top = 0;  // kS2, NCHW: bit 31 = the item's row is a top row (oy == 0)
     const uint32_t trash = 2 * bufb + lane * 16 + (wave & 3) * 1024;
-    if constexpr (!kNchw) {
+    if constexpr (kS2 && !kNchw) {
+        // item = (patch row, input pixel x, 16-byte slot); the pixel lands in its parity's half of the row
+        constexpr int PS = NT / SLOTS;
+        const uint32_t slot = tid % SLOTS;
+        uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - m24(pr, W);
+        const uint32_t dpr = pt_div(PS, W, rW), dx = PS - m24(dpr, W);
+        const uint32_t last = (uint32_t)a.pt_prows - 1;
+        int32_t row[NIT];
+        uint32_t prs[NIT], xs[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            prs[it] = pr, xs[it] = x;
+            row[it] = prow_tab[pr < last ? pr : last];
+            x += dx, pr += dpr;
+            if (x >= (uint32_t)W) x -= W, ++pr;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const bool ok = row[it] >= 0 && prs[it] <= last;
+            const uint32_t pos = (xs[it] & 1) ? (xs[it] + 1) >> 1 : (uint32_t)OW + 1 + (xs[it] >> 1);
+            // offset of the ky = 1 row (2 oy); the loads go through a descriptor whose base is one input row in front
+            // of the tensor, + ky rows as the scalar offset
+            s_src[it] = ok ? ((uint32_t)row[it] & ~1u) + m24(xs[it], a.C) + slot * 16 : m24(W, a.C);
+            s_dst[it] = ok ? (m24(m24(prs[it], W1) + pos, PITCH) + slot * 16) | ((uint32_t)row[it] << 31) : trash;
+        }
+    } else if constexpr (kS2) {
+        // item = (patch row, 8-channel group, 16-pixel segment of the input row): consecutive lanes = the segments of a
+        // row, then the channel groups of the stage
+        const uint32_t spr = (uint32_t)a.pt_spr;
+        const uint32_t rest = pt_div(tid, spr, a.pt_rspr), seg = tid - m24(rest, spr);
+        const uint32_t cg = rest % CG, pr = rest / CG;
+        const uint32_t last = (uint32_t)a.pt_prows - 1;
+        const int32_t row = prow_tab[pr < last ? pr : last];
+        const bool run_ok = pr <= last && row >= 0;
+        const int total = a.N * a.C * HW;  // < 2^31 (checked on the host)
+        int k0 = (int)seg * 16;
+        int off = (int)((uint32_t)row & ~1u) + (int)m24(cg * CI, HW) + k0;
+        // the window of the LAST channel of the LAST stage (ky = 2: one row further) must end inside the tensor
+        const int over = run_ok ? off + (a.C - KC + CI - 1) * HW + W + 16 - total : 0;
+        if (over > 0) off -= over, k0 -= over;
+        if (!run_ok || off < 0) off = W;  // (the stage offset reaches one row back)
+        s_src[0] = (uint32_t)off;  // the ky = 1 row (2 oy)
+        const uint32_t top = run_ok ? (uint32_t)row << 31 : 0u;
+        s_top = top;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const int x = k0 + b;
+            const bool ok = run_ok && x >= (int)seg * 16 && x < W;
+            const uint32_t pos = (x & 1) ? (uint32_t)(x + 1) >> 1 : (uint32_t)OW + 1 + ((uint32_t)x >> 1);
+            s_dst[b] = ok ? (m24(m24(pr, W1) + pos, PITCH) + cg * CI) | top : trash;
+        }
+    } else if constexpr (!kNchw) {
         constexpr int PS = NT / SLOTS;  // pixels between a lane's consecutive items
         const uint32_t slot = tid % SLOTS;
         uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - m24(pr, W);
@@ -264,14 +340,29 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // ---- staging of one stage, cut into NP pieces so that the K loop can place them one per MFMA slot:
     // NHWC sd[q] = item q's 16 bytes; NCHW sd[c] = 16 pixels of channel c of the lane's channel group
     v4i sd[NP];
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.in), 0, 0x7fffffff, 0x00020000);
+    // (kS2: the base lies one input row in front of the tensor, the stage adds ky rows)
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(static_cast<const char *>(a.in) - (kS2 && !kNchw ? (ptrdiff_t)W * a.C : 0)), 0, 0x7fffffff, 0x00020000);
     uint32_t tr_o[4][CI / 4];  // NCHW: the four pixels of one dword column, transposed
+    const uint32_t zp4 = (uint32_t)(a.in_zp & 0xff) * 0x01010101u;
     auto stage_load_one = [&](int stage, int it, auto qc) {
         constexpr int q = decltype(qc)::value;
         // NHWC: buffer loads (descriptor + 32-bit lane offset + scalar stage offset): as plain global loads the
         // optimiser turns the loop-invariant lane offsets into 64-bit pointers held across the K loop
-        // kPair: staging `stage` = the only stage of tile `stage`
-        if constexpr (!kNchw) {
+        // kPair: staging `stage` = the only stage of tile `stage`.  kS2: stage = (channel group, filter row ky)
+        if constexpr (kS2) {
+            const int cgs = (stage * 43) >> 7, ky = stage - 3 * cgs;  // stage / 3 for stage < 128
+            if constexpr (!kNchw) {
+                // ky = 0 of a top row (flagged) would start in front of the tensor: read the row itself (replaced at the write)
+                const uint32_t o = s_src[q] + ((ky == 0 && (int32_t)s_dst[q] < 0) ? (uint32_t)(W * a.C) : 0u);
+                sd[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)o, cgs * KC + ky * (W * a.C), 0));
+            } else {
+                // ky = 0 of a top row would start in front of the tensor: read the row itself (replaced at the write)
+                const char *base = static_cast<const char *>(a.in) + ((size_t)cgs * KC * HW + (size_t)(ky * W)) - W;
+                const uint32_t o = s_src[0] + ((ky == 0 && (int32_t)s_top < 0) ? (uint32_t)W : 0u);
+                sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * HW))));
+            }
+        } else if constexpr (!kNchw) {
             sd[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)s_src[q], kPair ? stage * a.pt_pair_in : stage * KC, 0));
         } else {
             const char *base = static_cast<const char *>(a.in) + (kPair ? (size_t)stage * (uint32_t)a.pt_pair_in : (size_t)stage * KC * HW);
@@ -279,11 +370,19 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * HW))));
         }
     };
-    auto stage_write_one = [&](uint32_t bufoff, int it, auto qc) {
+    // top: (kS2) the stage being written is a ky = 0 one -- flagged items (rows with oy == 0) get the zero point
+    auto stage_write_one = [&](uint32_t bufoff, int it, auto qc, bool top = false) {
         constexpr int q = decltype(qc)::value;
         if constexpr (!kNchw) {
-            const uint32_t d = s_dst[q];
-            *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = sd[q];
+            uint32_t d = s_dst[q];
+            v4i v = sd[q];
+            if constexpr (kS2) {
+                const bool t = top && (int32_t)d < 0;
+                d &= 0x7fffffffu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = t ? (int)zp4 : v[e];
+            }
+            *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = v;
         } else {
             // piece q = (dword column jd, channel quad ca): one 4 x 4 byte block of the CI channels x 16 pixels ->
             // 16 pixels x CI channels transposition; after the last quad the column's four pixels go out
@@ -298,13 +397,18 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             if constexpr (ca == QC - 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const uint32_t d = (!kTwo || it == 0) ? s_dst[4 * jd + e] : s_dst[NDST - 16 + 4 * jd + e];
+                    uint32_t d = (!kTwo || it == 0) ? s_dst[4 * jd + e] : s_dst[NDST - 16 + 4 * jd + e];
+                    bool t = false;
+                    if constexpr (kS2) {
+                        t = top && (int32_t)d < 0;
+                        d &= 0x7fffffffu;
+                    }
                     char *dp = smem + (d >= 2 * bufb ? d : d + bufoff);
                     if constexpr (CI == 16) {
                         const v4i v = {(int)tr_o[e][0], (int)tr_o[e][1], (int)tr_o[e][2], (int)tr_o[e][3]};
                         *reinterpret_cast<v4i *>(dp) = v;
                     } else {
-                        *reinterpret_cast<uint2 *>(dp) = make_uint2(tr_o[e][0], tr_o[e][1]);
+                        *reinterpret_cast<uint2 *>(dp) = make_uint2(t ? zp4 : tr_o[e][0], t ? zp4 : tr_o[e][1]);
                     }
                 }
             }
@@ -319,7 +423,6 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // (padding pixel, slot, buffer), units dealt out to the threads (a loop over all patch pixels kept 1 lane in W + 1
     // busy per ds_write_b128: 3 000 cycles)
     {
-        const uint32_t zp4 = (uint32_t)(a.in_zp & 0xff) * 0x01010101u;
         const v4i zv = {(int)zp4, (int)zp4, (int)zp4, (int)zp4};
         constexpr int S2 = 2 * SLOTS;
         const uint32_t n0 = ((uint32_t)a.pt_prows + 1) * S2;
@@ -328,7 +431,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             *reinterpret_cast<v4i *>(smem + (sb / SLOTS ? bufb : 0u) + m24(m24(pr, W1), PITCH) + (sb % SLOTS) * 16) = zv;
         }
         const uint32_t per_row = (uint32_t)W * S2;
-        const uint32_t n1 = (uint32_t)*inv_cnt * per_row;
+        const uint32_t n1 = kS2 ? 0u : (uint32_t)*inv_cnt * per_row;  // (kS2: only the left padding column)
         const float rper = a.pt_rW * (1.0f / S2);  // exact: S2 is a power of two
         for (uint32_t u = tid; u < n1; u += NT) {
             const uint32_t i = pt_div(u, per_row, rper), r2 = u - m24(i, per_row);
@@ -343,16 +446,17 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     uint32_t pbase[NB];
     {
         const uint32_t p0 = (uint32_t)(hb * 32 + frow);
-        uint32_t r = pt_div(p0, W, rW), x = p0 - m24(r, W);
-        const uint32_t d32r = pt_div(32, W, rW), d32x = 32 - m24(d32r, W);
+        uint32_t r = pt_div(p0, OW, rOW), x = p0 - m24(r, OW);
+        const uint32_t d32r = pt_div(32, OW, rOW), d32x = 32 - m24(d32r, OW);
         uint32_t prow[NB], xs[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {  // thirteen table reads, then the arithmetic
             const bool ok = (uint32_t)((hb + j) * 32 + frow) < (uint32_t)RW && row0 + pg * R + (int)r < total_rows;
-            prow[j] = trow_tab[ok ? pg * R + r : 0];  // patch row of the pixel's own input row (>= 1)
+            if constexpr (kS2) prow[j] = ok ? pg * R + r + 1 : 1;  // the tile row itself
+            else prow[j] = trow_tab[ok ? pg * R + r : 0];          // patch row of the pixel's own input row (>= 1)
             xs[j] = ok ? x : 0;
             x += d32x, r += d32r;
-            if (x >= (uint32_t)W) x -= W, ++r;
+            if (x >= (uint32_t)OW) x -= OW, ++r;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) pbase[j] = m24(m24(prow[j] - 1, W1) + xs[j], PITCH) + fhalf * 16 + kp * 32;
@@ -373,7 +477,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     zero_acc();
 
     mark();  // 7: pixel offsets computed
-    static_for<NP>([&](auto qc) { stage_write_one(0, 0, qc); });
+    static_for<NP>([&](auto qc) { stage_write_one(0, 0, qc, kS2); });
     if constexpr (kTwo) {
         if (a.pt_nitc > 1) {
             static_for<NP>([&](auto qc) { stage_load_one(0, 1, qc); });
@@ -400,6 +504,8 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     v4i rb[NB];
     auto tap_off = [&](int step) -> uint32_t {  // LDS offset of a K step's (tap, sub-step); wave-uniform
         const int tap = step / UI, ui = step - tap * UI;
+        if constexpr (kS2)  // kx = 0: slot ox, kx = 1: the even half (Wo + 1 + ox), kx = 2: slot ox + 1
+            return m24((uint32_t)(tap == 1 ? OW + 1 : tap == 0 ? 0 : 1), PITCH) + ui * (KP * 32);
         const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
         return m24((uint32_t)(ty * W1 + tx), PITCH) + ui * (KP * 32);
     };
@@ -421,9 +527,10 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         // the data of stage s + 1 was requested a whole stage ago (at step 5 / 8 of stage s - 1, or in the prologue):
         // requested only four steps ahead, the LDS writes of step 4 waited ~3 000 cycles for HBM in every stage
         const bool two = kTwo && a.pt_nitc > 1;
-        const bool do_write0 = F == 4 && more && step == 4;
+        const bool do_write0 = F == FW && more && step == FW;
+        const bool top_next = kS2 && s + 1 == 3 * (((s + 1) * 43) >> 7);  // the stage being written is a ky = 0 one
         const bool do_write1 = F == 7 && more && step == 7 && two;
-        const bool do_load = !kPair && (two ? F == 8 && step == 8 : F == 5 && step == 5) && s + 2 < nstg;
+        const bool do_load = !kPair && (two ? F == 8 && step == 8 : F == FL && step == FL) && s + 2 < nstg;
         static_for<NB>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             // the last step of a stage reads "next" fragments nobody uses (one code path; LDS reads cannot fault)
@@ -436,16 +543,16 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             constexpr int P0 = j * NP / NB;
             constexpr int P1 = (j + 1) * NP / NB - P0 > 1 ? P0 + 1 : -1;
             static_assert((j + 1) * NP / NB - P0 <= 2 && (j + 1) * NP / NB - P0 >= 1, "one or two pieces per slot");
-            if constexpr (!kPair && (F == 5 || (kTwo && F == 8))) {
+            if constexpr (!kPair && (F == FL || (kTwo && F == 8))) {
                 if (do_load) {
                     stage_load_one(s + 2, 0, std::integral_constant<int, P0>{});
                     if constexpr (P1 >= 0) stage_load_one(s + 2, 0, std::integral_constant<int, P1>{});
                 }
             }
-            if constexpr (kStage && F == 4) {
+            if constexpr (kStage && F == FW) {
                 if (do_write0) {
-                    stage_write_one(nbufoff, 0, std::integral_constant<int, P0>{});
-                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 0, std::integral_constant<int, P1>{});
+                    stage_write_one(nbufoff, 0, std::integral_constant<int, P0>{}, top_next);
+                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 0, std::integral_constant<int, P1>{}, top_next);
                 }
             }
             if constexpr (kStage && kTwo && F == 7) {
@@ -460,7 +567,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                 acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[F % FR], rb[j], acc[j], 0, 0, 0);  // rows = channels
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (kStage && kTwo && F == 4) {
+        if constexpr (kStage && kTwo && F == FW) {
             if (do_write0 && a.pt_nitc > 1) static_for<NP>([&](auto qc) { stage_load_one(s + 1, 1, qc); });
         }
     };
@@ -478,15 +585,15 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                 rb[j] = *reinterpret_cast<const v4i *>(smem + (pbase[j] + cur));
             });
         }
-        for (int step = 0; step < NSTEP; step += 9)
-            static_for<9>([&](auto fc) { kstep(passc, fc, s, step + decltype(fc)::value, bufoff, more); });
+        for (int step = 0; step < NSTEP; step += SPI)
+            static_for<SPI>([&](auto fc) { kstep(passc, fc, s, step + decltype(fc)::value, bufoff, more); });
         mark();        // 6 + 2 s: K steps of the stage done
         pt_barrier();  // every wave is done with this buffer; the next one is complete
         mark();        // 7 + 2 s
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------------
-    const int pixbase = (row0 + pg * R) * W + PASS * a.pt_pair_pix;  // flat output pixel of the pixel group's first pixel
+    const int pixbase = (row0 + pg * R) * OW + PASS * a.pt_pair_pix;  // flat output pixel of the pixel group's first pixel
     char *out = static_cast<char *>(a.out);
     // per-channel tables: NCHW lane = channel (column), NHWC 16 channels per lane (rows 8 g + 4 fhalf + e)
     float4 mu[4], bi[4];
@@ -511,22 +618,22 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     char *e_ptr = out;
     if constexpr (kNchw) {
         const uint32_t m00 = (uint32_t)(pixbase + hb * 32 + fhalf * 16);
-        const uint32_t e_n = pt_div(m00, HW, a.pt_rHW);
-        e_rem = m00 - m24(e_n, HW);
-        e_ptr = out + ((int64_t)(m24(e_n, a.Co) + (uint32_t)(ocb * 32 + frow)) * HW + e_rem);
+        const uint32_t e_n = pt_div(m00, OHW, a.pt_rHW);
+        e_rem = m00 - m24(e_n, OHW);
+        e_ptr = out + ((int64_t)(m24(e_n, a.Co) + (uint32_t)(ocb * 32 + frow)) * OHW + e_rem);
     } else {
         e_ptr = out + (int64_t)(pixbase + hb * 32 + frow) * a.Co + (ocb * 32 + fhalf * 16);
     }
     const int64_t e_step = kNchw ? 32 : (int64_t)32 * a.Co;
-    const int64_t e_wrap = (int64_t)(a.Co - 1) * HW;
+    const int64_t e_wrap = (int64_t)(a.Co - 1) * OHW;
     auto advance = [&]() {
         e_ptr += e_step;
         if constexpr (kNchw) {
             e_rem += 32;
-            if (HW >= 32) {  // wave-uniform: one image boundary at most
-                if (e_rem >= (uint32_t)HW) e_rem -= HW, e_ptr += e_wrap;
+            if (OHW >= 32) {  // wave-uniform: one image boundary at most
+                if (e_rem >= (uint32_t)OHW) e_rem -= OHW, e_ptr += e_wrap;
             } else {
-                while (e_rem >= (uint32_t)HW) e_rem -= HW, e_ptr += e_wrap;
+                while (e_rem >= (uint32_t)OHW) e_rem -= OHW, e_ptr += e_wrap;
             }
         }
     };
@@ -555,22 +662,22 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             // the common case decided ONCE per wave: every lane stores 16 pixels of one plane (whatever the byte address).
             // The general code below is ~220 instructions per block, with its dozen lane-mask branches even when no
             // lane takes them -- three times the requantisation itself
-            if (__builtin_amdgcn_ballot_w64(!(live && full && e_rem + 16 <= (uint32_t)HW)) == 0) {
+            if (__builtin_amdgcn_ballot_w64(!(live && full && e_rem + 16 <= (uint32_t)OHW)) == 0) {
                 const pt_u4 t4 = {v.x, v.y, v.z, v.w};
                 *reinterpret_cast<pt_u4 *>(dst) = t4;
                 return;
             }
             if (!live) return;
             const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-            if (full && e_rem + 16 <= (uint32_t)HW) {  // 16 pixels of one plane
+            if (full && e_rem + 16 <= (uint32_t)OHW) {  // 16 pixels of one plane
                 const pt_u4 t4 = {v.x, v.y, v.z, v.w};
                 *reinterpret_cast<pt_u4 *>(dst) = t4;
-            } else if (full && HW >= 16) {
+            } else if (full && OHW >= 16) {
                 // the run crosses into the next image once (planes of 49 or 196 bytes): dwords that lie inside one piece
                 // go out whole (at whatever byte address), the one that straddles the boundary byte by byte.  Kept small
                 // on purpose: this code sits in every one of the thirteen unrolled blocks
-                const int len1 = HW - (int)e_rem;                        // bytes that still belong to image n
-                char *dst2 = dst + (int64_t)(a.Co - 1) * HW;             // = plane (n + 1, oc) - len1: byte b >= len1 goes to dst2 + b
+                const int len1 = OHW - (int)e_rem;                        // bytes that still belong to image n
+                char *dst2 = dst + (int64_t)(a.Co - 1) * OHW;             // = plane (n + 1, oc) - len1: byte b >= len1 goes to dst2 + b
                 typedef uint32_t u1_a1 __attribute__((aligned(1)));
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -593,9 +700,9 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                     const uint32_t w = (e >> 2) == 0 ? w4[0] : (e >> 2) == 1 ? w4[1] : (e >> 2) == 2 ? w4[2] : w4[3];
                     if (pl0 + e < RW && m0 + e < a.M) *dst = (char)(w >> (8 * (e & 3)));
                     ++dst;
-                    if (++r2 == (uint32_t)HW) {  // next image: same channel plane, Co planes further
+                    if (++r2 == (uint32_t)OHW) {  // next image: same channel plane, Co planes further
                         r2 = 0;
-                        dst += (int64_t)(a.Co - 1) * HW;
+                        dst += (int64_t)(a.Co - 1) * OHW;
                     }
                 }
             }
@@ -667,26 +774,26 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int EPI, bool kNchw, bool kPair, int KC, int PG, int OB, int KP, int NW>
+template <int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_patch_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (NW == 4) {
-        patch_body<EPI, kNchw, kPair, KC, PG, OB, KP, 4, PT_NB>(a, smem, 0);
+        patch_body<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 4, PT_NB>(a, smem, 0);
     } else {
         // the two halves are two straight-line bodies (7 and 6 pixel blocks) behind ONE wave-uniform branch; both pass
         // the same sequence of workgroup barriers
         if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) == 0)
-            patch_body<EPI, kNchw, kPair, KC, PG, OB, KP, 8, 7>(a, smem, 0);
+            patch_body<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 7>(a, smem, 0);
         else
-            patch_body<EPI, kNchw, kPair, KC, PG, OB, KP, 8, 6>(a, smem, 1);
+            patch_body<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 6>(a, smem, 1);
     }
 }
 
-template <int EPI, bool kNchw, bool kPair, int KC, int PG, int OB, int KP, int NW>
+template <int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW>
 static void patch_launch_nw(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
-    auto kernel = conv_igemm_patch_kernel<EPI, kNchw, kPair, KC, PG, OB, KP, NW>;
+    auto kernel = conv_igemm_patch_kernel<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, NW>;
     static bool opted = false;
     if (!opted) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
@@ -698,13 +805,15 @@ static void patch_launch_nw(const ConvArgs &a, unsigned tiles, size_t lds, hipSt
 template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
 static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
-    if (PT_NW8(a.pt_geom)) {
+    if (PT_S2(a.pt_geom)) {
+        if constexpr (KC == 64 && KP <= 2) patch_launch_nw<EPI, kNchw, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
+    } else if (PT_NW8(a.pt_geom)) {
         if constexpr (KP == 1) {  // pair mode exists for eight waves, one K part
-            if (a.pt_pair_in) return patch_launch_nw<EPI, kNchw, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+            if (a.pt_pair_in) return patch_launch_nw<EPI, kNchw, true, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
         }
-        patch_launch_nw<EPI, kNchw, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+        patch_launch_nw<EPI, kNchw, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
     } else {
-        patch_launch_nw<EPI, kNchw, false, KC, PG, OB, KP, 4>(a, tiles, lds, s);
+        patch_launch_nw<EPI, kNchw, false, false, KC, PG, OB, KP, 4>(a, tiles, lds, s);
     }
 }
 

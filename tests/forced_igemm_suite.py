@@ -53,6 +53,14 @@ SHAPES = [
     dict(c=128, co=160, h=3, w=5, n=37),
     dict(c=64, co=64, h=5, w=300, n=1),
     dict(c=192, co=48, h=33, w=17, n=2, act=2),
+    # its stride-2 form (stage = 64 channels x one filter row, columns de-interleaved by parity): top padding rows, tiles
+    # that straddle images, a ragged last tile, 16-pixel NCHW segments that end inside a row, K parts, a wide row
+    dict(c=64, co=64, h=56, w=56, n=2, stride=(2, 2)),
+    dict(c=128, co=96, h=28, w=28, n=5, stride=(2, 2), act=1),
+    dict(c=256, co=64, h=14, w=14, n=9, stride=(2, 2)),
+    dict(c=64, co=40, h=6, w=10, n=3, stride=(2, 2), act=2),
+    dict(c=192, co=32, h=4, w=120, n=2, stride=(2, 2)),
+    dict(c=128, co=128, h=12, w=20, n=40, stride=(2, 2), act=1),
 ]
 F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19]
 
