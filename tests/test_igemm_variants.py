@@ -142,7 +142,8 @@ def _one_image(case, i):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout,exact", [(NHWC, True), (NCHW, True), (NHWC, False)], ids=["NHWC", "NCHW", "NHWC-converter-scales"])
+@pytest.mark.parametrize("layout,exact", [(NHWC, True), (NCHW, True), (NHWC, False), (NCHW, False)],
+                         ids=["NHWC", "NCHW", "NHWC-converter-scales", "NCHW-converter-scales"])
 @pytest.mark.parametrize("idx", range(len(RESNET_3X3)), ids=["%d_%d_at%d" % (s["c"], s["co"], s["h"]) for s in RESNET_3X3])
 def test_resnet50_3x3_batch128_full_size(gpu, idx, layout, exact):
     """exact=False: arbitrary (converter) scales, per channel -- the epilogue then divides by the output scale with
