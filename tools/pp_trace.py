@@ -53,9 +53,15 @@ def main():
         for nm in names:
             print("  %-22s %7d" % (nm, d[k])); k += 1
         st = 0
-        while k + 1 < len(d) - 0 and k + 2 <= len(d) - 1:
-            print("  stage %d steps %7d  barrier %6d" % (st, d[k], d[k + 1])); k += 2; st += 1
-        print("  %-22s %7d" % ("epilogue", d[-1]))
+        L = chain.entries[0]["layer"]
+        pair = L["cin"] == 64 and L["stride"] == 1 and len(d) - k == 6  # pair mode: steps, barrier, epilogue -- twice
+        if pair:
+            for tile in (0, 1):
+                print("  tile %d steps  %7d  barrier %6d  epilogue %6d" % (tile, d[k], d[k + 1], d[k + 2])); k += 3
+        else:
+            while k + 2 <= len(d) - 1:
+                print("  stage %d steps %7d  barrier %6d" % (st, d[k], d[k + 1])); k += 2; st += 1
+            print("  %-22s %7d" % ("epilogue", d[-1]))
         print("  total %d ticks" % (t[n - 1] - t[0]))
         sp = t[64:64 + 2048].reshape(-1, 2)
         sp = sp[sp[:, 1] != 0]
