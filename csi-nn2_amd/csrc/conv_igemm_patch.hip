@@ -130,16 +130,46 @@ int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, in
     // tile t and tile t + nt_m / 2 must be congruent (the same rows of another image) and no tile ragged.  One
     // prologue for two tiles = ~1.7 tile times per workgroup
     ps->pair_dn = 0;
-    static const char *pair_env = getenv("SHL_MI355X_PATCH_PAIR");  // "0": off (A/B)
+    static const char *pair_env = getenv("SHL_MI355X_PATCH_PAIR");  // "0": off (A/B), "1": whenever the tiles pair up (tests)
     const int64_t tiles = (int64_t)nt_m * ps->nt_n;
+    const bool pays = (pair_env && pair_env[0] == '1') || (double)((tiles + 511) / 512) * 1.7 < (double)((tiles + 255) / 256);
     if (!(pair_env && pair_env[0] == '0') && PT_NW8(geom) && C == kc && kp == 1 && nt_m % 2 == 0 && total_rows % tr == 0 &&
-        ((int64_t)(nt_m / 2) * tr) % H == 0 && (double)((tiles + 511) / 512) * 1.7 < (double)((tiles + 255) / 256))
+        ((int64_t)(nt_m / 2) * tr) % H == 0 && pays)
         ps->pair_dn = (int)((int64_t)(nt_m / 2) * tr / H);
     return 1;
 }
 
-// geometry of a forward pass with batch n; false when the patch does not fit LDS / the staging item budget
+bool patch_shape_uncached(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchShape *ps);
+
+// geometry of a forward pass with batch n; false when the patch does not fit LDS / the staging item budget.  The
+// search walks the tiles of every candidate row count: layer-mode callers launch per call, so the last few answers
+// are kept (per thread)
 bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchShape *ps)
+{
+    struct Entry {
+        int key[7];
+        bool ok;
+        PatchShape ps;
+    };
+    static thread_local Entry cache[16];
+    static thread_local int used = 0, next = 0;
+    const int key[7] = {n, H, W, C, Co, nchw ? 1 : 0, geom};
+    for (int i = 0; i < used; ++i)
+        if (!memcmp(cache[i].key, key, sizeof(key))) {
+            *ps = cache[i].ps;
+            return cache[i].ok;
+        }
+    Entry &e = cache[next];
+    next = (next + 1) % 16;
+    used = used < 16 ? used + 1 : 16;
+    memcpy(e.key, key, sizeof(key));
+    e.ps = PatchShape{};
+    e.ok = patch_shape_uncached(n, H, W, C, Co, nchw, geom, &e.ps);
+    *ps = e.ps;
+    return e.ok;
+}
+
+bool patch_shape_uncached(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchShape *ps)
 {
     const int kc = PT_KC(geom), pg = PT_PG(geom);
     if (!kc || C % kc != 0) return false;
@@ -232,8 +262,8 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         // (stride 2: a barrier per three K steps with two K parts, per six with one)
         const double total = rounds * (1.0 / kp + 0.12 + (kp > 1 ? 0.04 : 0.0) + (s2 && kp > 1 ? 0.10 : 0.0));
         static const char *dbg = getenv("SHL_MI355X_DEBUG_GEOM");
-        if (dbg) fprintf(stderr, "patch geom %d,%d,%d nw%d: rows %d prows %d tiles %d x %d lds %d nitc %d cost %.3f\n", pg, ob, kp, PT_NW8(g) ? 8 : 4,
-                         ps.rows, ps.prows, ps.nt_m, ps.nt_n, ps.lds, ps.nitc, total);
+        if (dbg) fprintf(stderr, "patch geom %d,%d,%d nw%d%s: rows %d prows %d tiles %d x %d lds %d nitc %d pair %d cost %.3f\n", pg, ob, kp, PT_NW8(g) ? 8 : 4,
+                         s2 ? " s2" : "", ps.rows, ps.prows, ps.nt_m, ps.nt_n, ps.lds, ps.nitc, ps.pair_dn, total);
         if (!best || total < best_cost - 1e-9) best = g, best_cost = total;
     }
     return best;

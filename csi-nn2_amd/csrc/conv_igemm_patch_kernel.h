@@ -111,7 +111,13 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
 #undef PT_PIN
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 31, fhalf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wv = NW == 8 ? wave >> 1 : wave;  // role: (pixel group, channel block, K part)
+    // role: (pixel group, channel block, K part).  Waves w and w + 4 of a workgroup share a SIMD (HW_ID, tools/probes/
+    // mfma_valu_overlap.hip: w0..w7 -> SIMD 0 2 1 3 0 2 1 3): the two halves of a role are waves w and w + 4, so that every
+    // SIMD carries 7 + 6 blocks (with the halves on neighbouring waves two SIMDs carried 14 and two 12)
+    // (measured per layer, both forms in one run: 1 - 4 % faster except NCHW in pair mode and with four K parts, which
+    // are 2 % slower and keep the halves on neighbouring waves; SHL_MI355X_DEBUG=64 swaps the choice)
+    const bool oldmap = NW == 8 && (((a.debug & 64) != 0) != (kNchw && (kPair || KP == 4)));
+    const int wv = NW == 8 ? (oldmap ? wave >> 1 : wave & 3) : wave;
     const int kp = wv % KP, ob = (wv / KP) % OB, pg = wv / (KP * OB);
     const int hb = h * HB;                      // first pixel block of this wave inside the pixel group
     const int W = a.W, H = a.H, W1 = W + 1, H1 = H + 1, HW = H * W;
@@ -748,7 +754,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                     v16i c = acc[j];
 #pragma unroll
                     for (int o = 1; o < KP; ++o) {
-                        const int other = wave + ((kp + o) % KP - kp) * (NW / 4);  // same role and half, another K part
+                        const int other = wave + ((kp + o) % KP - kp) * (oldmap ? 2 : 1);  // same role and half, another K part
                         const char *src = smem + other * (CH * 4096) + (j - rb) * 4096 + lane * 16;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -783,7 +789,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_patch_kernel(ConvArgs a)
     } else {
         // the two halves are two straight-line bodies (7 and 6 pixel blocks) behind ONE wave-uniform branch; both pass
         // the same sequence of workgroup barriers
-        if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) == 0)
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (((((a.debug & 64) != 0) != (kNchw && (kPair || KP == 4))) ? w & 1 : w >> 2) == 0)
             patch_body<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 7>(a, smem, 0);
         else
             patch_body<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 6>(a, smem, 1);

@@ -61,6 +61,11 @@ SHAPES = [
     dict(c=64, co=40, h=6, w=10, n=3, stride=(2, 2), act=2),
     dict(c=192, co=32, h=4, w=120, n=2, stride=(2, 2)),
     dict(c=128, co=128, h=12, w=20, n=40, stride=(2, 2), act=1),
+    # single-stage layers whose tiles pair up (SHL_MI355X_PATCH_PAIR=1 pairs them at any size: two congruent tiles per
+    # workgroup behind one prologue), incl. 49-byte NCHW planes
+    dict(c=64, co=64, h=8, w=8, n=24),
+    dict(c=128, co=96, h=14, w=14, n=8, act=1),
+    dict(c=64, co=32, h=7, w=7, n=32),
 ]
 F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19]
 

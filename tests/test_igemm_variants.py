@@ -72,6 +72,12 @@ VARIANTS = [
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_WAVES="4"), "patch"),
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_WAVES="4", SHL_MI355X_PATCH="1,2,2"), "patch"),
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_WAVES="4", SHL_MI355X_PATCH="1,1,4"), "patch"),
+    # ... pair mode (two congruent tiles per workgroup) forced wherever the tiles pair up, and the other assignment of
+    # a role's two halves to waves (bit 64)
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_PAIR="1"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_PAIR="1", SHL_MI355X_PATCH="2,2,1"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_PAIR="1", SHL_MI355X_PATCH="1,4,1"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_DEBUG="64"), "patch"),
 ]
 
 
