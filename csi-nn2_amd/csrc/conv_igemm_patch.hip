@@ -151,6 +151,7 @@ bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchS
         bool ok;
         PatchShape ps;
     };
+    geom &= ~(1 << 22);  // PT_NT is a launch flag, not geometry
     static thread_local Entry cache[16];
     static thread_local int used = 0, next = 0;
     const int key[7] = {n, H, W, C, Co, nchw ? 1 : 0, geom};
@@ -327,6 +328,7 @@ bool patch_setup(ConvArgs &a)
     a.pt_rspr = 1.0f / (float)ps.spr;
     a.pt_rntn = 1.0f / (float)ps.nt_n;
     a.pt_rHW = 1.0f / (float)(HO * WO);
+    if (!a.in_nchw && (int64_t)a.M * a.Co >= 20ll << 20) a.pt_geom |= 1 << 22;  // PT_NT: large NHWC outputs past L2
     return true;
 }
 

@@ -25,6 +25,7 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 #define PT_KP(g) (((g) >> 16) & 0xf)
 #define PT_NW8(g) (((g) >> 20) & 1)  // eight waves (two per SIMD) instead of four
 #define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (stage = (channel group, filter row))
+#define PT_NT(g) (((g) >> 22) & 1)   // NHWC output stored non-temporally (set per launch by patch_setup)
 
 // x / d for x < 2^22 (q is within one of the quotient after the float multiply)
 __device__ __forceinline__ uint32_t pt_div(uint32_t x, uint32_t d, float rcp)
@@ -657,7 +658,14 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             const int pl = (hb + j) * 32 + frow;
             const int m = pixbase + pl;
             const int oc = ocb * 32 + fhalf * 16;
-            if (ocb_ok && pl < RW && m < a.M && oc < a.Co) *reinterpret_cast<uint4 *>(e_ptr) = v;
+            if (ocb_ok && pl < RW && m < a.M && oc < a.Co) {
+                typedef uint32_t u4n __attribute__((ext_vector_type(4)));
+                const u4n vn = {v.x, v.y, v.z, v.w};
+                // outputs of >= 20 MB go past L2: the kernel's tail -- the write-back of the dirty lines -- shrinks by 3 us for
+                // 64 -> 64 @56 at batch 128 (25.7 MB); 12.8-MB outputs lose 1.5 us that way, NCHW plane runs gain nothing
+                if (PT_NT(a.pt_geom) != ((a.debug & 2048) != 0)) __builtin_nontemporal_store(vn, reinterpret_cast<u4n *>(e_ptr));
+                else *reinterpret_cast<uint4 *>(e_ptr) = v;
+            }
         } else {
             const int oc = ocb * 32 + frow;
             const int pl0 = (hb + j) * 32 + fhalf * 16;
