@@ -633,17 +633,27 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     }
     const int64_t e_step = kNchw ? 32 : (int64_t)32 * a.Co;
     const int64_t e_wrap = (int64_t)(a.Co - 1) * OHW;
-    auto advance = [&]() {
-        e_ptr += e_step;
+    auto advance_on = [&](char *&p, uint32_t &rem) {
+        p += e_step;
         if constexpr (kNchw) {
-            e_rem += 32;
+            rem += 32;
             if (OHW >= 32) {  // wave-uniform: one image boundary at most
-                if (e_rem >= (uint32_t)OHW) e_rem -= OHW, e_ptr += e_wrap;
+                if (rem >= (uint32_t)OHW) rem -= OHW, p += e_wrap;
             } else {
-                while (e_rem >= (uint32_t)OHW) e_rem -= OHW, e_ptr += e_wrap;
+                while (rem >= (uint32_t)OHW) rem -= OHW, p += e_wrap;
             }
         }
     };
+    auto advance = [&]() { advance_on(e_ptr, e_rem); };
+    // NCHW: blocks in which some lane's 16 pixels do not lie inside one plane are finished in a SECOND pass behind the
+    // block loop (slow_mask, the packed results parked in sv[] -- registers the accumulators have just left).  With that
+    // code (~220 instructions, a dozen lane-mask branches) inside each of the unrolled blocks the loop jumped over it
+    // thirteen times: 1.3 - 1.6 us per launch (measured by compiling it out) although no lane ever took it on the
+    // 56 x 56 and 28 x 28 maps
+    uint32_t slow_mask = 0;
+    uint4 sv[NB];
+    char *const e_ptr0 = e_ptr;
+    const uint32_t e_rem0 = e_rem;
     auto finalize = [&](int j, const v16i &c) {
         uint32_t pk[4];
 #pragma unroll
@@ -672,54 +682,79 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             const int m0 = pixbase + pl0;
             const bool live = ocb_ok && oc < a.Co && pl0 < RW && m0 < a.M;
             const bool full = pl0 + 16 <= RW && m0 + 16 <= a.M;
-            char *dst = e_ptr;
-            // the common case decided ONCE per wave: every lane stores 16 pixels of one plane (whatever the byte address).
-            // The general code below is ~220 instructions per block, with its dozen lane-mask branches even when no
-            // lane takes them -- three times the requantisation itself
-            if (__builtin_amdgcn_ballot_w64(!(live && full && e_rem + 16 <= (uint32_t)OHW)) == 0) {
+            // the common case -- 16 pixels of one plane, at whatever byte address -- is a predicated store; blocks in which
+            // some lane has another case are noted (scalar, no branch in this loop) for the second pass
+            const bool fast = live && full && e_rem + 16 <= (uint32_t)OHW;
+            if (fast) {
                 const pt_u4 t4 = {v.x, v.y, v.z, v.w};
-                *reinterpret_cast<pt_u4 *>(dst) = t4;
-                return;
+                *reinterpret_cast<pt_u4 *>(e_ptr) = t4;
             }
-            if (!live) return;
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-            if (full && e_rem + 16 <= (uint32_t)OHW) {  // 16 pixels of one plane
-                const pt_u4 t4 = {v.x, v.y, v.z, v.w};
-                *reinterpret_cast<pt_u4 *>(dst) = t4;
-            } else if (full && OHW >= 16) {
-                // the run crosses into the next image once (planes of 49 or 196 bytes): dwords that lie inside one piece
-                // go out whole (at whatever byte address), the one that straddles the boundary byte by byte.  Kept small
-                // on purpose: this code sits in every one of the thirteen unrolled blocks
-                const int len1 = OHW - (int)e_rem;                        // bytes that still belong to image n
-                char *dst2 = dst + (int64_t)(a.Co - 1) * OHW;             // = plane (n + 1, oc) - len1: byte b >= len1 goes to dst2 + b
-                typedef uint32_t u1_a1 __attribute__((aligned(1)));
+            sv[j] = v;
+            slow_mask |= __builtin_amdgcn_ballot_w64(!fast) != 0 ? 1u << j : 0u;
+        }
+    };
+    // the general NCHW store of block j (second pass): dst / rem = the lane's first output of the block.  Runs for the
+    // last block of EVERY tile whose pixel count is not a multiple of 32 (392 = 14 x 28 = 7 x 56) on the waves that finish
+    // last, so it is kept short: valid bytes [0, L) of the lane's 16, of which [0, len1) lie in image n and the rest in
+    // image n + 1 (the same channel plane, Co planes further); whole dwords go out whole at whatever byte address, the at
+    // most two dwords that straddle len1 or L byte by byte.  (A byte loop over all 16 cost 1.6 - 2.8 us per launch.)
+    auto store_general = [&](int j, const uint4 &v, char *dst, uint32_t rem) {
+        const int oc = ocb * 32 + frow;
+        const int pl0 = (hb + j) * 32 + fhalf * 16;
+        const int m0 = pixbase + pl0;
+        if (!(ocb_ok && oc < a.Co && pl0 < RW && m0 < a.M)) return;
+        int L = RW - pl0 < a.M - m0 ? RW - pl0 : a.M - m0;  // >= 1
+        L = L < 16 ? L : 16;
+        if (L == 16 && rem + 16 <= (uint32_t)OHW) return;  // stored in the first pass
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        if (OHW >= 16) {
+            const int len1 = OHW - (int)rem;                  // bytes that still belong to image n (> 0)
+            const int l1 = len1 < L ? len1 : L;
+            char *dst2 = dst + (int64_t)(a.Co - 1) * OHW;     // = plane (n + 1, oc) - len1: byte b >= len1 goes to dst2 + b
+            typedef uint32_t u1_a1 __attribute__((aligned(1)));
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    char *p = 4 * d >= len1 ? dst2 : dst;
-                    if (4 * d + 4 <= len1 || 4 * d >= len1) *reinterpret_cast<u1_a1 *>(p + 4 * d) = w4[d];
-                }
-                if (len1 & 3) {
-                    const int d = len1 >> 2;
-                    const uint32_t w = d == 0 ? w4[0] : d == 1 ? w4[1] : d == 2 ? w4[2] : w4[3];
+            for (int d = 0; d < 4; ++d) {
+                if (4 * d + 4 <= l1) *reinterpret_cast<u1_a1 *>(dst + 4 * d) = w4[d];
+                else if (4 * d >= len1 && 4 * d + 4 <= L) *reinterpret_cast<u1_a1 *>(dst2 + 4 * d) = w4[d];
+            }
+            // the dword that holds byte l1 (image boundary or end) and the one that holds byte L (end), when cut
+            const int d1 = (l1 & 3) ? l1 >> 2 : -1;
+            const int d2 = ((L & 3) && (L >> 2) != d1) ? L >> 2 : -1;
 #pragma unroll 1
-                    for (int e = 0; e < 4; ++e) {
-                        char *p = 4 * d + e < len1 ? dst : dst2;
-                        p[4 * d + e] = (char)(w >> (8 * e));
-                    }
-                }
-            } else {
-                uint32_t r2 = e_rem;
+            for (int k = 0; k < 2; ++k) {
+                const int d = k == 0 ? d1 : d2;
+                if (d < 0) continue;
+                const uint32_t w = d == 0 ? w4[0] : d == 1 ? w4[1] : d == 2 ? w4[2] : w4[3];
 #pragma unroll 1
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t w = (e >> 2) == 0 ? w4[0] : (e >> 2) == 1 ? w4[1] : (e >> 2) == 2 ? w4[2] : w4[3];
-                    if (pl0 + e < RW && m0 + e < a.M) *dst = (char)(w >> (8 * (e & 3)));
-                    ++dst;
-                    if (++r2 == (uint32_t)OHW) {  // next image: same channel plane, Co planes further
-                        r2 = 0;
-                        dst += (int64_t)(a.Co - 1) * OHW;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const int b = 4 * d + e;
+                    if (b < L) (b < len1 ? dst : dst2)[b] = (char)(w >> (8 * e));
                 }
             }
+        } else {  // planes of fewer than 16 pixels: several image boundaries inside one run
+            uint32_t r2 = rem;
+#pragma unroll 1
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t w = (e >> 2) == 0 ? w4[0] : (e >> 2) == 1 ? w4[1] : (e >> 2) == 2 ? w4[2] : w4[3];
+                if (e < L) *dst = (char)(w >> (8 * (e & 3)));
+                ++dst;
+                if (++r2 == (uint32_t)OHW) {  // next image: same channel plane, Co planes further
+                    r2 = 0;
+                    dst += (int64_t)(a.Co - 1) * OHW;
+                }
+            }
+        }
+    };
+    auto second_pass = [&]() {
+        if constexpr (kNchw) {
+            if (slow_mask == 0) return;  // wave-uniform
+            char *p = e_ptr0;
+            uint32_t rem = e_rem0;
+            static_for<NB>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (slow_mask & (1u << j)) store_general(j, sv[j], p, rem);
+                advance_on(p, rem);
+            });
         }
     };
 
@@ -732,6 +767,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             advance();
             if (j & 1) __builtin_amdgcn_sched_barrier(0);
         }
+        second_pass();
     } else {
         // K parts: block j is finished by the wave with kp == j % KP; the others hand their partial sums over
         // through LDS (exact int32 adds), CH blocks per round (CH x 4 KiB per wave, 128 KiB in all)
@@ -780,6 +816,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             });
             if constexpr (rb == 0) pt_barrier();
         });
+        second_pass();
     }
     mark();  // epilogue done
     };  // run_pass
