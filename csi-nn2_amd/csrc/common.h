@@ -394,7 +394,7 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch); // pt_geom 
 size_t patch_weight_bytes(const shl_mi355x_conv_desc &d, int geom);
 void patch_pack_weights(const shl_mi355x_conv_desc &d, int geom, const int8_t *src, int8_t *dst);
 bool patch_setup(ConvArgs &a);                                      // fills pt_rows .. pt_spr for a.N; false: does not fit
-bool patch_auto(const ConvArgs &a);                                 // the automatic choice takes it (enough tiles)
+bool patch_auto(const ConvArgs &a, bool vs_wave = false);                                 // the automatic choice takes it (enough tiles)
 int launch_conv_igemm_patch(const ConvArgs &a, hipStream_t s);
 // [N][R][S] -> [N][S][R] for 1- or 2-byte elements (layout.hip)
 int launch_transpose(const void *src, void *dst, int64_t n, int R, int S, int esize, hipStream_t s, int to_nhwc);

@@ -972,6 +972,8 @@ const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
     if (forced_patch) return "tile";
     if ((!ov[0] || !strcmp(ov, "res")) && res_applies(a, esize)) return "res";
     if (!strcmp(ov, "res")) return "tile";  // shapes the resident-weights kernel does not take
+    // mid-size batches of 3x3 layers: too few block tiles for the tile kernels, yet the row-patch kernel has its ~100 tiles
+    if (!ov[0] && esize == 1 && a.w_patch && !strcmp(igemm_variant(a.M, a.Co), "wave") && patch_auto(a, true)) return "patch";
     const bool forced_pc = !strcmp(ov, "pc");
     if (forced_pc || !ov[0]) {
         const int f = pc_flavour(a, esize, forced_pc);

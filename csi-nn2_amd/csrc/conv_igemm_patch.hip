@@ -332,7 +332,9 @@ bool patch_setup(ConvArgs &a)
     return true;
 }
 
-bool patch_auto(const ConvArgs &a)
+// vs_wave: the alternative is the barrier-free wave kernel (fewer than 128 block tiles of 128 x 128), whose time grows
+// with the batch while a patch launch stays at ~one tile time: 256 -> 256 @14 at batch 32 36 us against 15
+bool patch_auto(const ConvArgs &a, bool vs_wave)
 {
     static const char *env = getenv("SHL_MI355X_PATCH");
     if (env && env[0] == '0') return false;
@@ -342,11 +344,18 @@ bool patch_auto(const ConvArgs &a)
     if (!patch_setup(t)) return false;
     PatchShape ps;
     patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
-    if ((int64_t)ps.nt_m * ps.nt_n < (PT_S2(a.pt_geom) ? 192 : 96)) return false;  // fewer tiles than that: the latency-oriented kernels
+    // fewer tiles than that: the latency-oriented kernels.  Measured over batches 8 .. 256 (tools/dev/batch_sweep.sh): NCHW
+    // wins from 96 tiles (the alternative is a re-layout pass around another kernel), NHWC only once most CUs have a
+    // tile (64 -> 64 @56 at batch 16 = 128 tiles: 10.6 us against the tile kernel's 8.4)
+    const bool s2 = PT_S2(a.pt_geom);
+    if ((int64_t)ps.nt_m * ps.nt_n < ((s2 || (!a.in_nchw && !vs_wave)) ? 192 : 96)) return false;
+    // the stride-2 form beyond 256 input channels is >= 24 stages of three K steps: 512 -> 512 @14 at batch 256 takes 94 us
+    // against 52 through the re-layout pass + producer / consumer kernel
+    if (s2 && a.C > 256) return false;
     // NHWC with four K parts (512 channels @7 at batch 128): nine K steps per stage and the exchange of partial sums
     // leave it behind the producer / consumer kernel (25.4 vs 22.4 us); NCHW takes it anyway -- the alternative there
     // is two re-layout passes around that kernel (39 vs 47 us)
-    if (!a.in_nchw && PT_KP(a.pt_geom) == 4) return false;
+    if (!a.in_nchw && PT_KP(a.pt_geom) == 4 && !vs_wave) return false;
     return true;
 }
 

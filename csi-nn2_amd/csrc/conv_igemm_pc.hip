@@ -403,7 +403,10 @@ int pc_flavour(const ConvArgs &a, int esize, bool forced)
     if (a.kstride < 1024 || t256 >= 300) return -1;
     const int64_t t128 = (((int64_t)a.M + 127) / 128) * ((a.Co + 127) / 128);
     if (t256 >= 160) return 2;  // sixteen waves: 22.0 vs 23.3 us on 256 -> 256 @28 s2, 21.5-22.0 vs 22.6 on 256 -> 256 @14
-    return t128 >= 128 ? 1 : -1;
+    // below ~one 128 x 128 tile per other CU the choice used to fall to the barrier-free wave kernel, whose time grows
+    // with K x tiles: 512 -> 512 @14 stride 2 at batch 64 (100 tiles, K = 4 608) 70 us.  A producer / consumer tile of
+    // that depth is ~17 us whatever the number of tiles (tools/dev/batch_sweep.sh)
+    return t128 >= (a.kstride >= 2048 ? 24 : 64) ? 1 : -1;
 }
 
 template <typename G>
