@@ -352,7 +352,7 @@ int launch_conv_direct(const ConvArgs &a, int dtype, int layout, int dw_nhwc_wei
 int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 bool igemm_supports(const shl_mi355x_conv_desc &d);
-const char *igemm_variant(int64_t M, int64_t Co);  // "tile" | "regs" | "wave"
+const char *igemm_variant(int64_t M, int64_t Co, int64_t kbytes = 0);  // "tile" | "regs" | "wave"; kbytes: K row bytes when known
 const char *igemm_pick_name(const ConvArgs &a, int esize);  // + "pp": the kernel family launch_conv_igemm will use
 bool igemm_fuses_nchw_out(const ConvArgs &a, int esize);  // the block-tile kernels store NCHW themselves
 bool dwconv_supports(const shl_mi355x_conv_desc &d);

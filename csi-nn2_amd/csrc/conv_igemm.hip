@@ -992,7 +992,7 @@ const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
         }
         if (forced_pp) return "tile";  // shapes the ping-pong kernel does not take
     }
-    return igemm_variant(a.M, a.Co);
+    return igemm_variant(a.M, a.Co, a.kstride);
 }
 
 const char *igemm_pick_name(const ConvArgs &a, int esize) { return igemm_pick(a, esize, nullptr); }
@@ -1005,7 +1005,7 @@ bool igemm_fuses_nchw_out(const ConvArgs &a, int esize)
     return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc") || !strcmp(v, "res") || !strcmp(v, "patch");
 }
 
-const char *igemm_variant(int64_t M, int64_t Co)
+const char *igemm_variant(int64_t M, int64_t Co, int64_t kbytes)
 {
     const char *ov = variant_override();
     if (ov[0] && strcmp(ov, "pp") && strcmp(ov, "pc") && strcmp(ov, "res") && strcmp(ov, "patch")) return ov;
@@ -1013,7 +1013,10 @@ const char *igemm_variant(int64_t M, int64_t Co)
     // LDS tile kernel once there is at least ~one 128x128 tile for every other CU; below that
     // (MobileNetV1 at batch 1: 1-98 tiles) latency dominates and the barrier-free wave kernel wins
     const int64_t blocks128 = ((M + BM - 1) / BM) * ((Co + BN - 1) / BN);
-    return blocks128 >= 128 ? "tile" : "wave";
+    // ... from 96 tiles when K is deep (pointwise 512 -> 512 @14 at batch 16, 100 tiles: 7.6 us against 8.9; 1024 -> 1024 @7
+    // at batch 32: 9.5 against 13.5; at 52 tiles the wave kernel is still ahead, 6.1 against 7.5), from 128 otherwise
+    // (32 -> 64 @112 at batch 1 is 98 tiles of K = 32)
+    return blocks128 >= (kbytes >= 512 ? 96 : 128) ? "tile" : "wave";
 }
 
 int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
