@@ -1016,7 +1016,8 @@ const char *igemm_variant(int64_t M, int64_t Co, int64_t kbytes)
     // ... from 96 tiles when K is deep (pointwise 512 -> 512 @14 at batch 16, 100 tiles: 7.6 us against 8.9; 1024 -> 1024 @7
     // at batch 32: 9.5 against 13.5; at 52 tiles the wave kernel is still ahead, 6.1 against 7.5), from 128 otherwise
     // (32 -> 64 @112 at batch 1 is 98 tiles of K = 32)
-    return blocks128 >= (kbytes >= 512 ? 96 : 128) ? "tile" : "wave";
+    // (K rows of 8 KiB and more -- binary16 512 -> 512 3x3 -- from 24: 47 us against 67 at batch 16, 28 tiles)
+    return blocks128 >= (kbytes >= 8192 ? 24 : kbytes >= 512 ? 96 : 128) ? "tile" : "wave";
 }
 
 int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
