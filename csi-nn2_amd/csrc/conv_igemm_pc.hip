@@ -406,7 +406,8 @@ int pc_flavour(const ConvArgs &a, int esize, bool forced)
     // below ~one 128 x 128 tile per other CU the choice used to fall to the barrier-free wave kernel, whose time grows
     // with K x tiles: 512 -> 512 @14 stride 2 at batch 64 (100 tiles, K = 4 608) 70 us.  A producer / consumer tile of
     // that depth is ~17 us whatever the number of tiles (tools/dev/batch_sweep.sh)
-    return t128 >= (a.kstride >= 2048 ? 24 : 64) ? 1 : -1;
+    // (K = 1 152: 128 -> 128 @28 at batch 4 / 8, 25 / 49 tiles, 12.3 / 12.5 us on the wave kernel, ~8.7 here)
+    return t128 >= 24 ? 1 : -1;
 }
 
 template <typename G>
