@@ -153,7 +153,12 @@ static bool dwm_geometry(int C, int sh, int sw, int Ho, int Wo, int N, DwmGeom &
 {
     g.cb = (C % 128 == 0) ? 128 : ((C % 64 == 0) ? 64 : 32);
     g.btx = Wo <= 8 ? 1 : 2;               // MFMA pixel tiles are 8 wide x 4 high
-    g.bty = (sh == 1 && sw == 1) ? 2 : 1;  // stride 2 patches are 4x the pixels: half the rectangle
+    // rows of MFMA tiles per workgroup: stride 2 patches are 4x the pixels, so half the rectangle; narrow channel blocks
+    // (a 32- / 64-byte pixel) take twice the rows -- less halo per output, and the patch still is a few KiB
+    // (MobileNetV1 at batch 128: 32 ch @112 43.7 -> 36.0 us, 64 ch @112 stride 2 34.1 -> 32.2; 128-byte pixels lose)
+    const bool s1 = sh == 1 && sw == 1;
+    g.bty = s1 ? (g.cb <= 32 ? 4 : 2) : (g.cb <= 64 ? 2 : 1);
+    while (g.bty > 1 && (g.bty - 1) * 4 >= Ho) --g.bty;
     g.tiles_x = (Wo + g.btx * 8 - 1) / (g.btx * 8);
     g.tiles_y = (Ho + g.bty * 4 - 1) / (g.bty * 4);
     g.pw = (g.btx * 8 - 1) * sw + 3;
@@ -187,6 +192,16 @@ int launch_dwconv_mfma(const ConvArgs &a, hipStream_t s)
     }
     const dim3 grid((unsigned)(a.C / g.cb), (unsigned)g.tiles_x, (unsigned)(g.tiles_y * a.N));
     const size_t lds = (size_t)g.npieces * 1024 + (size_t)g.cb * 12;
+    static bool opted = false;
+    if (!opted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        opted = true;
+    }
     switch (epi_code(a)) {
         case 0: hipLaunchKernelGGL((dwconv3x3_i8_mfma_kernel<0>), grid, dim3(256), lds, s, a, g); break;
         case 1: hipLaunchKernelGGL((dwconv3x3_i8_mfma_kernel<1>), grid, dim3(256), lds, s, a, g); break;
