@@ -21,15 +21,16 @@ namespace shl {
 constexpr int STEM_K = 27, STEM_KG = 7;
 
 template <int COP, int EPI>  // COP: output channels padded to 32 or 64
-__global__ __launch_bounds__(64) void conv_stem_i8_kernel(ConvArgs a)
+__global__ __launch_bounds__(256) void conv_stem_i8_kernel(ConvArgs a)
 {
     __shared__ __attribute__((aligned(16))) int32_t w_lds[STEM_KG * COP];
     __shared__ __attribute__((aligned(16))) int32_t t_acc[COP];
     __shared__ __attribute__((aligned(16))) float t_mult[COP];
     __shared__ __attribute__((aligned(16))) float t_bias[COP];
     const int tid = threadIdx.x;
-    for (int i = tid; i < STEM_KG * COP; i += 64) w_lds[i] = static_cast<const int32_t *>(a.w)[i];
-    for (int i = tid; i < COP; i += 64) {  // tables are padded to a multiple of 128 entries
+    const int nthr = blockDim.x;  // 64 in the latency regime, 256 for large batches (the tables are staged per workgroup)
+    for (int i = tid; i < STEM_KG * COP; i += nthr) w_lds[i] = static_cast<const int32_t *>(a.w)[i];
+    for (int i = tid; i < COP; i += nthr) {  // tables are padded to a multiple of 128 entries
         t_acc[i] = a.acc_init[i];
         t_mult[i] = a.mult[i];
         t_bias[i] = a.bias[i];
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64) void conv_stem_i8_kernel(ConvArgs a)
     // a pixel's channels are split over COP/16 adjacent threads (16 channels = one 16-byte store
     // each): at batch 1 the layer is latency-bound and the per-thread dot4 chain is the long pole
     constexpr int NSPLIT = COP / 16;
-    const int gid = blockIdx.x * 64 + tid;
+    const int gid = blockIdx.x * nthr + tid;
     const int p = gid / NSPLIT;
     const int cb = (gid % NSPLIT) * 16;
     const bool live = p < a.M && cb < a.Co;
@@ -129,16 +130,18 @@ int launch_conv_stem(const ConvArgs &a, hipStream_t s)
 {
     if (a.M == 0) return SHL_MI355X_OK;
     const int nsplit = a.Co <= 32 ? 2 : 4;  // COP / 16 threads per pixel
-    const dim3 grid((unsigned)(((int64_t)a.M * nsplit + 63) / 64));
+    // workgroups of 256 threads once there are a few waves per SIMD anyway (batch 128: 57 us with 64-thread workgroups)
+    const int thr = (int64_t)a.M * nsplit >= (1 << 20) ? 256 : 64;
+    const dim3 grid((unsigned)(((int64_t)a.M * nsplit + thr - 1) / thr));
     const int epi = epi_code(a);
 #define SHL_STEM(COP)                                                                                              \
     switch (epi) {                                                                                                 \
-        case 0: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 0>), grid, dim3(64), 0, s, a); break;                  \
-        case 1: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 1>), grid, dim3(64), 0, s, a); break;                  \
-        case 2: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 2>), grid, dim3(64), 0, s, a); break;                  \
-        case 3: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 3>), grid, dim3(64), 0, s, a); break;                  \
-        case 4: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 4>), grid, dim3(64), 0, s, a); break;                  \
-        default: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 5>), grid, dim3(64), 0, s, a); break;                 \
+        case 0: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 0>), grid, dim3(thr), 0, s, a); break;                  \
+        case 1: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 1>), grid, dim3(thr), 0, s, a); break;                  \
+        case 2: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 2>), grid, dim3(thr), 0, s, a); break;                  \
+        case 3: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 3>), grid, dim3(thr), 0, s, a); break;                  \
+        case 4: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 4>), grid, dim3(thr), 0, s, a); break;                  \
+        default: hipLaunchKernelGGL((conv_stem_i8_kernel<COP, 5>), grid, dim3(thr), 0, s, a); break;                 \
     }
     if (a.Co <= 32) { SHL_STEM(32) } else { SHL_STEM(64) }
 #undef SHL_STEM
