@@ -400,7 +400,7 @@ int pc_flavour(const ConvArgs &a, int esize, bool forced)
     // automatic (ResNet-50 3x3 set at batch 128, profiles/r02_notes.md): deep-K layers with at most ~one 256 x 128
     // tile per CU -- 256 -> 256 @14 27.3 -> 22.9 us, 512 -> 512 @7 (196 tiles of 128 x 128) 25.7 -> 22.9 us; with
     // more tiles than that the two-workgroups-per-CU ping-pong flavour overlaps whole tiles and stays ahead
-    if (a.kstride < 1024 || t256 >= 300) return -1;
+    if (a.kstride < (a.Kh * a.Kw == 1 ? 512 : 1024) || t256 >= 300) return -1;  // (pointwise: 512 -> 1024 @7 at batch 128 9.2 us against 10.5)
     const int64_t t128 = (((int64_t)a.M + 127) / 128) * ((a.Co + 127) / 128);
     if (t256 >= 160) return 2;  // sixteen waves: 22.0 vs 23.3 us on 256 -> 256 @28 s2, 21.5-22.0 vs 22.6 on 256 -> 256 @14
     // below ~one 128 x 128 tile per other CU the choice used to fall to the barrier-free wave kernel, whose time grows

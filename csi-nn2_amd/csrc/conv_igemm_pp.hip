@@ -442,7 +442,8 @@ int pp_flavour(const ConvArgs &a, int esize, bool forced)
     // tiles of 256 x 128 per CU the two-workgroups-per-CU flavour wins (each workgroup's prologue, first DMA
     // wait and epilogue -- 40-45 % of a tile's time -- overlap the other's K loop: 128->128 @28 33.0 -> 27.8 us);
     // with one tile per CU or fewer the round-1 kernels are level or ahead and keep the layer
-    if (a.kstride < 1024) return -1;
+    // (pointwise layers from K = 512 bytes: 512 -> 512 @14 at batch 128 17.5 us against the tile kernel's 19.9)
+    if (a.kstride < (a.Kh * a.Kw == 1 ? 512 : 1024)) return -1;
     if (a.Co <= 64) return -1;  // half of a 256 x 128 tile's channels would be idle: the tile kernel has a 256 x 64 form (binary16 64 -> 64 @56 at batch 64: 55.5 us against 69.8)
     if (m256 * ((a.Co + 127) / 128) >= 300) return 3;
     return -1;
