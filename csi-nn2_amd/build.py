@@ -133,6 +133,8 @@ def build_oracle(force=False):
         # the reference's own layer tests against the backend (oracle/Makefile.layer_tests): after build_host
         if os.path.exists(ref_so) and os.path.exists(os.path.join(LIB, "libshl_mi355x_opt.so")):
             _run(["make", "-s", "-f", os.path.join(odir, "Makefile.layer_tests")] + (["-B"] if force else []))
+            # the reference's model example, unchanged, on the backend and on the reference kernels (oracle/Makefile.example)
+            _run(["make", "-s", "-f", os.path.join(odir, "Makefile.example")] + (["-B"] if force else []))
     return ref_so if os.path.exists(ref_so) else None
 
 

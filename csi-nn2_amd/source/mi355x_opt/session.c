@@ -287,6 +287,9 @@ int shl_mi355x_session_setup(struct csinn_session *sess)
     drop_session(sess);
     struct shl_ref_graph *g = shl_gref_get_graph(sess);
     if (g == NULL || g->layer_index == 0) return rc;
+    /* SHL_MI355X_HOST_SESSION=1: keep the executor's host path (every layer staged and traced on its own) */
+    const char *host_only = getenv("SHL_MI355X_HOST_SESSION");
+    if (host_only && host_only[0] == '1') return rc;
 
     /* device-resident only when every layer runs on the GPU */
     int tensors = g->input_num;

@@ -6,6 +6,7 @@
  * :391-413 shl_target_init_*), for slot CSINN_MI355X.
  */
 #include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "mi355x_internal.h"
@@ -535,4 +536,26 @@ void shl_target_init_mi355x(void)
     }
     shl_register_op_callback(CSINN_MI355X, shl_cb_map_mi355x);
     shl_register_runtime_callback(CSINN_MI355X, shl_mi355x_runtime_callback);
+    /* SHL_MI355X_SLOT=<api>: occupy one more dispatch slot, see shl_target_init_mi355x_slot */
+    const char *slot = getenv("SHL_MI355X_SLOT");
+    if (slot && *slot) shl_target_init_mi355x_slot(atoi(slot));
+}
+
+/* The backend under another backend's name.  Programs generated for a RISC-V target hard-code that target's
+ * dispatch slot (example/c906_mobilenetv1_f16.c:24: `sess->base_api = CSINN_C906`); on a host whose libshl does not
+ * contain that target the slot is empty, and registering there lets such a program run UNCHANGED on the GPU.
+ * Nothing in the backend depends on the slot number: callbacks are found through params->base.api / sess->base_api,
+ * whatever they are (source/nn2/setup.c:101-125). */
+int shl_target_init_mi355x_slot(int api)
+{
+    if (api < 0 || api >= CSINN_API_SIZE || api == CSINN_REF || api == CSINN_GREF) {
+        shl_debug_error("mi355x: dispatch slot %d cannot be taken\n", api);
+        return CSINN_FALSE;
+    }
+    shl_target_init_mi355x();
+    if (api != CSINN_MI355X) {
+        shl_register_op_callback(api, shl_cb_map_mi355x);
+        shl_register_runtime_callback(api, shl_mi355x_runtime_callback);
+    }
+    return CSINN_TRUE;
 }

@@ -25,6 +25,10 @@ extern "C" {
 
 /* registers the op map and the runtime map in slot CSINN_MI355X */
 void shl_target_init_mi355x(void);
+/* ... and in one more slot `api` (also: environment SHL_MI355X_SLOT=<api> at shl_target_init_mi355x time), so that a
+ * program that hard-codes another target's slot -- example/c906_mobilenetv1_f16.c:24 uses CSINN_C906 -- dispatches
+ * to this backend unchanged.  CSINN_REF / CSINN_GREF are refused.  CSINN_TRUE on success */
+int shl_target_init_mi355x_slot(int api);
 struct csinn_callback *shl_cb_map_mi355x(int op, int dtype);
 void *shl_mi355x_runtime_callback(int runtime_op);
 
