@@ -298,6 +298,8 @@ def load_backend(frontend):
         opt.shl_mi355x_get_stream.restype = C.c_void_p
         opt.shl_mi355x_release_params.argtypes = [C.c_void_p]
         opt.shl_mi355x_live_plans.argtypes = [C.POINTER(C.c_int64)]
+        opt.shl_mi355x_plans_created.restype = C.c_int64
+        opt.shl_target_init_mi355x_slot.argtypes = [C.c_int]
         opt.shl_mi355x_params_const_block.restype = C.c_void_p
         opt.shl_mi355x_params_const_block.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         opt.shl_mi355x_params_kernel_name.restype = C.c_char_p

@@ -346,6 +346,27 @@ int hip_fail(hipError_t e, const char *what);
         if (e_ != hipSuccess) return shl::hip_fail(e_, #expr); \
     } while (0)
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute is
+// per DEVICE and the library lets a process switch devices (shl_mi355x_set_device), so the "done" state is a bit per
+// device ordinal; the call is idempotent, so two threads racing here at worst both make it.  A failure is recorded
+// (set_error) and surfaces as the error of the launch that follows.
+struct LdsOptIn {
+    unsigned long long done = 0;
+};
+inline void lds_opt_in(LdsOptIn &st, const void *kernel, int bytes = 160 * 1024)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&st.done, __ATOMIC_ACQUIRE) & bit) return;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        return;
+    }
+    __atomic_fetch_or(&st.done, bit, __ATOMIC_RELEASE);
+}
+
 // ---- launchers implemented by the kernel translation units ----------------------------------
 int launch_conv_direct(const ConvArgs &a, int dtype, int layout, int dw_nhwc_weights,
                        hipStream_t s);

@@ -938,12 +938,8 @@ bool igemm_supports(const shl_mi355x_conv_desc &d)
 template <void (*KERNEL)(ConvArgs)>
 static void launch_kernel(dim3 grid, size_t lds, hipStream_t s, const ConvArgs &a, int threads = 256)
 {
-    static bool opted_in = false;
-    if (lds > 64 * 1024 && !opted_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        opted_in = true;
-    }
+    static LdsOptIn opted_in;
+    if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(KERNEL));
     hipLaunchKernelGGL(KERNEL, grid, dim3(threads), lds, s, a);
 }
 
@@ -1005,7 +1001,8 @@ bool igemm_fuses_nchw_out(const ConvArgs &a, int esize)
     ConvArgs t = a;
     t.out_nchw = 1;
     const char *v = igemm_pick(t, esize, nullptr);
-    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc") || !strcmp(v, "res") || !strcmp(v, "patch");
+    // (not the row-patch kernel: its output layout is its input's, patch_setup refuses the mixed case)
+    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc") || !strcmp(v, "res");
 }
 
 const char *igemm_variant(int64_t M, int64_t Co, int64_t kbytes)

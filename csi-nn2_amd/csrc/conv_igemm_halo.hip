@@ -481,12 +481,8 @@ static int halo_max_pixels(const ConvArgs &a, int tbm)
 template <void (*KERNEL)(ConvArgs)>
 static void launch_halo(dim3 grid, int threads, size_t lds, hipStream_t s, const ConvArgs &a)
 {
-    static bool opted_in = false;
-    if (lds > 64 * 1024 && !opted_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        opted_in = true;
-    }
+    static LdsOptIn opted_in;
+    if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(KERNEL));
     hipLaunchKernelGGL(KERNEL, grid, dim3(threads), lds, s, a);
 }
 

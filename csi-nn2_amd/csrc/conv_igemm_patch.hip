@@ -308,6 +308,11 @@ void patch_pack_weights(const shl_mi355x_conv_desc &d, int geom, const int8_t *s
 bool patch_setup(ConvArgs &a)
 {
     if (!a.w_patch || !a.pt_geom) return false;
+    // the output layout follows the input's (no a.out_nchw in the kernel): conv_forward's scratch fallback hands an NHWC
+    // view of an NCHW layer to kernels that store NCHW themselves -- not this one; the NHWC epilogue stores 16 channels
+    // per lane
+    if ((a.out_nchw != 0) != (a.in_nchw != 0)) return false;
+    if (!a.in_nchw && a.Co % 16 != 0) return false;
     PatchShape ps;
     if (!patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps)) return false;
     a.pt_rows = ps.rows;

@@ -846,11 +846,8 @@ template <int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int
 static void patch_launch_nw(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
     auto kernel = conv_igemm_patch_kernel<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, NW>;
-    static bool opted = false;
-    if (!opted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
-        opted = true;
-    }
+    static LdsOptIn opted;
+    lds_opt_in(opted, reinterpret_cast<const void *>(kernel), PT_LDS_MAX);
     hipLaunchKernelGGL(kernel, dim3(tiles), dim3(NW * 64), lds, s, a);
 }
 

@@ -416,12 +416,8 @@ static void pc_launch(const ConvArgs &a, bool i8, int epi, hipStream_t s)
     const unsigned tiles = (unsigned)(((a.M + G::BM - 1) / G::BM) * ((a.Co + G::BN - 1) / G::BN));
 #define SHL_PC(KERNEL)                                                                                            \
     do {                                                                                                          \
-        static bool opted = false;                                                                                \
-        if (!opted) {                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      160 * 1024);                                                                \
-            opted = true;                                                                                         \
-        }                                                                                                         \
+        static LdsOptIn opted;                                                                                    \
+        lds_opt_in(opted, reinterpret_cast<const void *>(KERNEL));                                                \
         hipLaunchKernelGGL(KERNEL, dim3(tiles), dim3(G::THREADS), G::LDS_B, s, a);                                       \
     } while (0)
     if (!i8) {

@@ -434,12 +434,8 @@ static void pcx_launch(const ConvArgs &a, bool i8, int epi, hipStream_t s)
     const unsigned tiles = (unsigned)(((a.M + G::BM - 1) / G::BM) * ((a.Co + G::BN - 1) / G::BN));
 #define SHL_PCX(...)                                                                                              \
     do {                                                                                                          \
-        static bool opted = false;                                                                                \
-        if (!opted) {                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_pcx_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      160 * 1024);                                                                \
-            opted = true;                                                                                         \
-        }                                                                                                         \
+        static LdsOptIn opted;                                                                                    \
+        lds_opt_in(opted, reinterpret_cast<const void *>(conv_igemm_pcx_kernel<__VA_ARGS__>));                    \
         hipLaunchKernelGGL((conv_igemm_pcx_kernel<__VA_ARGS__>), dim3(tiles), dim3(G::THREADS), G::LDS_B, s, a);   \
     } while (0)
     if (!i8) {

@@ -411,12 +411,8 @@ int launch_conv_igemm_res(const ConvArgs &a_in, hipStream_t s)
     const unsigned grid = (unsigned)((ntiles + rounds - 1) / rounds);
 #define SHL_RES(...)                                                                                                \
     do {                                                                                                            \
-        static bool opted = false;                                                                                  \
-        if (!opted) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_res_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      160 * 1024);                                                                  \
-            opted = true;                                                                                           \
-        }                                                                                                           \
+        static LdsOptIn opted;                                                                                      \
+        lds_opt_in(opted, reinterpret_cast<const void *>(conv_igemm_res_kernel<__VA_ARGS__>));                      \
         hipLaunchKernelGGL((conv_igemm_res_kernel<__VA_ARGS__>), dim3(grid), dim3(512), lds, s, a);                 \
     } while (0)
     if (a.debug == 32) {  // traced builds: the literal epilogue and the usual exact-scale + clamp one

@@ -47,7 +47,10 @@ struct PlanFlags {
     int32_t div_exact, div_fma, act_clamp;
     float clamp_lo, clamp_hi, inv_out_scale;
     int32_t pt_geom;
-    uint32_t reserved[8];
+    // what the packing of the block itself depends on: a receiver whose own plan differs holds bytes it cannot read
+    int32_t algo, kstride;
+    uint64_t block_bytes;
+    uint32_t reserved[4];
 };
 static_assert(sizeof(PlanFlags) == 64, "flags record");
 constexpr uint32_t PLAN_FLAGS_MAGIC = 0x53484c46u;  // "SHLF"
@@ -355,6 +358,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         f.div_exact = p->div_exact, f.div_fma = p->div_fma, f.act_clamp = p->act_clamp;
         f.clamp_lo = p->clamp_lo, f.clamp_hi = p->clamp_hi, f.inv_out_scale = p->inv_out_scale;
         f.pt_geom = p->pt_geom;
+        f.algo = algo, f.kstride = p->kstride, f.block_bytes = p->block_bytes;
         memcpy(host.data() + p->off_flags, &f, sizeof(f));
     }
     // padding value: the input zero point (int8) / 0.0 (f16)
@@ -584,13 +588,18 @@ int shl_mi355x_conv_plan_adopt_block(shl_mi355x_conv_plan *plan, void *stream)
         set_error("conv_plan_adopt_block: the block carries no flags record (sender built from another library version?)");
         return SHL_MI355X_EINVAL;
     }
-    if ((f.pt_geom != 0) != (plan->off_wpatch != 0)) {
-        set_error("conv_plan_adopt_block: sender and receiver disagree about the row-patch weight copy");
+    // the kernel family, the packed row length, the section offsets and the row-patch wave roles decide how the block's
+    // bytes are read: a sender that planned otherwise (its tables put it on the direct kernel, another batch another
+    // geometry) cannot be adopted -- its epilogue flags belong to ITS kernel (div_exact = div_fma = 0 is only legal there)
+    if (f.algo != plan->algo || f.kstride != plan->kstride || f.block_bytes != plan->block_bytes || f.pt_geom != plan->pt_geom) {
+        set_error("conv_plan_adopt_block: sender planned algo %d / K row %d / %llu bytes / patch roles 0x%x, receiver algo %d / %d / "
+                  "%llu / 0x%x -- create the receiver's plan from the same descriptor, batch and table regime",
+                  f.algo, f.kstride, (unsigned long long)f.block_bytes, (unsigned)f.pt_geom, plan->algo, plan->kstride,
+                  (unsigned long long)plan->block_bytes, (unsigned)plan->pt_geom);
         return SHL_MI355X_EINVAL;
     }
     plan->div_exact = f.div_exact, plan->div_fma = f.div_fma, plan->act_clamp = f.act_clamp;
     plan->clamp_lo = f.clamp_lo, plan->clamp_hi = f.clamp_hi, plan->inv_out_scale = f.inv_out_scale;
-    plan->pt_geom = f.pt_geom;
     return SHL_MI355X_OK;
 }
 

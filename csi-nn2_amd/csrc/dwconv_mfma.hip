@@ -192,15 +192,13 @@ int launch_dwconv_mfma(const ConvArgs &a, hipStream_t s)
     }
     const dim3 grid((unsigned)(a.C / g.cb), (unsigned)g.tiles_x, (unsigned)(g.tiles_y * a.N));
     const size_t lds = (size_t)g.npieces * 1024 + (size_t)g.cb * 12;
-    static bool opted = false;
-    if (!opted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        opted = true;
+    static LdsOptIn opted[6];
+    {
+        const void *fns[6] = {reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<0>), reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<1>),
+                              reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<2>), reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<3>),
+                              reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<4>), reinterpret_cast<const void *>(dwconv3x3_i8_mfma_kernel<5>)};
+        const int e = epi_code(a);
+        if (e >= 0 && e < 6) lds_opt_in(opted[e], fns[e]);
     }
     switch (epi_code(a)) {
         case 0: hipLaunchKernelGGL((dwconv3x3_i8_mfma_kernel<0>), grid, dim3(256), lds, s, a, g); break;

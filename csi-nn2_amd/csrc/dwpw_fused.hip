@@ -255,12 +255,8 @@ int launch_dwpw_fused(const ConvArgs &d, const ConvArgs &q, hipStream_t s)
     }
     // depthwise constants (24 B per channel) + the reduce-scatter slots
     const size_t lds = (size_t)d.C * 24 + 384 + (ksw > 1 ? (size_t)4 * ksw * 64 * 16 : 0);
-    static bool opted_in = false;
-    if (lds > 64 * 1024 && !opted_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwpw_fused_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        opted_in = true;
-    }
+    static LdsOptIn opted_in;
+    if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(dwpw_fused_kernel));
     if (lds > 160 * 1024) {
         set_error("dwpw_fused: %d channels do not fit the LDS staging", d.C);
         return SHL_MI355X_ENOTSUP;

@@ -402,14 +402,10 @@ int launch_conv1x1_nchw(const ConvArgs &a, int dtype, hipStream_t s)
     const size_t lds = (size_t)nw * per * 1024;
     static const char *tr_env = getenv("SHL_MI355X_NCHW_TR");  // "0": the gather kernel (A/B)
     if (lds <= 64 * 1024 && !(tr_env && tr_env[0] == '0')) {
-        static bool opted[2] = {false, false};
+        static LdsOptIn opted[2];
         const int ki = dtype == SHL_MI355X_I8 ? 0 : 1;
-        if (!opted[ki]) {
-            (void)hipFuncSetAttribute(ki == 0 ? reinterpret_cast<const void *>(conv1x1_nchw_tr_kernel<true>)
-                                              : reinterpret_cast<const void *>(conv1x1_nchw_tr_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            opted[ki] = true;
-        }
+        lds_opt_in(opted[ki], ki == 0 ? reinterpret_cast<const void *>(conv1x1_nchw_tr_kernel<true>)
+                                      : reinterpret_cast<const void *>(conv1x1_nchw_tr_kernel<false>), 96 * 1024);
         if (dtype == SHL_MI355X_I8)
             hipLaunchKernelGGL((conv1x1_nchw_tr_kernel<true>), grid, dim3(threads), lds, s, a);
         else

@@ -261,12 +261,8 @@ extern "C" int shl_mi355x_softmax(const void *input_dev, void *output_dev, int32
         return SHL_MI355X_ENOTSUP;
     }
     const size_t lds = (size_t)count * 8 + 256 * 4;
-    static bool opted_in = false;
-    if (lds > 48 * 1024 && !opted_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(shl::softmax_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        opted_in = true;
-    }
+    static shl::LdsOptIn opted_in;
+    if (lds > 48 * 1024) shl::lds_opt_in(opted_in, reinterpret_cast<const void *>(shl::softmax_kernel), 96 * 1024);
     static const char *seq_env = getenv("SHL_MI355X_SOFTMAX_SEQ");  // "1": the literal one-lane running sum (A/B, tests)
     hipLaunchKernelGGL(shl::softmax_kernel, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, input_dev,
                        output_dev, (int)dtype, (int)count, inner, in_scale, (float)in_zp, out_scale, (float)out_zp,

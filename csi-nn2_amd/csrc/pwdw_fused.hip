@@ -287,12 +287,8 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
     const size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
 #define SHL_PWDW(NSWV, MAXT)                                                                                         \
     do {                                                                                                       \
-        static bool opted_in = false;                                                                          \
-        if (lds > 64 * 1024 && !opted_in) {                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT>),       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-            opted_in = true;                                                                                   \
-        }                                                                                                      \
+        static LdsOptIn opted_in;                                                                              \
+        if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT>)); \
         hipLaunchKernelGGL((pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT>), grid, dim3(64 * f.nwaves), lds, s, f);                   \
     } while (0)
     if (f.nsw <= 2)

@@ -265,12 +265,8 @@ int launch_pwdw_stream(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
     const size_t lds = (size_t)2 * f.mt * 32 * kc + (size_t)f.mt * 32 * 128 + 6 * 128 * 4;
 #define SHL_PDS(NS)                                                                                    \
     do {                                                                                               \
-        static bool opted_in = false;                                                                  \
-        if (lds > 64 * 1024 && !opted_in) {                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pwdw_stream_kernel<NS>),          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
-            opted_in = true;                                                                           \
-        }                                                                                              \
+        static LdsOptIn opted_in;                                                                      \
+        if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(pwdw_stream_kernel<NS>)); \
         hipLaunchKernelGGL((pwdw_stream_kernel<NS>), grid, dim3(512), lds, s, f);                      \
     } while (0)
     switch (nsub) {

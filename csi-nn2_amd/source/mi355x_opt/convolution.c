@@ -18,7 +18,6 @@
  */
 #include <math.h>
 #include <stdlib.h>
-#include <pthread.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -505,69 +504,71 @@ static int dwconv_channel_init_act(CSINN_CONV_ARGS, int act)
 }
 
 /* The reference's protocol for these ids has no init: its exec re-reads kernel, bias and quantisation records on every
- * call.  The backend plans on the first exec and keeps the plan under the params block -- with a fingerprint of what
- * it was built from (tensor data pointers, record pointers, first record, geometry), so that a caller who swaps
- * weights or records between calls gets a new plan instead of the stale one.  (Weights rewritten IN PLACE behind the
- * same pointers are not seen: the plan snapshots them at first exec; call shl_mi355x_release_params to force a rebuild.) */
+ * call.  The backend plans on the first exec and keeps the plan under the params block -- together with a fingerprint
+ * of what it was built from, stored in the registry slot NEXT TO the plan (released with it by registry_put /
+ * shl_mi355x_release_params; a recycled params address therefore never meets a stale fingerprint, and there is no
+ * fixed-size table to fill up).  The fingerprint holds VALUES -- geometry, the activation records' numbers, a hash
+ * over every per-channel kernel record -- plus the weight / bias data pointers: a caller that allocates fresh tensor
+ * structs or records per inference keeps its plan; one that swaps weights or changes a scale gets a new one.
+ * (Weights rewritten IN PLACE behind the same pointers are not seen: the plan snapshots them at first exec; call
+ * shl_mi355x_release_params to force a rebuild.) */
 struct channel_key {
-    void *params;
-    const void *kdata, *bdata, *kq, *iq, *oq;
-    float kscale0, iscale, oscale;
-    int32_t kzp0, izp, ozp, omult, oshift;
+    const void *kdata, *bdata;
+    uint64_t krecords; /* FNV-1a over {zero_point, scale} of every kernel record */
+    float iscale, oscale;
+    int32_t izp, ozp, omult, oshift, kchannels, act;
     int32_t dims[12];
+    int32_t geom[8];
 };
-static struct channel_key g_channel_keys[64];
-static pthread_mutex_t g_channel_lock = PTHREAD_MUTEX_INITIALIZER;
 
-static void channel_key_of(struct channel_key *k, CSINN_CONV_ARGS)
+static void channel_key_of(struct channel_key *k, CSINN_CONV_ARGS, int act)
 {
     memset(k, 0, sizeof(*k));
-    k->params = params;
-    k->kdata = kernel->data, k->kq = kernel->qinfo;
+    k->kdata = kernel->data;
     k->bdata = bias ? bias->data : NULL;
-    k->iq = input->qinfo, k->oq = output->qinfo;
-    k->kscale0 = kernel->qinfo->scale, k->kzp0 = kernel->qinfo->zero_point;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (int c = 0; c < kernel->quant_channel; c++) {
+        unsigned char rec[8];
+        memcpy(rec, &kernel->qinfo[c].zero_point, 4);
+        memcpy(rec + 4, &kernel->qinfo[c].scale, 4);
+        for (int b = 0; b < 8; b++) h = (h ^ rec[b]) * 0x100000001b3ull;
+    }
+    k->krecords = h;
+    k->kchannels = kernel->quant_channel;
+    k->act = act;
     k->iscale = input->qinfo->scale, k->izp = input->qinfo->zero_point;
     k->oscale = output->qinfo->scale, k->ozp = output->qinfo->zero_point;
     k->omult = output->qinfo->multiplier, k->oshift = output->qinfo->shift;
     for (int i = 0; i < 4; i++) k->dims[i] = input->dim[i], k->dims[4 + i] = kernel->dim[i], k->dims[8 + i] = output->dim[i];
-}
-
-/* 1: the plan under `params` was built from exactly this; 0: first sight or something changed (key updated) */
-static int channel_key_matches(const struct channel_key *k)
-{
-    int hit = 0;
-    pthread_mutex_lock(&g_channel_lock);
-    size_t h = ((uintptr_t)k->params >> 4) % 64;
-    for (int probe = 0; probe < 64; probe++, h = (h + 1) % 64) {
-        if (g_channel_keys[h].params == k->params) {
-            hit = memcmp(&g_channel_keys[h], k, sizeof(*k)) == 0;
-            g_channel_keys[h] = *k;
-            break;
-        }
-        if (g_channel_keys[h].params == NULL) {
-            g_channel_keys[h] = *k;
-            break;
-        }
-    }
-    pthread_mutex_unlock(&g_channel_lock);
-    return hit;
+    k->geom[0] = params->stride_height, k->geom[1] = params->stride_width, k->geom[2] = params->pad_top;
+    k->geom[3] = params->pad_left, k->geom[4] = params->dilation_height, k->geom[5] = params->dilation_width;
+    k->geom[6] = params->group, k->geom[7] = params->base.layout;
 }
 
 static int channel_exec(CSINN_CONV_ARGS, int (*init_act)(CSINN_CONV_ARGS, int), int act, const char *what)
 {
+    if (input->qinfo == NULL || output->qinfo == NULL || kernel->qinfo == NULL) return CSINN_FALSE;
     struct channel_key key;
-    channel_key_of(&key, input, output, kernel, bias, params);
-    const int same = channel_key_matches(&key);
-    if (shl_mi355x_registry_get(params) == NULL || !same) {
+    channel_key_of(&key, input, output, kernel, bias, params, act);
+    if (!shl_mi355x_registry_tag_matches(params, &key, sizeof(key))) {
         int rc = init_act(input, output, kernel, bias, params, act); /* registry_put releases a previous plan */
         if (rc != CSINN_TRUE) return rc;
+        shl_mi355x_registry_set_tag(params, &key, sizeof(key));
     }
     return run_plan(&params->base, input, output, input->dim[0], what);
 }
 
 #define CHANNEL_OP(stem, init_fn, act, what)                                                               \
-    int shl_mi355x_##stem##_init(CSINN_CONV_ARGS) { return init_fn(input, output, kernel, bias, params, act); } \
+    int shl_mi355x_##stem##_init(CSINN_CONV_ARGS)                                                          \
+    {                                                                                                      \
+        int rc = init_fn(input, output, kernel, bias, params, act);                                        \
+        if (rc == CSINN_TRUE) { /* an explicit init: exec must not plan a second time */                   \
+            struct channel_key key;                                                                        \
+            channel_key_of(&key, input, output, kernel, bias, params, act);                                \
+            shl_mi355x_registry_set_tag(params, &key, sizeof(key));                                        \
+        }                                                                                                  \
+        return rc;                                                                                         \
+    }                                                                                                      \
     int shl_mi355x_##stem##_exec(CSINN_CONV_ARGS)                                                          \
     {                                                                                                      \
         return channel_exec(input, output, kernel, bias, params, init_fn, act, what);                      \

@@ -11,6 +11,9 @@ void shl_mi355x_registry_put(void *params, shl_mi355x_conv_plan *plan);
 void shl_mi355x_registry_put_group(void *params, shl_mi355x_conv_plan **plans, int n); /* takes the array */
 shl_mi355x_conv_plan *shl_mi355x_registry_get(void *params);
 shl_mi355x_conv_plan *shl_mi355x_registry_get_group(void *params, int i);
+/* a fingerprint of what the plan under `params` was built from, stored WITH the plan (released with it) */
+void shl_mi355x_registry_set_tag(void *params, const void *tag, size_t bytes);
+int shl_mi355x_registry_tag_matches(void *params, const void *tag, size_t bytes);
 
 /* Per-session execution context: the stream exec callbacks enqueue on and the session's own HBM
  * staging buffers (setup.c).  ctx_of(NULL) is the context of session-less calls. */

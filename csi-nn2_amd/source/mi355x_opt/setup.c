@@ -168,9 +168,13 @@ struct slot {
     shl_mi355x_conv_plan *plan;
     shl_mi355x_conv_plan **sub;
     int nsub;
+    void *tag; /* what the plan was built from, for callbacks that plan at exec time (CSINN_OP_*_CHANNEL): lives and
+                * dies with the plan, so there is no second table to fill up or to go stale */
+    size_t tag_bytes;
 };
 static struct slot *g_slots;
 static size_t g_cap, g_used;
+static int64_t g_stored; /* plans (or plan groups) ever bound: see shl_mi355x_plans_created */
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 #define TOMBSTONE ((void *)(uintptr_t)1)
 
@@ -200,12 +204,15 @@ static void rehash(size_t cap)
     free(old);
 }
 
+static struct slot *find(void *params);
+
 static void destroy_contents(struct slot *s)
 {
     if (s->plan) shl_mi355x_conv_plan_destroy(s->plan);
     for (int i = 0; i < s->nsub; i++)
         if (s->sub[i]) shl_mi355x_conv_plan_destroy(s->sub[i]);
     free(s->sub);
+    free(s->tag);
 }
 
 /* (re)binds `params` to a plan, or to `nsub` per-group plans (ownership of the array passes) */
@@ -230,8 +237,49 @@ static void registry_store(void *params, shl_mi355x_conv_plan *plan, shl_mi355x_
     g_slots[h].plan = plan;
     g_slots[h].sub = sub;
     g_slots[h].nsub = nsub;
+    g_slots[h].tag = NULL;
+    g_slots[h].tag_bytes = 0;
+    g_stored++;
     pthread_mutex_unlock(&g_lock);
     destroy_contents(&stale);
+}
+
+int64_t shl_mi355x_plans_created(void)
+{
+    pthread_mutex_lock(&g_lock);
+    const int64_t n = g_stored;
+    pthread_mutex_unlock(&g_lock);
+    return n;
+}
+
+/* attach a copy of `tag` to the plan bound to `params` (replaces an earlier one) */
+void shl_mi355x_registry_set_tag(void *params, const void *tag, size_t bytes)
+{
+    void *copy = malloc(bytes ? bytes : 1);
+    if (copy == NULL) return;
+    memcpy(copy, tag, bytes);
+    pthread_mutex_lock(&g_lock);
+    struct slot *s = find(params);
+    void *old = NULL;
+    if (s) {
+        old = s->tag;
+        s->tag = copy;
+        s->tag_bytes = bytes;
+        copy = NULL;
+    }
+    pthread_mutex_unlock(&g_lock);
+    free(old);
+    free(copy);
+}
+
+/* 1 when `params` has a plan whose tag equals these bytes */
+int shl_mi355x_registry_tag_matches(void *params, const void *tag, size_t bytes)
+{
+    pthread_mutex_lock(&g_lock);
+    struct slot *s = find(params);
+    const int hit = s && (s->plan || s->nsub) && s->tag && s->tag_bytes == bytes && memcmp(s->tag, tag, bytes) == 0;
+    pthread_mutex_unlock(&g_lock);
+    return hit;
 }
 
 void shl_mi355x_registry_put(void *params, shl_mi355x_conv_plan *plan) { registry_store(params, plan, NULL, 0); }
@@ -282,6 +330,8 @@ int shl_mi355x_release_params(void *params)
         s->plan = NULL;
         s->sub = NULL;
         s->nsub = 0;
+        s->tag = NULL;
+        s->tag_bytes = 0;
     }
     pthread_mutex_unlock(&g_lock);
     if (dead.plan == NULL && dead.nsub == 0) return CSINN_FALSE;

@@ -49,6 +49,9 @@ int shl_mi355x_session_has_own_stream(struct csinn_session *sess);
 int shl_mi355x_release_params(void *params);
 /* number of live plans and their total HBM bytes (leak checks in tests) */
 int shl_mi355x_live_plans(int64_t *hbm_bytes);
+/* how many times a plan (or a grouped layer's plan set) has been bound to a params block since the library was loaded:
+ * lets a caller see that an exec-time planner (the CSINN_OP_*_CHANNEL ids) does NOT plan again on a repeated call */
+int64_t shl_mi355x_plans_created(void);
 /* device block of the plan attached to `params` (for the RCCL weight broadcast) */
 void *shl_mi355x_params_const_block(void *params, size_t *bytes);
 /* multi-GPU setup: RCCL broadcast of the layers' constant blocks from rank `root` over the

@@ -403,7 +403,7 @@ def oracle_channel_run(case):
     return out
 
 
-def csinn_channel_run(fe, api, case, device=None, call_init=True, keep_params=None, reuse_params=None):
+def csinn_channel_run(fe, api, case, device=None, call_init=True, keep_params=None, reuse_params=None, repeat=1):
     """shl_op_callback_map(CSINN_OP_*_CHANNEL*) + cb->init (if any) + cb->exec through front-end `fe`.
     reuse_params: an entry a previous call left in `keep_params` -- the SAME params block is called with this case's tensors."""
     keep = pkg.Keep()
@@ -451,9 +451,10 @@ def csinn_channel_run(fe, api, case, device=None, call_init=True, keep_params=No
             raise pkg.MI355XError("init of op %d returned %d" % (op, rc))
     if not cb.exec:
         raise pkg.MI355XError("op %d has no exec callback" % op)
-    rc = fn_t(cb.exec)(t_in, t_out, t_w, t_b, params)
-    if rc != pkg.CSINN_TRUE:
-        raise pkg.MI355XError("exec of op %d returned %d" % (op, rc))
+    for _ in range(repeat):  # the same tensors again: an exec-time planner must keep its plan
+        rc = fn_t(cb.exec)(t_in, t_out, t_w, t_b, params)
+        if rc != pkg.CSINN_TRUE:
+            raise pkg.MI355XError("exec of op %d returned %d" % (op, rc))
     if device is not None:
         out = device.download(dev_out, out.shape, out.dtype)
         device.free(dev_in)
