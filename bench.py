@@ -485,7 +485,12 @@ def main():
                    "process_group": "none" if world == 1 else "gloo (bootstrap only: RCCL id, flags, barriers, MAX of window times)",
                    "device_memory": "C-ABI allocator (shl_mi355x_malloc)",
                    "ops_per_image": ops_per_image, "algorithmic_bytes_per_image": chain.total_bytes() // batch,
-                   "device": arch.value.decode(), "compute_units": cus.value},
+                   "device": arch.value.decode(), "compute_units": cus.value,
+                   # what proves N distinct devices took part: every rank's PCI bus id (hipDeviceGetPCIBusId through the
+                   # C-ABI, gathered over the bootstrap group) and the rank count RCCL itself reports for the communicator
+                   "device_bus_ids": par.LAST_BROADCAST.get("bus_ids") or [par.device_bus_id(hip)],
+                   "distinct_devices": par.LAST_BROADCAST.get("distinct_devices", 1),
+                   "rccl_nranks": par.LAST_BROADCAST.get("rccl_nranks")},
     }
 
     def finish():

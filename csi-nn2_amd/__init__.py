@@ -194,6 +194,8 @@ def load_hip():
         "shl_mi355x_comm_unique_id": (C.c_int, [vp]),
         "shl_mi355x_comm_create": (C.c_int, [vp, i32, i32, C.POINTER(vp)]),
         "shl_mi355x_comm_destroy": (C.c_int, [vp]),
+        "shl_mi355x_comm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "shl_mi355x_device_bus_id": (C.c_int, [C.c_char_p, sz]),
         "shl_mi355x_comm_bcast": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), i32, i32, vp]),
         "shl_mi355x_conv_plan_destroy": (C.c_int, [vp]),
         "shl_mi355x_conv_plan_algo": (C.c_int, [vp]),

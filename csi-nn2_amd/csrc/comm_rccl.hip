@@ -25,6 +25,9 @@ struct RcclApi {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*GroupStart)();
     ncclResult_t (*GroupEnd)();
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *);
     const char *(*GetErrorString)(ncclResult_t);
 };
 
@@ -53,6 +56,9 @@ static RcclApi *rccl()
         SHL_SYM(Broadcast, "ncclBroadcast")
         SHL_SYM(GroupStart, "ncclGroupStart")
         SHL_SYM(GroupEnd, "ncclGroupEnd")
+        SHL_SYM(CommCount, "ncclCommCount")
+        SHL_SYM(CommUserRank, "ncclCommUserRank")
+        SHL_SYM(CommCuDevice, "ncclCommCuDevice")
         SHL_SYM(GetErrorString, "ncclGetErrorString")
 #undef SHL_SYM
         state = 1;
@@ -115,6 +121,25 @@ int shl_mi355x_comm_destroy(void *comm)
     if (!r || !comm) return SHL_MI355X_OK;
     ncclResult_t e = r->CommDestroy((ncclComm_t)comm);
     return e == ncclSuccess ? SHL_MI355X_OK : rccl_fail(r, e, "ncclCommDestroy");
+}
+
+int shl_mi355x_comm_info(void *comm, int32_t *nranks, int32_t *rank, int32_t *device)
+{
+    RcclApi *r = rccl();
+    if (!r) return SHL_MI355X_ENOTSUP;
+    if (!comm) {
+        set_error("comm_info: NULL communicator");
+        return SHL_MI355X_EINVAL;
+    }
+    int n = 0, me = 0, dev = 0;
+    ncclResult_t e = r->CommCount((ncclComm_t)comm, &n);
+    if (e == ncclSuccess) e = r->CommUserRank((ncclComm_t)comm, &me);
+    if (e == ncclSuccess) e = r->CommCuDevice((ncclComm_t)comm, &dev);
+    if (e != ncclSuccess) return rccl_fail(r, e, "ncclCommCount / UserRank / CuDevice");
+    if (nranks) *nranks = n;
+    if (rank) *rank = me;
+    if (device) *device = dev;
+    return SHL_MI355X_OK;
 }
 
 int shl_mi355x_comm_bcast(void *comm, void *const *blocks_dev, const size_t *bytes, int32_t count, int32_t root,

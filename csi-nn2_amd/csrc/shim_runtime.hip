@@ -72,6 +72,18 @@ int shl_mi355x_device_info(char *arch, size_t arch_len, int32_t *cu_count, int64
     return SHL_MI355X_OK;
 }
 
+int shl_mi355x_device_bus_id(char *buf, size_t len)
+{
+    if (!buf || len < 14) {
+        shl::set_error("device_bus_id: need a buffer of at least 14 bytes");
+        return SHL_MI355X_EINVAL;
+    }
+    int dev = 0;
+    SHL_HIP(hipGetDevice(&dev));
+    SHL_HIP(hipDeviceGetPCIBusId(buf, (int)len, dev));
+    return SHL_MI355X_OK;
+}
+
 void *shl_mi355x_malloc(size_t bytes)
 {
     void *p = nullptr;

@@ -102,7 +102,35 @@ def broadcast_plan_blocks(chain, torch, dist, hip, src=0):
     return n
 
 
-def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c=True):
+def device_bus_id(hip):
+    """PCI bus id of this process's current device through the C-ABI ("" when there is none)"""
+    import ctypes as C
+    buf = C.create_string_buffer(32)
+    return buf.value.decode() if hip.shl_mi355x_device_bus_id(buf, 32) == 0 else ""
+
+
+def gather_bus_ids(torch, dist, mine):
+    """every rank's PCI bus id, in rank order (32 bytes each over the bootstrap group)"""
+    ctl = _control_device(dist)
+    raw = mine.encode()[:32].ljust(32, b"\0")
+    t = torch.tensor(list(raw), dtype=torch.uint8, device=ctl)
+    out = [torch.zeros(32, dtype=torch.uint8, device=ctl) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [bytes(o.cpu().tolist()).rstrip(b"\0").decode() for o in out]
+
+
+def shared_devices(bus_ids):
+    """{bus id: [ranks]} for every device that more than one rank sits on ("" = a rank without a device)"""
+    seen = {}
+    for r, b in enumerate(bus_ids):
+        seen.setdefault(b, []).append(r)
+    return {b: rs for b, rs in seen.items() if len(rs) > 1 or b == ""}
+
+
+LAST_BROADCAST = {}  # facts about the last broadcast_weights call of this process (bench.py puts them into its JSON line)
+
+
+def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c=True, bus_id=None):
     """The one-time weight broadcast of `chain`.  Preferred: RCCL behind the C boundary -- rank `src` draws an
     ncclUniqueId through the C-ABI, the 128 bytes travel over the process group that already exists (bootstrap
     only), every rank creates the communicator and calls shl_mi355x_bcast_const_blocks (host code stays C, as
@@ -112,6 +140,16 @@ def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c
     import ctypes as C
     why = "disabled"
     ctl = _control_device(dist)  # the process group is bootstrap only: small CPU tensors under gloo
+    # one device per rank is what ncclCommInitRank needs; ranks that share a device (or have none) must find out HERE,
+    # over the bootstrap group, not inside a collective that then waits for a peer that can never join
+    bus_ids = gather_bus_ids(torch, dist, device_bus_id(hip) if bus_id is None else bus_id)
+    shared = shared_devices(bus_ids)
+    LAST_BROADCAST.clear()
+    LAST_BROADCAST.update(bus_ids=bus_ids, distinct_devices=len(set(b for b in bus_ids if b)), rccl_nranks=None)
+    if shared:
+        prefer_c = False
+        why = "RCCL refused before ncclCommInitRank: " + "; ".join(
+            ("ranks %s have no device" % rs) if b == "" else ("ranks %s share device %s" % (rs, b)) for b, rs in sorted(shared.items()))
     if prefer_c:
         ok = torch.tensor([int(hip.shl_mi355x_comm_available())], dtype=torch.int32, device=ctl)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -128,6 +166,9 @@ def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c
             good = torch.tensor([int(rc == 0)], dtype=torch.int32, device=ctl)
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
             if int(good.item()) == 1:
+                nr, me, dv = C.c_int32(), C.c_int32(), C.c_int32()
+                if hip.shl_mi355x_comm_info(comm, C.byref(nr), C.byref(me), C.byref(dv)) == 0:
+                    LAST_BROADCAST.update(rccl_nranks=nr.value, rccl_rank=me.value, rccl_device=dv.value)
                 n = len(chain.entries)
                 params = (C.c_void_p * n)(*[C.cast(e["params"], C.c_void_p) for e in chain.entries])
                 rc = opt.shl_mi355x_bcast_const_blocks(comm, params, n, src, chain.sess)

@@ -105,6 +105,9 @@ int shl_mi355x_device_count(void);
 int shl_mi355x_set_device(int ordinal);
 /* "gfx950:sramecc+:xnack-", compute-unit count, HBM bytes of the current device */
 int shl_mi355x_device_info(char *arch, size_t arch_len, int32_t *cu_count, int64_t *hbm_bytes);
+/* PCI bus id "dddd:bb:dd.f" of the current device (hipDeviceGetPCIBusId): what tells the ranks of a multi-GPU job
+ * that they really sit on distinct devices before they enter a collective */
+int shl_mi355x_device_bus_id(char *buf, size_t len);
 
 /* ---- memory and streams (stand in for hipMalloc/hipMemcpyAsync/hipStream*) --------- */
 void *shl_mi355x_malloc(size_t bytes);
@@ -173,6 +176,8 @@ int shl_mi355x_comm_available(void);
 int shl_mi355x_comm_unique_id(void *id128);
 int shl_mi355x_comm_create(const void *id128, int32_t rank, int32_t world, void **comm_out);
 int shl_mi355x_comm_destroy(void *comm);
+/* what RCCL itself says about a communicator: ncclCommCount / ncclCommUserRank / ncclCommCuDevice */
+int shl_mi355x_comm_info(void *comm, int32_t *nranks, int32_t *rank, int32_t *device);
 int shl_mi355x_comm_bcast(void *comm, void *const *blocks_dev, const size_t *bytes, int32_t count, int32_t root,
                           void *stream);
 

@@ -81,6 +81,38 @@ def test_weight_broadcast_under_gloo_world_size_2(tmp_path):
     assert line == "RESULT ok=1 collectives=2 covered=1024", line
 
 
+GUARD_WORKER = textwrap.dedent("""
+    import os, sys, importlib
+    sys.path.insert(0, %(root)r)
+    import torch, torch.distributed as dist
+    sharding = importlib.import_module("csi-nn2_amd.sharding")
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank = dist.get_rank()
+    same = sharding.gather_bus_ids(torch, dist, "0000:05:00.0")
+    apart = sharding.gather_bus_ids(torch, dist, "0000:%%02x:00.0" %% (5 + rank))
+    none = sharding.gather_bus_ids(torch, dist, "")
+    if rank == 0:
+        print("RESULT", same, sharding.shared_devices(same), apart, sharding.shared_devices(apart), sharding.shared_devices(none))
+    dist.destroy_process_group()
+""")
+
+
+def test_ranks_that_share_a_device_find_out_before_the_collective(tmp_path):
+    """ncclCommInitRank with two ranks on ONE device must not be entered (it fails late or hangs).
+    broadcast_weights gathers every rank's PCI bus id over the bootstrap group first and refuses RCCL with a message
+    naming the ranks and the device; here the gathering and the verdict under gloo, world size 2, no GPU."""
+    script = tmp_path / "guard.py"
+    script.write_text(GUARD_WORKER % dict(root=cases.ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29619", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0]
+    assert line == ("RESULT ['0000:05:00.0', '0000:05:00.0'] {'0000:05:00.0': [0, 1]} "
+                    "['0000:05:00.0', '0000:06:00.0'] {} {'': [0, 1]}"), line
+
+
 def test_rccl_entry_points_without_a_gpu(built):
     """The C-ABI side of the weight broadcast (csrc/comm_rccl.hip): librccl is opened on first use; bad
     arguments and the absence of a device are reported, never a crash."""
@@ -96,6 +128,11 @@ def test_rccl_entry_points_without_a_gpu(built):
         assert hip.shl_mi355x_comm_create(uid, 0, 1, C.byref(comm)) != 0           # no device: refused loudly
         assert b"device" in hip.shl_mi355x_last_error().lower()
     assert hip.shl_mi355x_comm_destroy(None) == 0
+    assert hip.shl_mi355x_comm_info(None, None, None, None) in (-2, -3)            # EINVAL / ENOTSUP
+    buf = C.create_string_buffer(32)
+    if hip.shl_mi355x_device_count() == 0:
+        assert hip.shl_mi355x_device_bus_id(buf, 32) != 0                          # no device: an error, not garbage
+    assert hip.shl_mi355x_device_bus_id(buf, 4) != 0                               # buffer too small
 
 
 @pytest.mark.gpu
@@ -148,3 +185,8 @@ def test_bench_shards_a_total_batch_over_two_ranks_on_one_device():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["per_gpu_batch"] == 5
     assert "batch shard x2" in line["config"]["parallelism"] and "broadcast" in line["config"]["parallelism"]
     assert line["value"] > 0 and len(line["windows_ms"]) == 2
+    # both ranks report the same PCI bus id, and the broadcast says why RCCL was not entered
+    ids = line["config"]["device_bus_ids"]
+    assert len(ids) == 2 and ids[0] == ids[1] and ids[0] and line["config"]["distinct_devices"] == 1
+    assert "share device " + ids[0] in line["config"]["parallelism"], line["config"]["parallelism"]
+    assert line["config"]["rccl_nranks"] is None
