@@ -308,6 +308,7 @@ def load_backend(frontend):
         opt.shl_mi355x_params_kernel_name.argtypes = [C.c_void_p]
         opt.shl_mi355x_session_is_device_resident.argtypes = [C.POINTER(Session)]
         opt.shl_mi355x_session_fused_pairs.argtypes = [C.POINTER(Session)]
+        opt.shl_mi355x_session_folded_activations.argtypes = [C.POINTER(Session)]
         opt.shl_mi355x_session_stream.argtypes = [C.POINTER(Session)]
         opt.shl_mi355x_session_stream.restype = C.c_void_p
         opt.shl_mi355x_session_set_stream.argtypes = [C.POINTER(Session), C.c_void_p]

@@ -330,6 +330,28 @@ int shl_mi355x_conv2d_relu6_init(CSINN_CONV_ARGS)
     return conv_init_common(input, output, kernel, bias, params, SHL_MI355X_ACT_RELU6);
 }
 
+/* Graph-level rewrite (session.c:plan_fusion): a convolution whose ONLY consumer is a relu / relu6 layer takes the
+ * activation into its own epilogue and writes the activation layer's output tensor.  Exact when the two layers are
+ * what the fused op ids compute -- shl_ref_conv2d_relu_quant runs the convolution and then relu on the QUANTISED
+ * output with the same record (source/reference/convolution_relu.c:34-45) -- i.e. when the convolution's and the
+ * activation's output records are the same numbers (binary16: both scales 1).  `output` is the ACTIVATION's output
+ * tensor.  Replaces the plan under `params` on success; on failure the old plan stays. */
+int shl_mi355x_conv2d_fold_activation(struct csinn_tensor *input, struct csinn_tensor *conv_output,
+                                      struct csinn_tensor *output, struct csinn_tensor *kernel, struct csinn_tensor *bias,
+                                      struct csinn_conv2d_params *params, int relu6)
+{
+    if (shl_mi355x_registry_get(params) == NULL) return CSINN_FALSE; /* grouped / never initialised */
+    if (conv_output->qinfo == NULL || output->qinfo == NULL || conv_output->quant_channel > 1 || output->quant_channel > 1)
+        return CSINN_FALSE;
+    if (conv_output->dtype != output->dtype || conv_output->dim_count != output->dim_count) return CSINN_FALSE;
+    for (int i = 0; i < output->dim_count; i++)
+        if (conv_output->dim[i] != output->dim[i]) return CSINN_FALSE;
+    if (conv_output->qinfo->scale != output->qinfo->scale) return CSINN_FALSE;
+    if (output->dtype == CSINN_DTYPE_INT8 && conv_output->qinfo->zero_point != output->qinfo->zero_point) return CSINN_FALSE;
+    if (output->dtype == CSINN_DTYPE_FLOAT16 && !scale_is_one(output->qinfo->scale)) return CSINN_FALSE;
+    return conv_init_common(input, output, kernel, bias, params, relu6 ? SHL_MI355X_ACT_RELU6 : SHL_MI355X_ACT_RELU);
+}
+
 static int run_plan(struct csinn_params_base *base, struct csinn_tensor *input, struct csinn_tensor *output,
                     int batch, const char *what)
 {

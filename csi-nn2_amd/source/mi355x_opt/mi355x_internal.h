@@ -33,6 +33,10 @@ int shl_mi355x_stage_out_end(struct shl_mi355x_ctx *ctx, struct csinn_tensor *t,
 
 float shl_mi355x_half_to_float(uint16_t h);
 
+/* session.c: fold the relu / relu6 layer that is the convolution's only consumer into its plan (convolution.c) */
+int shl_mi355x_conv2d_fold_activation(struct csinn_tensor *input, struct csinn_tensor *conv_output,
+                                      struct csinn_tensor *output, struct csinn_tensor *kernel, struct csinn_tensor *bias,
+                                      struct csinn_conv2d_params *params, int relu6);
 int shl_mi355x_conv2d_relu_init(CSINN_CONV_ARGS);
 int shl_mi355x_conv2d_relu6_init(CSINN_CONV_ARGS);
 

@@ -42,8 +42,9 @@ struct dev_session {
     void *prev_stream; /* the session's stream before it became device resident */
     int prev_own;      /* ... and whether that was a stream of its own (else: the process default) */
     void *graph_exec;
-    unsigned char *fused; /* per layer: 1 = runs fused with the next layer (depthwise + pointwise) */
-    int nfused;
+    unsigned char *fused;  /* per layer: 1 / 2 = runs fused with the next convolution (dw + pw / pw + dw) */
+    unsigned char *folded; /* per layer: 1 = the relu / relu6 layer behind it runs in this convolution's epilogue */
+    int nfused, nfolded;
     struct dev_session *next;
 };
 
@@ -71,6 +72,7 @@ static void free_session(struct dev_session *ds)
     }
     free(ds->t);
     free(ds->fused);
+    free(ds->folded);
     free(ds);
 }
 
@@ -156,35 +158,74 @@ static int is_conv_op(int type)
     return type == CSINN_OP_CONV2D || type == CSINN_OP_CONV2D_RELU || type == CSINN_OP_CONV2D_RELU6;
 }
 
-/* Graph-level fusion of a layer with its ONLY consumer when the pair of device plans qualifies; the
- * intermediate tensor then never exists in HBM:
+static int consumers_of(struct shl_ref_graph *g, struct shl_node *tensor)
+{
+    int consumers = 0;
+    for (int k = 0; k < g->layer_index; k++)
+        for (int j = 0; j < g->layer[k]->in_num; j++)
+            if (g->layer[k]->in[j] == tensor) consumers++;
+    for (int k = 0; k < g->output_num; k++)
+        if (g->output[k] == tensor) consumers++;
+    return consumers;
+}
+
+/* the tensor node layer i finally writes: its own output, or the output of the activation layer folded into it */
+static struct shl_node *final_out(struct dev_session *ds, struct shl_ref_graph *g, int i)
+{
+    return ds->folded[i] ? g->layer[i + 1]->out[0] : g->layer[i]->out[0];
+}
+
+/* Graph-level rewrites; the intermediate tensors then never exist in HBM:
+ *   conv / depthwise (no activation) -> relu | relu6, the convolution's only consumer, same output record
+ *        the activation moves into the convolution's epilogue (folded[i] = 1, the relu layer is skipped): what a
+ *        converter emits for a RISC-V target -- example/c906_mobilenetv1_f16.c is 28 csinn_conv2d + 27 csinn_relu --
+ *        runs as 28 launches, not 55
  *   1x1 convolution -> depthwise 3x3   one launch of csrc/pwdw_fused.hip   (fused[i] = 2)
  *   depthwise 3x3 -> 1x1 convolution   one launch of csrc/dwpw_fused.hip   (fused[i] = 1, opt-in) */
 static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
 {
     ds->fused = calloc((size_t)g->layer_index + 1, 1);
-    for (int i = 0; i + 1 < g->layer_index; i++) {
+    ds->folded = calloc((size_t)g->layer_index + 1, 1);
+    static const char *off = NULL;
+    off = getenv("SHL_MI355X_NO_FUSION");
+    for (int i = 0; !(off && off[0] == '1') && i + 1 < g->layer_index; i++) {
         struct shl_node *a = g->layer[i], *b = g->layer[i + 1];
-        if (b->in[0] != a->out[0]) continue;
+        const int plain = a->type == CSINN_OP_CONV2D || a->type == CSINN_OP_DEPTHWISE_CONV2D;
+        if (!plain || (b->type != CSINN_OP_RELU && b->type != CSINN_OP_RELU6)) continue;
+        if (b->in[0] != a->out[0] || consumers_of(g, a->out[0]) != 1) continue;
+        if (shl_mi355x_conv2d_fold_activation(a->in[0]->data, a->out[0]->data, b->out[0]->data, a->in[1]->data,
+                                              a->in[2]->data, a->data, b->type == CSINN_OP_RELU6) == CSINN_TRUE) {
+            ds->folded[i] = 1;
+            ds->nfolded++;
+            i++; /* the activation layer is taken */
+        }
+    }
+    for (int i = 0; i + 1 < g->layer_index; i++) {
+        const int j = i + 1 + ds->folded[i]; /* the next layer that still runs */
+        if (j >= g->layer_index) break;
+        struct shl_node *a = g->layer[i], *b = g->layer[j];
+        struct shl_node *mid = final_out(ds, g, i);
+        if (b->in[0] != mid) {
+            i = j - 1;
+            continue;
+        }
         const int pw_dw = is_conv_op(a->type) && is_dw_op(b->type);
-        if (!pw_dw && !(is_dw_op(a->type) && is_conv_op(b->type))) continue;
-        int consumers = 0;
-        for (int k = 0; k < g->layer_index; k++)
-            for (int j = 0; j < g->layer[k]->in_num; j++)
-                if (g->layer[k]->in[j] == a->out[0]) consumers++;
-        for (int k = 0; k < g->output_num; k++)
-            if (g->output[k] == a->out[0]) consumers++;
-        if (consumers != 1) continue;
+        if ((!pw_dw && !(is_dw_op(a->type) && is_conv_op(b->type))) || consumers_of(g, mid) != 1) {
+            i = j - 1;
+            continue;
+        }
         shl_mi355x_conv_plan *pa = shl_mi355x_registry_get(a->data), *pb = shl_mi355x_registry_get(b->data);
         struct csinn_tensor *in = a->in[0]->data;
         if (pa && pb && pw_dw && shl_mi355x_pwdw_fusable(pa, pb, in->dim[0])) {
             ds->fused[i] = 2;
             ds->nfused++;
-            i++; /* the depthwise layer is taken */
+            i = j + ds->folded[j]; /* the depthwise layer (and its activation) is taken */
         } else if (pa && pb && !pw_dw && shl_mi355x_dwpw_fusable(pa, pb, in->dim[0])) {
             ds->fused[i] = 1;
             ds->nfused++;
-            i++; /* the pointwise layer is taken */
+            i = j + ds->folded[j]; /* the pointwise layer (and its activation) is taken */
+        } else {
+            i = j - 1;
         }
     }
 }
@@ -195,19 +236,23 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
     for (int i = 0; i < g->layer_index; i++) {
         struct shl_node *n = g->layer[i];
         struct csinn_params_base *params = n->data;
+        const int first = i;
+        const int folded = ds->folded && ds->folded[i];
         struct dev_tensor *in = lookup(ds, n->in[0]);
-        struct dev_tensor *out = lookup(ds, n->out[0]);
+        struct dev_tensor *out = lookup(ds, folded ? g->layer[i + 1]->out[0] : n->out[0]);
         int (*f)() = params->cb->exec;
         int rc;
         if (ds->fused && ds->fused[i]) {
-            struct shl_node *nx = g->layer[i + 1];
-            struct dev_tensor *out2 = lookup(ds, nx->out[0]);
+            const int j = i + 1 + folded;
+            struct shl_node *nx = g->layer[j];
+            const int folded2 = ds->folded && ds->folded[j];
+            struct dev_tensor *out2 = lookup(ds, folded2 ? g->layer[j + 1]->out[0] : nx->out[0]);
             int (*fwd)(const shl_mi355x_conv_plan *, const shl_mi355x_conv_plan *, const void *, void *, int32_t,
                        void *) = ds->fused[i] == 2 ? shl_mi355x_pwdw_forward : shl_mi355x_dwpw_forward;
             int st = fwd(shl_mi355x_registry_get(n->data), shl_mi355x_registry_get(nx->data), in->dev, out2->dev,
                          in->shadow.dim[0], ds->stream);
             rc = st == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
-            i++;
+            i = j + folded2;
         } else if (op_arity(n->type) == 1) {
             rc = f(&in->shadow, &out->shadow, params);
         } else if (op_arity(n->type) == 2) { /* add: the second operand is an activation or a constant */
@@ -215,9 +260,10 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
             rc = f(&in->shadow, in1 ? (void *)&in1->shadow : n->in[1]->data, &out->shadow, params);
         } else {
             rc = f(&in->shadow, &out->shadow, n->in[1]->data, n->in[2]->data, params);
+            i += folded; /* the activation layer ran inside the convolution */
         }
         if (rc != CSINN_TRUE) {
-            shl_debug_error("mi355x: layer %d (%s) failed while building the device graph\n", i,
+            shl_debug_error("mi355x: layer %d (%s) failed while building the device graph\n", first,
                             n->name ? n->name : "?");
             return CSINN_FALSE;
         }
@@ -434,6 +480,13 @@ int shl_mi355x_session_fused_pairs(struct csinn_session *sess)
 {
     struct dev_session *ds = find_session(sess);
     return ds ? ds->nfused : 0;
+}
+
+/* number of relu / relu6 layers of `sess` that run inside the epilogue of the convolution in front of them */
+int shl_mi355x_session_folded_activations(struct csinn_session *sess)
+{
+    struct dev_session *ds = find_session(sess);
+    return ds ? ds->nfolded : 0;
 }
 
 /* 1 when `sess` executes as one device-resident hipGraph, 0 when host-staged */

@@ -37,6 +37,7 @@ int csinn_tensor_byte_size(struct csinn_tensor *tensor);
 int shl_target_init_mi355x_slot(int api);
 int shl_mi355x_session_is_device_resident(struct csinn_session *sess);
 int shl_mi355x_session_fused_pairs(struct csinn_session *sess);
+int shl_mi355x_session_folded_activations(struct csinn_session *sess);
 __attribute__((constructor)) static void occupy_slot(void) { shl_target_init_mi355x_slot(SLOT_C906); }
 #else
 struct csinn_callback *shl_cb_map_ref(int op, int dtype);
@@ -89,8 +90,9 @@ void __wrap_csinn_session_deinit(struct csinn_session *sess)
         fclose(f);
     }
 #ifdef HARNESS_MI355X
-    printf("example_harness: output %d bytes, device_resident=%d fused_pairs=%d\n", bytes,
-           shl_mi355x_session_is_device_resident(sess), shl_mi355x_session_fused_pairs(sess));
+    printf("example_harness: output %d bytes, device_resident=%d fused_pairs=%d folded_activations=%d\n", bytes,
+           shl_mi355x_session_is_device_resident(sess), shl_mi355x_session_fused_pairs(sess),
+           shl_mi355x_session_folded_activations(sess));
 #else
     printf("example_harness: output %d bytes, reference kernels\n", bytes);
 #endif

@@ -161,7 +161,9 @@ class MiniNet:
     (the structure of example/c906_mobilenetv1_f16.c in miniature).  fp16 keeps relu as separate
     layers like the example; int8 uses the fused CONV2D_RELU ops."""
 
-    def __init__(self, dtype="int8", layout="NHWC", seed=5, hw=16, c0=16, c1=32, classes=40):
+    def __init__(self, dtype="int8", layout="NHWC", seed=5, hw=16, c0=16, c1=32, classes=40, split_relu=False):
+        """split_relu: int8 too keeps relu as separate layers (same record as the convolution in front, which is what
+        makes conv -> relu equal to the fused op ids: the session folds them, session.c:plan_fusion)"""
         self.dtype, self.layout, self.hw, self.c0, self.c1, self.classes = dtype, layout, hw, c0, c1, classes
         rng = np.random.default_rng(seed)
         int8 = dtype == "int8"
@@ -184,16 +186,16 @@ class MiniNet:
             return case["ho"], _q(case["out_scale"], case["out_zp"])
 
         h, q = hw, q_in
-        fused = 1 if int8 else 0
+        fused = 1 if int8 and not split_relu else 0
         h, q = conv("stem", c0, c1, 3, 2, 1, False, fused, h, q, -3)
-        if not int8:
-            self.layers.append(("relu", "stem_relu", None))
+        if not fused:
+            self.layers.append(("relu", "stem_relu", q if int8 else None))
         h, q = conv("dw", c1, c1, 3, 1, 1, True, fused, h, q, -3)
-        if not int8:
-            self.layers.append(("relu", "dw_relu", None))
+        if not fused:
+            self.layers.append(("relu", "dw_relu", q if int8 else None))
         h, q = conv("pw", c1, 2 * c1, 1, 1, 0, False, fused, h, q, -2)
-        if not int8:
-            self.layers.append(("relu", "pw_relu", None))
+        if not fused:
+            self.layers.append(("relu", "pw_relu", q if int8 else None))
         q_pool = _q(2.0 ** -3, -7) if int8 else q
         self.layers.append(("pool", "gap", (q, q_pool, h)))
         _, q_fc = conv("classifier", 2 * c1, classes, 1, 1, 0, False, 0, 1, q_pool, -1)
@@ -219,7 +221,7 @@ class MiniNet:
                 cur = cases.oracle_run(case, "ref" if self.dtype == "int8" else "f16")
             elif kind == "relu":
                 cur = siso_oracle(dict(kind="relu", x=cur, dtype=self.dtype, layout=self.layout, axis=1,
-                                       in_q=(1.0, 0), out_q=(1.0, 0)))
+                                       in_q=info or (1.0, 0), out_q=info or (1.0, 0)))
             elif kind == "pool":
                 q_in, q_out, _ = info
                 cur = siso_oracle(dict(kind="pool", x=cur, dtype=self.dtype, layout=self.layout, axis=1,
@@ -270,7 +272,7 @@ class MiniNet:
                 cur, cur_shape = t_out, case["out_shape"]
             else:
                 if kind == "relu":
-                    shape, q = cur_shape, (1.0, 0)
+                    shape, q = cur_shape, info or (1.0, 0)
                 elif kind == "pool":
                     shape = (cur_shape[0], 1, 1, cur_shape[3]) if nhwc else (cur_shape[0], cur_shape[1], 1, 1)
                     q = info[1]

@@ -116,6 +116,8 @@ def test_the_unmodified_example_runs_on_the_backend(tmp_path):
     # default: the whole model device resident, one hipGraph per csinn_session_run
     got2, text2 = run_example("mi355x", tmp_path)
     assert "device_resident=2" in text2, text2[-2000:]
+    # the example's 27 csinn_relu layers run inside the epilogues of the convolutions in front of them
+    assert "folded_activations=27" in text2, text2[-2000:]
     close_enough(got2, want, "device-resident session vs committed reference output")
     if os.path.exists(os.path.join(BIN, "c906_mobilenetv1_f16_ref")):
         live, _ = run_example("ref", tmp_path)

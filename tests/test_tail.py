@@ -5,6 +5,7 @@ CPU (-m "not gpu"): the oracle restatements against golden vectors produced by t
 reference (tests/golden/make_tail_golden.py).  GPU: the backend against the oracle and the goldens,
 through the C-ABI and through csinn_* in layer and graph mode.
 """
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -115,16 +116,48 @@ def gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,layout", [("int8", "NHWC"), ("int8", "NCHW"), ("f16", "NCHW")])
+def test_separate_relu_layers_are_folded_into_the_convolutions(gpu, dtype, layout):
+    """What a converter emits for the reference's RISC-V targets is conv -> relu as two layers
+    (example/c906_mobilenetv1_f16.c: 28 csinn_conv2d + 27 csinn_relu).  The device session folds a relu that is the
+    convolution's only consumer and shares its output record into the convolution's epilogue (session.c:plan_fusion) --
+    exactly the fused op ids' arithmetic (convolution_relu.c:34-45).  Three of the model's four convolutions have one;
+    results equal the oracle's layer-by-layer replay bit for bit (binary16: same words)."""
+    fe, hip, opt = gpu
+    opt.shl_mi355x_session_folded_activations.argtypes = [C.POINTER(pkg.Session)]
+    net = tail.MiniNet(dtype, layout, seed=9, split_relu=True)
+    sess = net.build(fe, pkg.API_MI355X)
+    assert opt.shl_mi355x_session_is_device_resident(sess) == 2
+    assert opt.shl_mi355x_session_folded_activations(sess) == 3
+    for k in range(3):
+        x = net.input(k)
+        got, want = net.run(fe, x), net.oracle(x)
+        if dtype == "int8":
+            assert_same(got, want, dtype, "split-relu mininet input %d" % k)
+        else:
+            assert_same(got, want, dtype, "split-relu mininet input %d" % k)
+    net.close(fe)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES, ids=IDS)
 def test_tail_op_matches_oracle_and_golden(gpu, case):
     fe, hip, _ = gpu
     _, want = golden(case["name"], case["dtype"])
     oracle = tail.siso_oracle(case)
-    lsb = 1 if case["kind"] == "softmax" else 0  # double exp on the device vs glibc: at most one quantum
+    # softmax: bit-exact too.  The device's double exp is not glibc's (both are accurate to < 1 ulp of a DOUBLE), but a
+    # last-bit difference of e[j] only reaches the result if the double quotient e[j] / acc lies within 2^-29 relative of
+    # a float rounding boundary AND that float decides an int8 quantum (fp16: a half-up boundary): ~1e-9 per output.
+    # Measured: 0 of 2 295 579 int8 and 0 of 368 228 fp16 outputs differ (tools/dev/softmax_probe.py, r04 notes); the
+    # goldens below come from the genuine library (tests/golden/make_tail_golden.py).
     for device in (None, cases.HipDevice(hip)):
         got = tail.siso_run(fe, pkg.API_MI355X, case, device=device)
-        assert_same(got, oracle, case["dtype"], case["name"] + " vs oracle", lsb)
-        assert_same(got, want, case["dtype"], case["name"] + " vs reference golden", lsb)
+        if case["kind"] == "softmax" and case["dtype"] != "int8":
+            assert np.array_equal(got.view(np.uint16), oracle.view(np.uint16)), case["name"] + " vs oracle: fp16 words differ"
+            assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), case["name"] + " vs reference golden"
+            continue
+        assert_same(got, oracle, case["dtype"], case["name"] + " vs oracle")
+        assert_same(got, want, case["dtype"], case["name"] + " vs reference golden")
 
 
 @pytest.mark.gpu
@@ -139,7 +172,7 @@ def test_mini_model_runs_device_resident_as_one_hipgraph(gpu, dtype, layout):
     for k in (0, 1, 0):  # replay with changing inputs
         x, want = golden("mininet_%s_%s_%d" % (dtype, layout, k), dtype)
         got = net.run(fe, x)
-        assert_same(got, want, dtype, "mininet %s input %d" % (dtype, k), lsb=1)
+        assert_same(got, want, dtype, "mininet %s input %d" % (dtype, k))
     plans_before = opt.shl_mi355x_live_plans(None)
     assert plans_before >= 4
     net.close(fe)
@@ -170,7 +203,7 @@ def test_session_runs_in_place_on_caller_hbm_buffers_and_back_to_host(gpu):
     dev = cases.HipDevice(hip)
     x0, want0 = golden("mininet_int8_NHWC_0", "int8")
     x1, want1 = golden("mininet_int8_NHWC_1", "int8")
-    assert_same(net.run(fe, x0), want0, "int8", "host run", lsb=1)
+    assert_same(net.run(fe, x0), want0, "int8", "host run")
     d_in, d_out = dev.alloc(x1.nbytes), dev.alloc(want1.nbytes)
     dev.upload(d_in, x1)
     keep = pkg.Keep()
@@ -181,7 +214,7 @@ def test_session_runs_in_place_on_caller_hbm_buffers_and_back_to_host(gpu):
     for _ in range(3):
         assert fe.csinn_session_run(sess) == pkg.CSINN_TRUE       # enqueues only
     pkg.check(hip.shl_mi355x_stream_sync(opt.shl_mi355x_session_stream(sess)), hip, "sync")
-    assert_same(dev.download(d_out, want1.shape, np.int8), want1, "int8", "in-place device run", lsb=1)
+    assert_same(dev.download(d_out, want1.shape, np.int8), want1, "int8", "in-place device run")
     # back to host tensors: output via a caller-owned host buffer (CPU_ACC), input from host
     host_out = np.zeros(want0.shape, np.int8)
     t_hout = pkg.make_tensor(fe, keep, want0.shape, pkg.DTYPE_INT8, pkg.LAYOUT_NHWC, data=host_out, sess=sess)
@@ -189,7 +222,7 @@ def test_session_runs_in_place_on_caller_hbm_buffers_and_back_to_host(gpu):
     t_hin = pkg.make_tensor(fe, keep, x0.shape, pkg.DTYPE_INT8, pkg.LAYOUT_NHWC, data=x0, sess=sess)
     fe.csinn_update_input(0, t_hin, sess)
     assert fe.csinn_session_run(sess) == pkg.CSINN_TRUE
-    assert_same(host_out, want0, "int8", "host run after device runs", lsb=1)
+    assert_same(host_out, want0, "int8", "host run after device runs")
     dev.free(d_in)
     dev.free(d_out)
     net.close(fe)

@@ -156,7 +156,9 @@ def test_mobilenetv1_session_equals_the_oracle_model(gpu, dtype, layout):
         want = oracle_whole_model(ms, x, dtype, layout).reshape(-1)
         if dtype == "int8":
             n, worst = cases.mismatch_report(got, want)
-            assert worst <= 1 and n <= 2, "softmax output: %d mismatches (max %d)" % (n, worst)   # device exp vs glibc
+            # bit-exact, softmax included (why a last-bit difference between the device's and glibc's double exp does
+            # not reach an int8 output: tests/test_tail.py; 0 of 2.3 M outputs in tools/dev/softmax_probe.py)
+            assert n == 0, "softmax output: %d mismatches (max %d)" % (n, worst)
             assert int(np.argmax(got)) == int(np.argmax(want))
         else:
             g, w = got.astype(np.float64), want.astype(np.float64)
