@@ -328,7 +328,7 @@ def measure_config(tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, cha
     of its dominant kernel.  With a process group: every rank runs its shard, rank 0's weights are broadcast first."""
     torch, fe, hip, opt, wl, par, stream, detail = (env[k] for k in ("torch", "fe", "hip", "opt", "wl", "par", "stream", "detail"))
     hbm = CHbm(hip)
-    fuse = chained_x and dtype_x == "int8" and layout_x == "NHWC" and batch_x <= 8
+    fuse = chained_x and batch_x <= 8 and ((dtype_x == "int8" and layout_x == "NHWC") or (dtype_x == "f16" and layout_x == "NCHW"))
     rc = wl.LayerChain(fe, hip, opt, layers_x, batch_x, hbm.alloc, hbm.upload, dtype=dtype_x, layout=layout_x, seed=seed,
                        chained=chained_x, fuse=fuse)
     how = None
@@ -441,7 +441,7 @@ def main():
             raise SystemExit("rank %d owns no image of a total batch of %d" % (rank, args.total_batch))
     # the graph-level rewrite csinn_session_setup applies on this backend (session.c plan_fusion):
     # pointwise + the depthwise layer that consumes it = one launch
-    fuse = chained and args.dtype == "int8" and layout == "NHWC" and not args.no_fuse
+    fuse = chained and not args.no_fuse and ((args.dtype == "int8" and layout == "NHWC") or (args.dtype == "f16" and layout == "NCHW"))
     # rank 0 owns the real weights; other ranks build their plans from a different seed and must
     # receive rank 0's packed blocks over RCCL before they can agree with it
     chain = wl.LayerChain(fe, hip, opt, layers, batch, hbm.alloc, hbm.upload, dtype=args.dtype, layout=layout,

@@ -293,7 +293,29 @@ __device__ __forceinline__ float f16_bits_to_float(uint16_t h)
     return (float)v;
 }
 
+// float32_to_float16_base (source/nn2/utils.c:576-620): drop 12 mantissa bits, scale by 2^-112, + 0x1000, >> 13,
+// saturating beyond +-65519.  For a NORMAL binary16 result (2^-14 <= |x| < 65520) the scaling is exact and the recipe is
+// "round to nearest, ties away from zero" -- bit 12 alone decides, everything below it was dropped.  The hardware's
+// v_cvt_f16_f32 rounds ties to even, so the two differ exactly when the low 13 bits are 0x1000 and bit 13 is clear: one
+// conversion + a compare instead of ~25 integer operations.  Checked against the literal recipe for every one of the
+// 503 308 288 float32 values in that range (both signs); zero, subnormal results, saturation, infinities and NaN take
+// the literal code below.
+__device__ __forceinline__ uint16_t float_to_f16_bits_literal(float x);
 __device__ __forceinline__ uint16_t float_to_f16_bits_ref(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    const uint32_t a = u & 0x7FFFFFFFu;
+    if (a - 0x38800000u < 0x477FF000u - 0x38800000u) {
+        const _Float16 h = (_Float16)x;  // round to nearest even
+        uint16_t hb;
+        __builtin_memcpy(&hb, &h, 2);
+        return (uint16_t)(hb + ((u & 0x3FFFu) == 0x1000u ? 1u : 0u));
+    }
+    if (a == 0u) return (uint16_t)(u >> 16);
+    return float_to_f16_bits_literal(x);
+}
+
+__device__ __forceinline__ uint16_t float_to_f16_bits_literal(float x)
 {
     if (x > 65519.0f) return 0x7BFFu;
     if (x < -65519.0f) return 0xFBFFu;
@@ -370,6 +392,7 @@ inline void lds_opt_in(LdsOptIn &st, const void *kernel, int bytes = 160 * 1024)
 // ---- launchers implemented by the kernel translation units ----------------------------------
 int launch_conv_direct(const ConvArgs &a, int dtype, int layout, int dw_nhwc_weights,
                        hipStream_t s);
+int launch_conv_group_direct(const ConvArgs &a, int dtype, int layout, hipStream_t s);  // SHL_MI355X_ALGO_GROUP
 int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 int launch_dwconv(const ConvArgs &a, int dtype, int layout, hipStream_t s);
 bool igemm_supports(const shl_mi355x_conv_desc &d);
@@ -404,6 +427,8 @@ int launch_dwpw_fused(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);
 bool pwdw_fusable(const ConvArgs &pw, const ConvArgs &dw, int pw_is_igemm, int dw_dot4_packed);
 int launch_pwdw_fused(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
 // stem 3x3 (3 -> 32) + the depthwise 3x3 consuming it in one launch (stemdw_fused.hip)
+bool pwdw_f16_nchw_fusable(const ConvArgs &pw, const ConvArgs &dw);  // binary16 NCHW form (pwdw_f16_nchw.hip)
+int launch_pwdw_f16_nchw(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
 bool stemdw_fusable(const ConvArgs &stem, const ConvArgs &dw);
 int launch_stemdw_fused(const ConvArgs &stem, const ConvArgs &dw, hipStream_t s);
 // the same pair in bandwidth form for large batches (pwdw_stream.hip)

@@ -149,6 +149,95 @@ __global__ __launch_bounds__(256) void conv_stem_f16_nchw_kernel(ConvArgs a)
     }
 }
 
+// Grouped convolution, one launch per layer (SHL_MI355X_ALGO_GROUP; shl_ref_group_conv2d_quant,
+// source/reference/convolution.c:271-354, 476-508).  One output per thread as above.
+//   NCHW: the usual grouped convolution -- output channel oc of group g = oc / (Cout/G) reads input channels
+//         g C/G .. of ITS image (the reference's slices (j G + i) are exactly those planes);
+//   NHWC: the reference treats input and output as G consecutive tensors [N,H,W,C/G] -> [N,Ho,Wo,Cout/G]; block
+//         b = flat image index / N selects the filters b Cout/G ..  -- restated literally.
+// Weights: OIHW [Cout][C/G][Kh][Kw] / OHWI [Cout][Kh][Kw][C/G]; tables are indexed by the GLOBAL output channel.
+template <typename T, bool kNHWC>
+__global__ __launch_bounds__(256) void conv_group_direct_kernel(ConvArgs a)
+{
+    const int cpg = a.C / a.group, opg = a.Co / a.group;
+    const int64_t total = (int64_t)a.M * a.Co;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int oy, ox, ocg;      // output position, GLOBAL output channel
+        int64_t in_base;      // element offset of (its image / block, input channel 0 of its group)
+        int64_t pix_stride;   // elements between consecutive input pixels
+        int64_t ch_stride;    // elements between consecutive input channels of one pixel
+        if (kNHWC) {
+            const int ocl = (int)(idx % opg);
+            int64_t p = idx / opg;
+            ox = (int)(p % a.Wo);
+            p /= a.Wo;
+            oy = (int)(p % a.Ho);
+            const int64_t img = p / a.Ho;      // over G * N consecutive [H, W, C/G] images
+            const int blk = (int)(img / a.N);  // the group
+            ocg = blk * opg + ocl;
+            in_base = img * a.H * a.W * cpg;
+            pix_stride = cpg;
+            ch_stride = 1;
+        } else {
+            ox = (int)(idx % a.Wo);
+            int64_t p = idx / a.Wo;
+            oy = (int)(p % a.Ho);
+            p /= a.Ho;
+            ocg = (int)(p % a.Co);
+            const int64_t n = p / a.Co;
+            in_base = (n * a.C + (int64_t)(ocg / opg) * cpg) * a.H * a.W;
+            pix_stride = 1;
+            ch_stride = (int64_t)a.H * a.W;
+        }
+        const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
+        const T *in = static_cast<const T *>(a.in) + in_base;
+        const T *w = static_cast<const T *>(a.w);
+        int32_t acc_i = 0;
+        float acc_f = 0.0f;
+        for (int ky = 0; ky < a.Kh; ++ky) {
+            const int y = y0 + ky * a.dh;
+            if (y < 0 || y >= a.H) continue;
+            for (int kx = 0; kx < a.Kw; ++kx) {
+                const int x = x0 + kx * a.dw;
+                if (x < 0 || x >= a.W) continue;
+                for (int ic = 0; ic < cpg; ++ic) {
+                    const int64_t ii = ((int64_t)y * a.W + x) * pix_stride + ic * ch_stride;
+                    const int64_t wi = kNHWC ? (((int64_t)ocg * a.Kh + ky) * a.Kw + kx) * cpg + ic
+                                             : (((int64_t)ocg * cpg + ic) * a.Kh + ky) * a.Kw + kx;
+                    if constexpr (sizeof(T) == 1) {
+                        acc_i += ((int32_t)in[ii] - a.in_zp) * (int32_t)w[wi];
+                    } else {
+                        acc_f = __fadd_rn(acc_f, __fmul_rn((float)in[ii], (float)w[wi]));
+                    }
+                }
+            }
+        }
+        if constexpr (sizeof(T) == 1)
+            static_cast<int8_t *>(a.out)[idx] = (int8_t)requant_i8_fast<true>(acc_i, a.mult[ocg], a.bias[ocg], a);
+        else
+            static_cast<uint16_t *>(a.out)[idx] = finish_f16(acc_f, a.bias[ocg], a);
+    }
+}
+
+int launch_conv_group_direct(const ConvArgs &a, int dtype, int layout, hipStream_t s)
+{
+    const int64_t total = (int64_t)a.M * a.Co;
+    if (total == 0) return SHL_MI355X_OK;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 blocks per CU
+    const dim3 grid((unsigned)blocks);
+    const bool nhwc = layout == SHL_MI355X_NHWC;
+    if (dtype == SHL_MI355X_I8) {
+        if (nhwc) hipLaunchKernelGGL((conv_group_direct_kernel<int8_t, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_group_direct_kernel<int8_t, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (nhwc) hipLaunchKernelGGL((conv_group_direct_kernel<_Float16, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_group_direct_kernel<_Float16, false>), grid, dim3(256), 0, s, a);
+    }
+    SHL_HIP(hipGetLastError());
+    return SHL_MI355X_OK;
+}
+
 template <typename T>
 static void launch_t(const ConvArgs &a, int layout, int dw_last, dim3 grid, hipStream_t s)
 {

@@ -232,8 +232,16 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         set_error("conv_plan_create: STEM kernel needs int8 NHWC 3x3 with 3 input channels, Cout <= 64");
         return SHL_MI355X_ENOTSUP;
     }
+    if (algo == SHL_MI355X_ALGO_GROUP && d.group < 2) {
+        set_error("conv_plan_create: ALGO_GROUP needs group > 1");
+        return SHL_MI355X_EINVAL;
+    }
+    if (algo != SHL_MI355X_ALGO_GROUP && d.group != 1 && !is_depthwise(d)) {
+        set_error("conv_plan_create: grouped convolution (group=%d) runs as SHL_MI355X_ALGO_GROUP only", d.group);
+        return SHL_MI355X_ENOTSUP;
+    }
     if (algo != SHL_MI355X_ALGO_IGEMM && algo != SHL_MI355X_ALGO_DW && algo != SHL_MI355X_ALGO_DIRECT &&
-        algo != SHL_MI355X_ALGO_STEM) {
+        algo != SHL_MI355X_ALGO_STEM && algo != SHL_MI355X_ALGO_GROUP) {
         set_error("conv_plan_create: unknown algorithm %d", algo);
         return SHL_MI355X_EINVAL;
     }
@@ -310,6 +318,8 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
                                  d.stride_h, d.stride_w))
                 p->kernel_name = "dwconv_mfma_i8";
         }
+    } else if (algo == SHL_MI355X_ALGO_GROUP) {
+        p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_group_direct_i8" : "conv_group_direct_f16";
     } else {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_direct_i8" : "conv_direct_f16";
     }
@@ -721,6 +731,8 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
             return launch_conv_stem(a, s);
         case SHL_MI355X_ALGO_DW_CHANNEL:
             return launch_dwconv_channel(a, s);
+        case SHL_MI355X_ALGO_GROUP:
+            return launch_conv_group_direct(a, d.dtype, d.layout, s);
         default:
             return launch_conv_direct(a, d.dtype, d.layout,
                                       is_depthwise(d) && d.layout == SHL_MI355X_NHWC, s);
@@ -781,6 +793,8 @@ static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv
                            const ConvArgs &b)
 {
     const int pw_igemm = pw->algo == SHL_MI355X_ALGO_IGEMM, dw_dot4 = dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12;
+    if (pw->desc.dtype == SHL_MI355X_F16)  // binary16 NCHW (pwdw_f16_nchw.hip)
+        return pw_igemm && dw->algo == SHL_MI355X_ALGO_DW && pwdw_f16_nchw_fusable(a, b) ? 4 : 0;
     if (pw->algo == SHL_MI355X_ALGO_STEM) return dw_dot4 && stemdw_fusable(a, b) ? 3 : 0;  // stem + depthwise
     static const char *st = getenv("SHL_MI355X_PWDW_STREAM");
     if (st && st[0] == '1' && pw_igemm && dw_dot4 && pwdw_stream_eligible(a, b)) return 2;
@@ -794,8 +808,11 @@ int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     static const char *off = getenv("SHL_MI355X_NO_FUSION");
     static const char *sel = getenv("SHL_MI355X_PWDW");  // "0": keep pointwise and depthwise launches apart
     if ((off && off[0] == '1') || (sel && sel[0] == '0')) return 0;
-    if (dw->desc.dtype != SHL_MI355X_I8 || pw->desc.dtype != SHL_MI355X_I8) return 0;
-    if (dw->desc.layout != SHL_MI355X_NHWC || pw->desc.layout != SHL_MI355X_NHWC) return 0;
+    if (dw->desc.dtype != pw->desc.dtype || dw->desc.layout != pw->desc.layout) return 0;
+    // int8 NHWC (pwdw_fused.hip, stemdw_fused.hip, pwdw_stream.hip) or binary16 NCHW (pwdw_f16_nchw.hip)
+    const bool i8_nhwc = pw->desc.dtype == SHL_MI355X_I8 && pw->desc.layout == SHL_MI355X_NHWC;
+    const bool f16_nchw = pw->desc.dtype == SHL_MI355X_F16 && pw->desc.layout == SHL_MI355X_NCHW;
+    if (!i8_nhwc && !f16_nchw) return 0;
     ConvArgs a, b;
     static char dummy[16];
     if (fill_args(pw, dummy, dummy, batch, a) != SHL_MI355X_OK || fill_args(dw, dummy, dummy, batch, b) != SHL_MI355X_OK)
@@ -820,6 +837,7 @@ int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     if (rc != SHL_MI355X_OK) return rc;
     if (b.M == 0) return SHL_MI355X_OK;
     switch (pwdw_kernel_for(pw, dw, a, b)) {
+        case 4: return launch_pwdw_f16_nchw(a, b, (hipStream_t)stream);
         case 3: return launch_stemdw_fused(a, b, (hipStream_t)stream);
         case 2: return launch_pwdw_stream(a, b, (hipStream_t)stream);
         default: return launch_pwdw_fused(a, b, (hipStream_t)stream);

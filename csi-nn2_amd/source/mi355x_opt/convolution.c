@@ -24,6 +24,8 @@
 #include "mi355x_internal.h"
 
 int shl_mi355x_group_conv2d_exec(CSINN_CONV_ARGS);
+static int run_plan(struct csinn_params_base *base, struct csinn_tensor *input, struct csinn_tensor *output, int batch,
+                    const char *what);
 
 /* ------------------------------------------------------------------------ descriptor */
 
@@ -86,7 +88,7 @@ static int build_tables(const struct shl_mi355x_conv_desc *d, struct csinn_tenso
                 const int8_t *w = kernel->data;
                 const float sp = s_in * (float)input->qinfo->zero_point;
                 const int64_t inner = kelems / co;
-                const int dw = d->group > 1;
+                const int dw = d->group > 1 && d->algo != SHL_MI355X_ALGO_GROUP;
                 for (int oc = 0; oc < co; oc++) {
                     const float sk = kernel->qinfo[kernel->quant_channel > 1 ? oc : 0].scale;
                     float t = dw ? bias_f[oc] : 0.0f;
@@ -152,7 +154,8 @@ static int create_plan(struct csinn_session *sess, struct shl_mi355x_conv_desc *
 
     float *mult = shl_mem_alloc((int64_t)d->out_c * sizeof(float));
     float *bias_f = shl_mem_alloc((int64_t)d->out_c * sizeof(float));
-    const int dw_last = d->group > 1 && d->layout == SHL_MI355X_NHWC;
+    /* depthwise 1HWO weights; a grouped convolution (ALGO_GROUP) keeps OHWI rows and the conv2d form of the fold */
+    const int dw_last = d->group > 1 && d->algo != SHL_MI355X_ALGO_GROUP && d->layout == SHL_MI355X_NHWC;
     int rc = build_tables(d, input, kernel, bias, fuse_zp2bias, dw_last, mult, bias_f);
     if (rc == CSINN_TRUE) {
         int st = shl_mi355x_conv_plan_create(d, kernel->data, mult, bias_f,
@@ -176,55 +179,23 @@ static int create_plan(struct csinn_session *sess, struct shl_mi355x_conv_desc *
  *        and writes block i * (N*Ho*Wo*Cout/g) -- i.e. the buffers are treated as G consecutive
  *        NHWC tensors, NOT as channel-interleaved groups.  Restated literally: identical results
  *        are the contract.
- * One device plan per group (kept together under the layer's params block); slices start at arbitrary
- * byte offsets, so the plans use the alignment-free direct kernel. */
+ * One device plan and one launch per layer (SHL_MI355X_ALGO_GROUP): the slice arithmetic of both layouts lives
+ * in the kernel's index computation (csrc/conv_direct.hip:conv_group_direct_kernel), so ResNeXt's 32 groups at batch
+ * 128 are one launch instead of 4 096, and any group count is accepted. */
 
 static int group_conv_init(struct shl_mi355x_conv_desc *d, struct csinn_tensor *input,
                            struct csinn_tensor *output, struct csinn_tensor *kernel,
                            struct csinn_tensor *bias, struct csinn_conv2d_params *params)
 {
-    const int G = d->group;
-    if (G > 64) {
-        shl_debug_error("mi355x: grouped convolution with %d groups is not supported\n", G);
-        return CSINN_FALSE;
-    }
+    /* ONE plan and ONE launch per layer, any number of groups: SHL_MI355X_ALGO_GROUP carries the slice semantics of
+     * both layouts in the kernel's index arithmetic (csrc/conv_direct.hip:conv_group_direct_kernel).  Kernel, bias and
+     * their per-channel records are the layer's own tensors: group i's filters are rows i Cout/G .. of them. */
     struct shl_mi355x_conv_desc sub = *d;
-    sub.group = 1;
-    sub.in_c = d->in_c / G;
-    sub.out_c = d->out_c / G;
-    sub.algo = SHL_MI355X_ALGO_DIRECT;
-    if (d->layout == SHL_MI355X_NCHW) sub.batch = 1;
-    const int es = d->dtype == SHL_MI355X_I8 ? 1 : 2;
-    const int64_t ksz = (int64_t)sub.out_c * sub.in_c * d->kernel_h * d->kernel_w; /* elements per group */
-    const int has_bias = bias != NULL && bias->dim_count != 0 && bias->data != NULL;
-    shl_mi355x_conv_plan **plans = calloc((size_t)G, sizeof(*plans));
-    if (plans == NULL) return CSINN_FALSE;
-    for (int i = 0; i < G; i++) {
-        struct csinn_tensor k = *kernel, b;
-        k.data = (char *)kernel->data + i * ksz * es;
-        k.dim[0] = sub.out_c;
-        if (kernel->quant_channel > 1) {
-            k.qinfo = kernel->qinfo + i * sub.out_c;
-            k.quant_channel = sub.out_c;
-        }
-        if (has_bias) {
-            b = *bias;
-            b.data = (char *)bias->data + (int64_t)i * sub.out_c * (d->dtype == SHL_MI355X_I8 ? 4 : 2);
-            b.dim[0] = sub.out_c;
-            if (bias->quant_channel > 1) {
-                b.qinfo = bias->qinfo + i * sub.out_c;
-                b.quant_channel = sub.out_c;
-            }
-        }
-        int rc = create_plan(params->base.sess, &sub, input, output, &k, has_bias ? &b : bias,
-                             params->conv_extra.fuse_zp2bias, &plans[i]);
-        if (rc != CSINN_TRUE) {
-            for (int j = 0; j < i; j++) shl_mi355x_conv_plan_destroy(plans[j]);
-            free(plans);
-            return rc;
-        }
-    }
-    shl_mi355x_registry_put_group(params, plans, G);
+    sub.algo = SHL_MI355X_ALGO_GROUP;
+    shl_mi355x_conv_plan *plan = NULL;
+    int rc = create_plan(params->base.sess, &sub, input, output, kernel, bias, params->conv_extra.fuse_zp2bias, &plan);
+    if (rc != CSINN_TRUE) return rc;
+    shl_mi355x_registry_put(params, plan);
     params->base.cb->exec = shl_mi355x_group_conv2d_exec;
     return CSINN_TRUE;
 }
@@ -233,35 +204,7 @@ int shl_mi355x_group_conv2d_exec(CSINN_CONV_ARGS)
 {
     (void)kernel;
     (void)bias;
-    const int G = params->group;
-    const int nhwc = params->base.layout == CSINN_LAYOUT_NHWC;
-    const int es = input->dtype == CSINN_DTYPE_INT8 ? 1 : 2;
-    const int N = input->dim[0];
-    const int64_t in_all = csinn_tensor_size(input), out_all = csinn_tensor_size(output);
-    const int64_t isz = nhwc ? in_all / G : in_all / ((int64_t)N * G);  /* elements per slice */
-    const int64_t osz = nhwc ? out_all / G : out_all / ((int64_t)N * G);
-    struct shl_mi355x_ctx *ctx = shl_mi355x_ctx_of(params->base.sess);
-    void *stream = shl_mi355x_ctx_stream(ctx);
-    const char *in_dev = shl_mi355x_stage_in(ctx, input, 0);
-    char *out_dev = shl_mi355x_stage_out_begin(ctx, output, 1);
-    if (in_dev == NULL || out_dev == NULL) return CSINN_FALSE;
-    const int images = nhwc ? 1 : N;
-    for (int j = 0; j < images; j++)
-        for (int i = 0; i < G; i++) {
-            shl_mi355x_conv_plan *plan = shl_mi355x_registry_get_group(params, i);
-            if (plan == NULL) {
-                shl_debug_error("mi355x: group_conv2d called without a successful init\n");
-                return CSINN_FALSE;
-            }
-            const int64_t slice = (int64_t)j * G + i;
-            int st = shl_mi355x_conv_forward(plan, in_dev + slice * isz * es, out_dev + slice * osz * es,
-                                             nhwc ? N : 1, stream);
-            if (st != SHL_MI355X_OK) {
-                shl_debug_error("mi355x: group_conv2d launch failed (%d): %s\n", st, shl_mi355x_last_error());
-                return CSINN_FALSE;
-            }
-        }
-    return shl_mi355x_stage_out_end(ctx, output, out_dev);
+    return run_plan(&params->base, input, output, input->dim[0], "group_conv2d");
 }
 
 /* ------------------------------------------------------------------------ conv2d family */

@@ -217,6 +217,8 @@ class LayerChain:
         idx = self.units[u]
         if len(idx) == 1:
             return self.entries[idx[0]]["kernel_name"]
+        if self.dtype != "int8":
+            return "pwdw_f16_nchw"
         return "stemdw_fused_i8" if self.entries[idx[0]]["kernel_name"].startswith("conv_stem") else "pwdw_fused_i8"
 
     def unit_name(self, u):

@@ -63,7 +63,15 @@ enum shl_mi355x_algo {
     SHL_MI355X_ALGO_DW = 3,     /* bandwidth-tuned depthwise kernel */
     SHL_MI355X_ALGO_GEMV = 4,   /* fullyconnected, small batch (reserved) */
     SHL_MI355X_ALGO_STEM = 5,   /* 3x3 conv with 3 input channels (image stem), v_dot4 */
-    SHL_MI355X_ALGO_DW_CHANNEL = 6 /* CSINN_OP_DEPTHWISE_CONV2D_CHANNEL: int64 accumulation (plan_create_dw_channel) */
+    SHL_MI355X_ALGO_DW_CHANNEL = 6, /* CSINN_OP_DEPTHWISE_CONV2D_CHANNEL: int64 accumulation (plan_create_dw_channel) */
+    /* grouped convolution (1 < group, not depthwise) with shl_ref_group_conv2d_quant's slice semantics
+     * (source/reference/convolution.c:271-354, 476-508), ONE launch per layer:
+     *   NCHW  image j, group i reads input planes (j G + i) C/G .. and writes output planes (j G + i) Cout/G .. (the
+     *         usual grouped convolution);
+     *   NHWC  the buffers are G consecutive tensors [N, H, W, C/G] -> [N, Ho, Wo, Cout/G] (NOT channel-interleaved
+     *         groups): restated literally, identical results are the contract.
+     * Never chosen by ALGO_AUTO: a descriptor with group > 1 alone cannot say which of the two the caller means */
+    SHL_MI355X_ALGO_GROUP = 7
 };
 
 /* ------------------------------------------------------------------------------------

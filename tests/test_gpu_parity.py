@@ -431,9 +431,14 @@ def test_unsupported_requests_are_refused(gpu):
     with pytest.raises(pkg.MI355XError):
         cases.csinn_run(fe, pkg.API_MI355X, case)
     before = opt.shl_mi355x_live_plans(None)
-    many = cases.make_case(6, c=130, co=130, groups=65)  # more groups than the backend keeps plans for
-    with pytest.raises(pkg.MI355XError):
-        cases.csinn_run(fe, pkg.API_MI355X, many)
+    # (65 groups used to be refused -- one plan per group, at most 64; SHL_MI355X_ALGO_GROUP is one plan per layer)
+    many = cases.make_case(6, c=130, co=130, groups=65)
+    keep = []
+    got = cases.csinn_run(fe, pkg.API_MI355X, many, keep_params=keep)
+    n, worst = cases.mismatch_report(got, cases.oracle_group_run(many, "exact"))
+    assert n == 0, "65 groups: %d mismatches (max %d)" % (n, worst)
+    assert opt.shl_mi355x_live_plans(None) == before + 1
+    opt.shl_mi355x_release_params(keep[0][0])
     assert opt.shl_mi355x_live_plans(None) == before
 
 

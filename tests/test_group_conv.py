@@ -69,7 +69,24 @@ def test_group_conv_on_the_backend(gpu, i):
         got = cases.csinn_run(fe, pkg.API_MI355X, case, device=device, keep_params=keep)
         check(got, want, case, name + " vs reference golden")
         check(got, cases.oracle_group_run(case, "exact" if case["dtype"] == "int8" else "f16"), case, name + " vs oracle")
-    assert opt.shl_mi355x_live_plans(None) == before + 2 * case["group"]
+    assert opt.shl_mi355x_live_plans(None) == before + 2          # ONE plan (= one launch) per layer, whatever the group count
     for params, _ in keep:
         assert opt.shl_mi355x_release_params(params) == pkg.CSINN_TRUE
     assert opt.shl_mi355x_live_plans(None) == before
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["NCHW", "NHWC"])
+def test_resnext_style_group_conv_is_one_launch(gpu, layout):
+    """32 groups (more than the old limit of 64 would be fine too: 96 below) at a batch > 1 used
+    to be N x G launches of per-group plans; SHL_MI355X_ALGO_GROUP is one plan and one launch."""
+    fe, hip, opt = gpu
+    for seed, groups, c in ((901, 32, 128), (902, 96, 192)):
+        case = cases.make_case(seed, layout=layout, n=3, h=9, w=7, c=c, co=c, k=(3, 3), stride=(1, 1), pad=(1, 1, 1, 1), groups=groups, act=1)
+        keep = []
+        before = opt.shl_mi355x_live_plans(None)
+        got = cases.csinn_run(fe, pkg.API_MI355X, case, device=cases.HipDevice(hip), keep_params=keep)
+        assert opt.shl_mi355x_live_plans(None) == before + 1
+        assert opt.shl_mi355x_params_kernel_name(keep[0][0]).decode() == "conv_group_direct_i8"
+        check(got, cases.oracle_group_run(case, "exact"), case, "%d groups %s vs oracle" % (groups, layout))
+        opt.shl_mi355x_release_params(keep[0][0])

@@ -122,6 +122,44 @@ def test_mobilenetv1_fp16_nchw_chain_layer_by_layer(gpu):
     chain.release()
 
 
+@pytest.mark.gpu
+def test_mobilenetv1_fp16_nchw_chain_with_fused_pairs(gpu):
+    """configs[3] as bench.py and csinn_session_setup run it: a pointwise layer and the depthwise layer consuming it are
+    ONE launch (csrc/pwdw_f16_nchw.hip), 28 layers in 16 launches.  A pair's output is checked against the oracle's replay
+    of BOTH layers from the pair's own GPU input (the intermediate never reaches HBM): 1e-3 relative, the bar every
+    binary16 layer has, with the tensor-range term of compare_f16_tol covering values that cancel."""
+    chain, outs = run_chain(gpu, "f16", "NCHW", True)
+    pairs = [u for u in chain.units if len(u) == 2]
+    assert len(pairs) == 12 and len(chain.units) == 16, chain.units
+    feeds = chain_inputs(chain)
+    for u in chain.units:
+        first = u[0]
+        x = feeds[first] if first in feeds else outs[first - 1]
+        mid = None
+        for i in u:
+            e = chain.entries[i]
+            mid, x = x, cases.oracle_run(layer_case(e["layer"], e["ops"], "f16", "NCHW", x), "f16")
+        assert np.isfinite(x.astype(np.float32)).all()
+        names = " + ".join(wl.layer_name(chain.entries[i]["layer"]) for i in u)
+        what = "fp16 NCHW unit %s (%s)" % (names, chain.unit_kernel_name(chain.units.index(u)))
+        if len(u) == 1:
+            golden_util.compare_f16_tol(outs[u[-1]], x, what)
+            continue
+        # a pair: the intermediate tensor is stored in binary16 by both sides and may differ by one rounding (2^-10
+        # relative) wherever the two fp32 summation orders straddle a rounding boundary; through the depthwise layer
+        # that is at most 2^-10 * sum |mid| |w| per output -- the condition-aware form of the same 1e-3 bar (outputs
+        # that cancel to ~0 have no meaningful RELATIVE error).  sum |mid| |w| comes from the oracle itself.
+        e = chain.entries[u[1]]
+        cond_case = layer_case(dict(e["layer"], act=0), dict(e["ops"], kernel=np.abs(e["ops"]["kernel"]),
+                                                           bias=np.zeros_like(e["ops"]["bias"])), "f16", "NCHW", np.abs(mid))
+        cond = cases.oracle_run(cond_case, "f16").astype(np.float64)
+        g, w = outs[u[-1]].astype(np.float64), x.astype(np.float64)
+        bad = np.abs(g - w) > 1e-3 * np.abs(w) + 1e-3 * cond + 1e-6
+        assert not bad.any(), "%s: %d of %d values beyond 1e-3 (|out| + sum |mid||w|), worst excess %.3e" % (
+            what, int(bad.sum()), g.size, float((np.abs(g - w) - 1e-3 * np.abs(w) - 1e-3 * cond).max()))
+    chain.release()
+
+
 def oracle_whole_model(ms, x, dtype, layout, seed=99):
     """Replays workloads.ModelSession (27 convs, global_avgpool2d, classifier, softmax) through the oracle."""
     int8 = dtype == "int8"
