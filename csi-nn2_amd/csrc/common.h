@@ -359,6 +359,68 @@ __device__ __forceinline__ uint16_t finish_f16(float acc, float bias_f, const Co
     return float_to_f16_bits_ref(f);
 }
 
+// Four outputs at once, packed: the reference's rounding is "add 0x1000 to the float's bits, drop 13 bits" once the 12
+// low bits are gone and the result is a NORMAL binary16 -- i.e. a round-toward-zero conversion of bits + 0x1000, and
+// v_cvt_pkrtz_f16_f32 converts TWO values per instruction (finite values beyond the binary16 range come out as +-65504,
+// which is the reference's saturation; zero stays zero).  What the shortcut does not cover -- a non-zero result below
+// 2^-14 (the reference rounds those on the subnormal grid after a scaled multiply), NaN, an output scale != 1 -- is
+// detected with a running min / max over the four magnitudes and sent through a branch-free form of the literal code
+// (inlined, no function call: a kernel with a call frame is given scratch memory, which costs ~15 us per LAUNCH on this
+// part -- measured on pwdw_f16_nchw.hip).  shl_mi355x_debug_f16_round_check walks all 2^32 float patterns.
+// the literal recipe without branches (selects only): the fall-back of the packed form, compact enough to be inlined
+// where it is needed
+__device__ __forceinline__ uint32_t float_to_f16_bits_literal_nb(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    const uint32_t sign = u & 0x80000000u;
+    const uint32_t a = u ^ sign;
+    const float s = __fmul_rn(__uint_as_float(a & 0xFFFFF000u), __uint_as_float(15u << 23));  // * 2^-112
+    uint32_t v = __float_as_uint(s) + 0x1000u;
+    v = v > (31u << 23) ? (31u << 23) : v;
+    uint32_t h = v >> 13;
+    h = a > 0x7F800000u ? 0x7FFFu : h;                     // NaN
+    h = a > 0x477FEF00u && a <= 0x7F800000u ? 0x7BFFu : h;  // |x| > 65519 (infinity included): saturate
+    return h | (sign >> 16);
+}
+
+// pack2_f16_ref(x0, x1, lo, hi): the two roundings + the magnitudes' running min of (|x| - 1) and max of |x| (as bits)
+__device__ __forceinline__ uint32_t pack2_f16_ref(float x0, float x1, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const uint32_t a0 = u0 & 0x7FFFFFFFu, a1 = u1 & 0x7FFFFFFFu;
+    lo = min(lo, min(a0 - 1u, a1 - 1u));
+    hi = max(hi, max(a0, a1));
+    // finite values beyond +-65520 must not carry into the exponent field's end: clamp first (the conversion saturates)
+    const float c0 = __builtin_amdgcn_fmed3f(x0, -65520.0f, 65520.0f), c1 = __builtin_amdgcn_fmed3f(x1, -65520.0f, 65520.0f);
+    const auto pk = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(__float_as_uint(c0) + 0x1000u), __uint_as_float(__float_as_uint(c1) + 0x1000u));
+    uint32_t r;
+    __builtin_memcpy(&r, &pk, 4);
+    return r;
+}
+
+// true when every magnitude seen was zero or a normal binary16 result, and none a NaN
+__device__ __forceinline__ bool pack_f16_ref_ok(uint32_t lo, uint32_t hi) { return lo >= 0x387FFFFFu && hi <= 0x7F800000u; }
+
+// bias, relu / relu6, rounding of four values; output scale 1 only (callers check ConvArgs::scale_out)
+__device__ __forceinline__ uint2 finish4_f16_unit_scale(float v0, float v1, float v2, float v3, float bias_f, int act)
+{
+    float x[4] = {__fadd_rn(v0, bias_f), __fadd_rn(v1, bias_f), __fadd_rn(v2, bias_f), __fadd_rn(v3, bias_f)};
+    if (act != SHL_MI355X_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] = x[e] > 0.0f ? x[e] : 0.0f;  // (NaN -> 0, as the reference's comparison)
+            if (act == SHL_MI355X_ACT_RELU6) x[e] = fminf(x[e], 6.0f);
+        }
+    }
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    uint32_t p0 = pack2_f16_ref(x[0], x[1], lo, hi), p1 = pack2_f16_ref(x[2], x[3], lo, hi);
+    if (!pack_f16_ref_ok(lo, hi)) {
+        p0 = float_to_f16_bits_literal_nb(x[0]) | float_to_f16_bits_literal_nb(x[1]) << 16;
+        p1 = float_to_f16_bits_literal_nb(x[2]) | float_to_f16_bits_literal_nb(x[3]) << 16;
+    }
+    return make_uint2(p0, p1);
+}
+
 // ---- host-side error plumbing (shim_runtime.hip) --------------------------------------------
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);

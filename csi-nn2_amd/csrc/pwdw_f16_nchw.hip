@@ -48,7 +48,9 @@ struct PwDwF16Args {
     int32_t nsub;     // K sub-steps in all = C / 16
     int32_t ppitch;   // patch row pitch in elements (mt * 32)
     int32_t patch_off;  // byte offset of the patch in LDS: behind max(staging, partial sums)
-    uint32_t wo_magic;  // ceil(2^20 / Wo): i / Wo == (i * wo_magic) >> 20 for i < 4096
+    int32_t sl;         // depthwise phase: outputs per strip
+    int32_t spr;        // strips per output row = ceil(Wo / sl)
+    uint32_t spr_magic; // ceil(2^20 / spr): s / spr == (s * spr_magic) >> 20 for s < 4096
 };
 
 // one transposing read: 8 bytes = 4 consecutive rows (channels) of this lane's pixel
@@ -57,6 +59,28 @@ __device__ __forceinline__ uint2 lds_read_tr16(uint32_t addr)
     uint2 r;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
     return r;
+}
+
+// A 16-byte piece that would run over the end of the tensor (the last rows of the last channel of the last image):
+// the 16 bytes that END at the tensor's end are loaded instead and shifted down by the difference -- the elements that
+// exist land where they belong, the rest is zero.  Branch-free and call-free on purpose: a device function call gives
+// the kernel a stack, and a kernel with scratch memory costs ~15 us per launch.
+__device__ __forceinline__ uint4 load_piece_at_end(const char *base, int64_t off, int64_t tensor_bytes)
+{
+    typedef uint4 __attribute__((aligned(1))) uint4_u;
+    const int64_t off2 = tensor_bytes - 16;
+    const int sh = (int)(off - off2);  // 2 .. 14 bytes (elements are 2 bytes)
+    const uint4 v = *reinterpret_cast<const uint4_u *>(base + off2);
+    const int q = sh >> 2;
+    const bool half = (sh & 2) != 0;
+    // dword k of the result = bytes 4 k + sh .. of v (zeros beyond it)
+    const uint32_t d0 = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+    const uint32_t d1 = q == 0 ? v.y : q == 1 ? v.z : q == 2 ? v.w : 0u;
+    const uint32_t d2 = q == 0 ? v.z : q == 1 ? v.w : 0u;
+    const uint32_t d3 = q == 0 ? v.w : 0u;
+    const uint32_t d4 = 0u;
+    return half ? make_uint4(d0 >> 16 | d1 << 16, d1 >> 16 | d2 << 16, d2 >> 16 | d3 << 16, d3 >> 16 | d4 << 16)
+                : make_uint4(d0, d1, d2, d3);
 }
 
 // MTW: tiles per wave (upper bound), NSW: K sub-steps per wave (upper bound)
@@ -134,11 +158,8 @@ __global__ __launch_bounds__(512) void pwdw_f16_nchw_kernel(PwDwF16Args f)
             if (off + 16 <= tensor_bytes) {
                 typedef uint4 __attribute__((aligned(1))) uint4_u;  // runs start at any even byte address
                 st[u] = *reinterpret_cast<const uint4_u *>(src);
-            } else {  // the last pieces of the tensor: element by element
-                uint32_t w4[4] = {0, 0, 0, 0};
-                for (int e = 0; e < 8 && off + 2 * e + 2 <= tensor_bytes; ++e)
-                    w4[e >> 1] |= (uint32_t) * reinterpret_cast<const uint16_t *>(src + 2 * e) << (16 * (e & 1));
-                st[u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            } else {
+                st[u] = load_piece_at_end(static_cast<const char *>(q.in), off, tensor_bytes);
             }
         }
 #pragma unroll
@@ -178,7 +199,13 @@ __global__ __launch_bounds__(512) void pwdw_f16_nchw_kernel(PwDwF16Args f)
         }
     }
 
-    if (q.debug & 256) return;  // ablation (tools/pair_bench.py): stop after staging + MFMA
+    if (q.debug & 256) {  // ablation (tools/pair_bench.py): stop after staging + MFMA (the loads must have landed)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::"v"(acc[0][0]) : "memory");
+        return;
+    }
+    if (q.debug & 2048) {  // ablation: the same point, but without having waited for anything
+        return;
+    }
     uint16_t *patch = reinterpret_cast<uint16_t *>(smem + f.patch_off);  // [32 channels][ppitch]
     uint16_t *pch = patch + frow * f.ppitch;  // this lane's channel row
     if (f.ks == 1) {
@@ -190,11 +217,8 @@ __global__ __launch_bounds__(512) void pwdw_f16_nchw_kernel(PwDwF16Args f)
             if (tile < f.mt) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    uint16_t h[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = finish_f16(acc[i][4 * g + e], p_bias, q);
                     *reinterpret_cast<uint2 *>(pch + tile * 32 + 8 * g + 4 * fhalf) =
-                        make_uint2((uint32_t)h[0] | (uint32_t)h[1] << 16, (uint32_t)h[2] | (uint32_t)h[3] << 16);
+                        finish4_f16_unit_scale(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3], p_bias, q.act);
                 }
             }
         }
@@ -227,39 +251,122 @@ __global__ __launch_bounds__(512) void pwdw_f16_nchw_kernel(PwDwF16Args f)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s4[e] = __fadd_rn(s4[e], __int_as_float(o[e]));
             }
-            uint16_t h[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = finish_f16(s4[e], p_bias, q);
-            *reinterpret_cast<uint2 *>(pch + tile * 32 + 8 * fgrp + 4 * fhalf) =
-                make_uint2((uint32_t)h[0] | (uint32_t)h[1] << 16, (uint32_t)h[2] | (uint32_t)h[3] << 16);
+            *reinterpret_cast<uint2 *>(pch + tile * 32 + 8 * fgrp + 4 * fhalf) = finish4_f16_unit_scale(s4[0], s4[1], s4[2], s4[3], p_bias, q.act);
         }
     }
     __syncthreads();
     if (q.debug & 1024) return;  // ablation: stop after the pointwise epilogue
 
-    // ---- depthwise 3x3 on the slice's 32 channels from the patch: 16 threads per channel walk the channel's output run
+    // ---- depthwise 3x3 on the slice's 32 channels from the patch.  16 threads per channel; a thread takes strips of
+    // `sl` consecutive outputs of one row and slides a 3 x 3 window of fp32 values along it (three -- stride 2: six --
+    // LDS reads per output instead of nine, row validity once per strip, column validity once per column).  The sum
+    // runs in the reference's ky -> kx order in fp32 and a tap outside the image leaves it untouched, as the reference
+    // skips it (a select per tap: adding a zero product would be the same bits only for finite weights).
     int bhv = d.Ho - oy0;
     bhv = bhv < f.bh ? bhv : f.bh;
-    const int per = bhv * d.Wo;  // outputs per channel: one contiguous run of the NCHW output (< 4096)
     uint16_t *out = static_cast<uint16_t *>(d.out) + ((int64_t)(n * d.C + dc) * d.Ho + oy0) * d.Wo;
     const uint16_t *prow = patch + dch * f.ppitch;
     float wf[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wf[t] = f16_bits_to_float(dw9[t]);
-    for (int i = tid & 15; i < per; i += 16) {
-        const int oyl = (int)(((uint32_t)i * f.wo_magic) >> 20);
-        const int ox = i - oyl * d.Wo;
-        const int y0 = (oy0 + oyl) * d.sh - d.pt, x0 = ox * d.sw - d.pl;
-        float accd = 0.0f;  // ky -> kx order, fp32, out-of-image taps skipped: as the reference
+    if (f.sl == 1) {  // narrow maps (Wo <= 16): one output per step, nothing to slide
+        const int per = bhv * d.Wo;
+        for (int i = tid & 15; i < per; i += 16) {
+            const int oyl = (int)(((uint32_t)i * f.spr_magic) >> 20);  // spr == Wo here
+            const int ox = i - oyl * d.Wo;
+            const int y0 = (oy0 + oyl) * d.sh - d.pt, x0 = ox * d.sw - d.pl;
+            uint16_t tv[9];
+            bool ok[9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int y = y0 + ky, x = x0 + kx;
-                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                    accd = __fadd_rn(accd, __fmul_rn(f16_bits_to_float(prow[(y - yc0) * W + x]), wf[ky * 3 + kx]));
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int y = y0 + ky, x = x0 + kx;
+                    const bool in_img = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                    ok[ky * 3 + kx] = in_img;
+                    tv[ky * 3 + kx] = prow[in_img ? (y - yc0) * W + x : 0];
+                }
+            float accd = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float s1 = __fadd_rn(accd, __fmul_rn(f16_bits_to_float(tv[t]), wf[t]));
+                accd = ok[t] ? s1 : accd;
             }
-        out[i] = finish_f16(accd, dbias, d);
+            float xo = __fadd_rn(accd, dbias);
+            if (d.act != SHL_MI355X_ACT_NONE) {
+                xo = xo > 0.0f ? xo : 0.0f;
+                if (d.act == SHL_MI355X_ACT_RELU6) xo = fminf(xo, 6.0f);
+            }
+            out[i] = float_to_f16_bits_ref(xo);
+        }
+        return;
+    }
+    const int nstrips = bhv * f.spr;
+    const int step = d.sw;
+    for (int st = tid & 15; st < nstrips; st += 16) {
+        const int oyl = (int)(((uint32_t)st * f.spr_magic) >> 20);
+        const int ox0 = (st - oyl * f.spr) * f.sl;
+        int nout = d.Wo - ox0;
+        nout = nout < f.sl ? nout : f.sl;
+        const int y0 = (oy0 + oyl) * d.sh - d.pt;
+        bool rok[3];
+        int roff[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int y = y0 + ky;
+            rok[ky] = (unsigned)y < (unsigned)H;
+            roff[ky] = rok[ky] ? (y - yc0) * W : 0;
+        }
+        float col[3][3];  // [window column][ky]
+        bool cok[3];
+        int x = ox0 * step - d.pl;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cok[k] = (unsigned)(x + k) < (unsigned)W;
+            const int xc = cok[k] ? x + k : 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) col[k][ky] = f16_bits_to_float(prow[roff[ky] + xc]);
+        }
+        uint16_t *o = out + oyl * d.Wo + ox0;
+#pragma unroll 1
+        for (int e = 0; e < nout; ++e) {
+            float accd = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float s1 = __fadd_rn(accd, __fmul_rn(col[k][ky], wf[ky * 3 + k]));
+                    accd = rok[ky] && cok[k] ? s1 : accd;
+                }
+            float xo = __fadd_rn(accd, dbias);
+            if (d.act != SHL_MI355X_ACT_NONE) {
+                xo = xo > 0.0f ? xo : 0.0f;
+                if (d.act == SHL_MI355X_ACT_RELU6) xo = fminf(xo, 6.0f);
+            }
+            o[e] = float_to_f16_bits_ref(xo);
+            // slide: stride 1 keeps two columns, stride 2 one
+            x += step;
+            const int keep = 3 - step;  // columns that stay
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool fresh = k >= keep;
+                const int src = k + step;  // window column this one comes from when it is kept
+                if (!fresh) {
+                    cok[k] = src == 1 ? cok[1] : cok[2];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) col[k][ky] = src == 1 ? col[1][ky] : col[2][ky];
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < 3; ++k) {
+                if (k >= keep) {
+                    cok[k] = (unsigned)(x + k) < (unsigned)W;
+                    const int xc = cok[k] ? x + k : 0;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) col[k][ky] = f16_bits_to_float(prow[roff[ky] + xc]);
+                }
+            }
+        }
     }
 }
 
@@ -271,6 +378,7 @@ static bool f16_shapes_pair(const ConvArgs &q, const ConvArgs &d)
     if (d.Kh != 3 || d.Kw != 3 || d.dh != 1 || d.dw != 1 || d.C != d.Co || d.C != q.Co) return false;
     if (d.H != q.Ho || d.W != q.Wo || d.N != q.N) return false;
     if (d.sh < 1 || d.sh > 2 || d.sw < 1 || d.sw > 2 || d.pt > 2 || d.pl > 2 || d.pt < 0 || d.pl < 0) return false;
+    if (q.scale_out || d.scale_out) return false;                       // the packed epilogue is the scale-1 one
     if (q.C > 512) return false;                                        // 8 parts x 4 sub-steps x 16 channels
     if ((int64_t)q.N * q.C * q.H * q.W >= ((int64_t)1 << 30)) return false;  // comfortable 64-bit-free index ranges
     if (q.N > 65535) return false;
@@ -327,7 +435,9 @@ static bool f16_choose(const ConvArgs &q, const ConvArgs &d, F16Choice &ch)
             found = true;
             PwDwF16Args &f = ch.f;
             f.bh = bh, f.rh = rh, f.mt = mt, f.ks = ks, f.ks_log2 = lg, f.mwn = mwn, f.nsw = nsw, f.nsub = nsub, f.ppitch = ppitch, f.patch_off = (int32_t)patch_off;
-            f.wo_magic = ((1u << 20) + d.Wo - 1) / d.Wo;
+            f.sl = (d.Wo + 15) / 16;
+            f.spr = (d.Wo + f.sl - 1) / f.sl;
+            f.spr_magic = ((1u << 20) + f.spr - 1) / f.spr;
             ch.mtw_t = mtw_t, ch.nsw_t = nsw_t, ch.lds = lds, ch.blocks = blocks;
         }
     }

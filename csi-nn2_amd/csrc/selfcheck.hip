@@ -38,7 +38,49 @@ __global__ __launch_bounds__(256) void div_check_kernel(const float *divisors, u
     }
 }
 
+// every float32 bit pattern: the packed rounding of common.h (pack2_f16_ref, where pack_f16_ref_ok admits it) and the
+// one-value fast path of float_to_f16_bits_ref against the literal restatement of float32_to_float16_base
+__global__ __launch_bounds__(256) void f16_round_check_kernel(unsigned long long *out)  // [0] mismatches [1] admitted [2] first bad pattern
+{
+    unsigned bad = 0, admitted = 0;
+    uint32_t first = 0;
+    const uint32_t stride = gridDim.x * 256;
+    uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    for (uint32_t it = 0; it < (0x80000000u / stride) * 2u; ++it, u += stride) {
+        const float x = __uint_as_float(u);
+        const uint16_t want = float_to_f16_bits_literal(x);
+        if (float_to_f16_bits_ref(x) != want && (u & 0x7FFFFFFFu) <= 0x7F800000u) ++bad, first = u;
+        if (float_to_f16_bits_literal_nb(x) != want) ++bad, first = u;  // the branch-free form of the recipe itself
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        const uint32_t pk = pack2_f16_ref(x, x, lo, hi);
+        if (pack_f16_ref_ok(lo, hi)) {
+            ++admitted;
+            if ((pk & 0xFFFFu) != want || (pk >> 16) != want) ++bad, first = u;
+        }
+    }
+    if (bad) {
+        atomicAdd(&out[0], (unsigned long long)bad);
+        out[2] = first;
+    }
+    atomicAdd(&out[1], (unsigned long long)admitted);
+}
+
 }  // namespace shl
+
+extern "C" int shl_mi355x_debug_f16_round_check(uint64_t *out3)
+{
+    using namespace shl;
+    if (!out3) return SHL_MI355X_EINVAL;
+    unsigned long long *d = nullptr;
+    SHL_HIP(hipMalloc((void **)&d, 24));
+    SHL_HIP(hipMemset(d, 0, 24));
+    hipLaunchKernelGGL(f16_round_check_kernel, dim3(4096), dim3(256), 0, nullptr, d);  // 2^20 threads x 4096 patterns
+    SHL_HIP(hipGetLastError());
+    SHL_HIP(hipDeviceSynchronize());
+    SHL_HIP(hipMemcpy(out3, d, 24, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return SHL_MI355X_OK;
+}
 
 extern "C" int shl_mi355x_debug_div_check(const float *divisors_host, int32_t n, uint64_t *mismatches,
                                           float *first_pair)

@@ -199,6 +199,11 @@ int shl_mi355x_debug_trace(uint64_t *host, int32_t count);
  * `x / scale`): for each of the `n` divisors every significand of the dividend is compared with the hardware's
  * correctly rounded division.  *mismatches = number of differing quotients, first_pair[0..1] = one (f, s). */
 int shl_mi355x_debug_div_check(const float *divisors_host, int32_t n, uint64_t *mismatches, float *first_pair);
+/* Tests only.  The binary16 epilogues round with one hardware conversion + a fix-up instead of the ~25 integer
+ * operations of float32_to_float16_base (source/nn2/utils.c:576-620): every one of the 2^32 float32 bit patterns is
+ * pushed through both the one-value and the packed two-value shortcut (csrc/common.h) and compared with the literal
+ * restatement.  out3[0] = mismatches, out3[1] = patterns the packed shortcut admits, out3[2] = one offending pattern. */
+int shl_mi355x_debug_f16_round_check(uint64_t *out3);
 
 /*
  * Plan for CSINN_OP_DEPTHWISE_CONV2D_CHANNEL{,_RELU,_RELU6} (int8, NCHW, kernel O1HW): the reference's one

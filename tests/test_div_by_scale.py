@@ -47,6 +47,20 @@ def test_fma_division_is_the_ieee_quotient_for_every_significand():
 
 
 @pytest.mark.gpu
+def test_f16_rounding_shortcuts_equal_the_reference_recipe_for_every_float():
+    """float32_to_float16_base (source/nn2/utils.c:576-620) -- drop 12 bits, scale by 2^-112, + 0x1000, >> 13, saturate
+    -- restated literally in common.h and replaced in the epilogues by (a) one round-to-nearest-even conversion + a tie
+    fix and (b) a packed round-toward-zero conversion of bits + 0x1000 for two values at once.  The device walks ALL
+    2^32 float32 patterns through both; the packed form declines (literal code instead) non-zero results below 2^-14
+    and NaN, which leaves 2.38 of the 4.29 billion patterns admitted."""
+    hip, _ = pkg.load_backend(pkg.load_frontend("standalone"))
+    out = (C.c_uint64 * 3)()
+    assert hip.shl_mi355x_debug_f16_round_check(C.addressof(out)) == 0, hip.shl_mi355x_last_error()
+    assert out[0] == 0, "%d roundings differ from the literal recipe, e.g. pattern 0x%08x" % (out[0], out[2])
+    assert out[1] > 2_300_000_000, out[1]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shift", [0, 45])
 def test_scales_outside_the_fma_range_leave_the_implicit_gemm_kernels(shift):
     """Multipliers beyond 2^60 / 2^32 are legal but exotic: the plan keeps the hardware's division (direct kernel,
