@@ -205,8 +205,6 @@ def load_hip():
         "shl_mi355x_conv_plan_const_block": (vp, [vp, C.POINTER(sz)]),
         "shl_mi355x_conv_plan_adopt_block": (C.c_int, [vp, vp]),
         "shl_mi355x_conv_forward": (C.c_int, [vp, vp, vp, i32, vp]),
-        "shl_mi355x_dwpw_fusable": (C.c_int, [vp, vp, i32]),
-        "shl_mi355x_dwpw_forward": (C.c_int, [vp, vp, vp, vp, i32, vp]),
         "shl_mi355x_pwdw_fusable": (C.c_int, [vp, vp, i32]),
         "shl_mi355x_pwdw_forward": (C.c_int, [vp, vp, vp, vp, i32, vp]),
         "shl_mi355x_relu_i8": (C.c_int, [vp, vp, sz, f32, i32, f32, i32, i32, vp]),

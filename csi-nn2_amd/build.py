@@ -40,7 +40,7 @@ def _glob(d, exts):
 
 
 # sources whose kernels read LDS fragments through asynchronous inline asm (lds_read128_async): no spills allowed
-NO_SPILL_SOURCES = ("conv_igemm.hip", "conv_igemm_pp.hip", "conv_igemm_pc.hip", "conv_igemm_pcx.hip", "conv_igemm_res.hip",
+NO_SPILL_SOURCES = ("conv_igemm.hip", "conv_igemm_pp.hip", "conv_igemm_pc.hip",
                     "conv_igemm_halo.hip")
 
 

@@ -482,9 +482,6 @@ bool conv1x1_nchw_eligible(const ConvArgs &a);
 int launch_conv1x1_nchw(const ConvArgs &a, int dtype, hipStream_t s);
 bool dwconv_nchw_supports(const shl_mi355x_conv_desc &d);
 int launch_dwconv_nchw(const ConvArgs &a, int dtype, hipStream_t s);
-// depthwise 3x3 + pointwise 1x1 in one launch (dwpw_fused.hip)
-bool dwpw_fusable(const ConvArgs &dw, const ConvArgs &pw, int dw_dot4_packed, int pw_is_igemm);
-int launch_dwpw_fused(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);
 // pointwise 1x1 + the depthwise 3x3 that consumes it in one launch (pwdw_fused.hip)
 bool pwdw_fusable(const ConvArgs &pw, const ConvArgs &dw, int pw_is_igemm, int dw_dot4_packed);
 int launch_pwdw_fused(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
@@ -493,9 +490,6 @@ bool pwdw_f16_nchw_fusable(const ConvArgs &pw, const ConvArgs &dw);  // binary16
 int launch_pwdw_f16_nchw(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
 bool stemdw_fusable(const ConvArgs &stem, const ConvArgs &dw);
 int launch_stemdw_fused(const ConvArgs &stem, const ConvArgs &dw, hipStream_t s);
-// the same pair in bandwidth form for large batches (pwdw_stream.hip)
-bool pwdw_stream_eligible(const ConvArgs &pw, const ConvArgs &dw);
-int launch_pwdw_stream(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
 // 3x3 stride-1 "same" int8 convolution with the im2col matrix implicit in ONE staged row patch (conv_igemm_patch.hip)
 bool patch_supports(const shl_mi355x_conv_desc &d);                 // shape class the kernel takes at all
 int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch); // pt_geom for a batch (plan time), 0: none

@@ -944,13 +944,20 @@ static void launch_kernel(dim3 grid, size_t lds, hipStream_t s, const ConvArgs &
 }
 
 // "tile" | "regs" | "wave" | "" (automatic) -- read once; for A/B measurements only
+// Per-call override of the family choice: the plan's measured pick (conv_plan.hip:tune_plan sets it around its timing
+// launches, shl_mi355x_conv_forward around every launch of a tuned plan).  The environment variable, when set, wins.
+static thread_local const char *g_plan_variant = nullptr;
+void igemm_set_plan_variant(const char *v) { g_plan_variant = v; }
+bool igemm_env_override() { return getenv("SHL_MI355X_IGEMM") != nullptr; }
+
 static const char *variant_override()
 {
     static const char *v = getenv("SHL_MI355X_IGEMM");
-    return v ? v : "";
+    if (v) return v;
+    return g_plan_variant ? g_plan_variant : "";
 }
 
-// which kernel family runs problem `a`: "wave" | "regs" | "tile" | "pp" | "pc" | "res"; *flavour = tile flavour of pp / pc
+// which kernel family runs problem `a`: "wave" | "regs" | "tile" | "pp" | "pc" | "patch" | "gemv"; *flavour = tile flavour of pp / pc
 const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
 {
     const char *ov = variant_override();
@@ -966,8 +973,6 @@ const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
         }
     }
     if (forced_patch) return "tile";
-    if ((!ov[0] || !strcmp(ov, "res")) && res_applies(a, esize)) return "res";
-    if (!strcmp(ov, "res")) return "tile";  // shapes the resident-weights kernel does not take
     // mid-size batches of 3x3 layers: too few block tiles for the tile kernels, yet the row-patch kernel has its ~100 tiles
     // (NHWC with K rows under 2 KiB: the producer / consumer tile below is ahead, 128 -> 128 @28 at batch 16 8.5 us against 10.3)
     if (!ov[0] && esize == 1 && a.w_patch && (a.in_nchw || a.kstride >= 2048) && !strcmp(igemm_variant(a.M, a.Co), "wave") &&
@@ -1002,13 +1007,13 @@ bool igemm_fuses_nchw_out(const ConvArgs &a, int esize)
     t.out_nchw = 1;
     const char *v = igemm_pick(t, esize, nullptr);
     // (not the row-patch kernel: its output layout is its input's, patch_setup refuses the mixed case)
-    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc") || !strcmp(v, "res");
+    return !strcmp(v, "tile") || !strcmp(v, "pp") || !strcmp(v, "pc");
 }
 
 const char *igemm_variant(int64_t M, int64_t Co, int64_t kbytes)
 {
     const char *ov = variant_override();
-    if (ov[0] && strcmp(ov, "pp") && strcmp(ov, "pc") && strcmp(ov, "res") && strcmp(ov, "patch")) return ov;
+    if (ov[0] && strcmp(ov, "pp") && strcmp(ov, "pc") && strcmp(ov, "patch")) return ov;
     if (ov[0]) return "tile";
     // LDS tile kernel once there is at least ~one 128x128 tile for every other CU; below that
     // (MobileNetV1 at batch 1: 1-98 tiles) latency dominates and the barrier-free wave kernel wins
@@ -1032,14 +1037,7 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     const char *v = igemm_pick(a, esize, &ppf);
     if (!strcmp(v, "patch")) return launch_conv_igemm_patch(a, s);
     if (!strcmp(v, "pp")) return launch_conv_igemm_pp(a, dtype, ppf, s);
-    if (!strcmp(v, "res")) return launch_conv_igemm_res(a, s);
-    if (!strcmp(v, "pc")) {
-        // opt-in: the shifted-row form moves 1.8x fewer bytes but is no faster (the loop is not paced by the byte
-        // count: profiles/r02_notes.md)
-        static const char *pcx_env = getenv("SHL_MI355X_PCX");
-        if (pcx_env && pcx_env[0] == '1' && pcx_applies(a)) return launch_conv_igemm_pcx(a, dtype, ppf, s);
-        return launch_conv_igemm_pc(a, dtype, ppf, s);
-    }
+    if (!strcmp(v, "pc")) return launch_conv_igemm_pc(a, dtype, ppf, s);
     const int epi = i8 ? epi_code(a) : 0;
     dim3 grid;
     size_t lds = 0;

@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "igemm_common.h"
@@ -35,6 +37,7 @@ struct shl_mi355x_conv_plan {
     int32_t kchunks;
     int32_t cchunks;
     const char *kernel_name;
+    const char *variant;  // implicit-GEMM family measured best at plan time (tune_plan), nullptr = the selection rules
 };
 
 namespace shl {
@@ -175,6 +178,99 @@ static void pack_igemm(const shl_mi355x_conv_desc &d, const char *src, char *dst
                     }
         }
     }
+}
+
+// ---- plan-time choice of the implicit-GEMM family by MEASUREMENT ---------------------------------
+// The selection rules of conv_igemm.hip:igemm_pick are threshold ladders tuned at batch 1 and 128 on two networks; in
+// between they were wrong by up to 2x (profiles/r03_notes.md).  So a plan whose layer the implicit-GEMM kernels take
+// times the rules' own pick against every family forced in turn -- wave, tile, ping-pong, producer / consumer, row-patch;
+// a family that does not apply resolves to "tile", i.e. costs one redundant timing -- on scratch tensors of the plan's
+// own shape and batch, and keeps a challenger only if it beats the rules by more than 3 %.  Results are cached per
+// (shape, layout, dtype, batch, epilogue flavour) for the life of the process (ResNet-50's 16 3x3 layers are 7 shapes).
+// All families are exact in int8 and within the same 1e-3 in binary16, so the choice never changes results.
+// SHL_MI355X_TUNE=0 turns it off; SHL_MI355X_IGEMM=<family> (A/B runs, the forced-variant tests) implies that.
+static bool tuning_enabled()
+{
+    const char *e = getenv("SHL_MI355X_TUNE");  // read per plan: a caller may switch tuning off for some layers
+    if (e && e[0] == '0') return false;
+    return !igemm_env_override();
+}
+
+static const char *family_kernel_name(const char *v, bool i8)
+{
+    if (!strcmp(v, "wave")) return i8 ? "conv_igemm_wave_i8_mfma32x32x32" : "conv_igemm_wave_f16_mfma32x32x16";
+    if (!strcmp(v, "tile")) return i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
+    if (!strcmp(v, "pp")) return i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
+    if (!strcmp(v, "pc")) return i8 ? "conv_igemm_pc_i8_mfma32x32x32" : "conv_igemm_pc_f16_mfma32x32x16";
+    return "conv_igemm_patch_i8_mfma32x32x32";
+}
+
+struct TuneResult {
+    const char *variant;  // nullptr: the rules
+};
+static std::mutex g_tune_lock;
+static std::map<std::vector<int32_t>, TuneResult> g_tune_cache;
+
+static void tune_plan(shl_mi355x_conv_plan *p, hipStream_t stream)
+{
+    const shl_mi355x_conv_desc &d = p->desc;
+    if (!tuning_enabled() || d.batch <= 0) return;
+    const bool i8 = d.dtype == SHL_MI355X_I8;
+    const std::vector<int32_t> key = {d.layout, d.dtype, d.act, d.batch, d.in_h, d.in_w, d.in_c, d.out_h, d.out_w, d.out_c,
+                                      d.kernel_h, d.kernel_w, d.stride_h, d.stride_w, d.pad_top, d.pad_left, d.dilation_h,
+                                      d.dilation_w, p->div_exact, p->div_fma, p->act_clamp, p->pt_geom};
+    {
+        std::lock_guard<std::mutex> g(g_tune_lock);
+        auto it = g_tune_cache.find(key);
+        if (it != g_tune_cache.end()) {
+            p->variant = it->second.variant;
+            if (p->variant) p->kernel_name = family_kernel_name(p->variant, i8);
+            return;
+        }
+    }
+    const size_t es = i8 ? 1 : 2;
+    const size_t in_b = (size_t)d.batch * d.in_c * d.in_h * d.in_w * es, out_b = (size_t)d.batch * d.out_c * d.out_h * d.out_w * es;
+    char *in = nullptr, *out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    TuneResult best = {nullptr};
+    if (hipMalloc((void **)&in, in_b ? in_b : 16) == hipSuccess && hipMalloc((void **)&out, out_b ? out_b : 16) == hipSuccess &&
+        hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
+        hipMemsetAsync(in, i8 ? (d.in_zp & 0xff) : 0, in_b, stream) == hipSuccess) {
+        static const char *const cands[] = {nullptr, "wave", "tile", "pp", "pc", "patch"};
+        float t_rules = 0.f, t_best = 0.f;
+        for (const char *c : cands) {
+            if (c && !strcmp(c, "patch") && !p->off_wpatch) continue;  // no row-patch weight copy: the family cannot run
+            if (c && !strcmp(c, "pc") && !p->pix_tab) continue;
+            p->variant = c;
+            float ms = -1.f;
+            bool ok = shl_mi355x_conv_forward(p, in, out, d.batch, stream) == SHL_MI355X_OK;  // warm (code, LDS opt-in)
+            if (ok) ok = hipEventRecord(e0, stream) == hipSuccess;
+            for (int r = 0; ok && r < 3; ++r) ok = shl_mi355x_conv_forward(p, in, out, d.batch, stream) == SHL_MI355X_OK;
+            if (ok) ok = hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                         hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(stream);
+                continue;
+            }
+            if (!c) t_rules = t_best = ms;
+            else if (ms < t_best * 0.97f && ms < t_rules * 0.97f) t_best = ms, best.variant = c;
+            static const char *dbg = getenv("SHL_MI355X_DEBUG_TUNE");
+            if (dbg) fprintf(stderr, "tune %dx%dx%d->%d k%d s%d b%d %s: %-6s %.2f us\n", d.in_h, d.in_w, d.in_c, d.out_c, d.kernel_h,
+                             d.stride_h, d.batch, d.layout == SHL_MI355X_NCHW ? "NCHW" : "NHWC", c ? c : "rules", ms * 1e3f / 3);
+        }
+        if (t_rules <= 0.f) best.variant = nullptr;  // the rules' own pick could not be timed: keep it
+    }
+    (void)hipStreamSynchronize(stream);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(in);
+    (void)hipFree(out);
+    (void)hipGetLastError();
+    p->variant = best.variant;
+    if (p->variant) p->kernel_name = family_kernel_name(p->variant, i8);
+    std::lock_guard<std::mutex> g(g_tune_lock);
+    g_tune_cache[key] = best;
 }
 
 }  // namespace shl
@@ -458,6 +554,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         free(p);
         return hip_fail(e, "upload(plan block)");
     }
+    if (algo == SHL_MI355X_ALGO_IGEMM && tuning_enabled() && d.batch > 0) want_pix_tab = true;  // a candidate of tune_plan
     if (want_pix_tab) {
         const int64_t M = (int64_t)d.batch * d.out_h * d.out_w;
         std::vector<int2> tab((size_t)M);
@@ -487,6 +584,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             return hip_fail(e, "upload(pixel address table)");
         }
     }
+    if (algo == SHL_MI355X_ALGO_IGEMM && kernel_host) tune_plan(p, (hipStream_t)stream);
     *plan_out = p;
     return SHL_MI355X_OK;
 }
@@ -676,6 +774,9 @@ static int fill_args(const shl_mi355x_conv_plan *plan, const void *input_dev, vo
 
 extern "C" {
 
+static int conv_forward_impl(const shl_mi355x_conv_plan *plan, const void *input_dev, void *output_dev, int32_t batch,
+                             void *stream);
+
 int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev,
                             void *output_dev, int32_t batch, void *stream)
 {
@@ -683,6 +784,17 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
         set_error("conv_forward: NULL argument");
         return SHL_MI355X_EINVAL;
     }
+    // the family measured best for this plan's own batch (other batches: the selection rules)
+    const bool tuned = plan->variant && (batch <= 0 || batch == plan->desc.batch);
+    if (tuned) igemm_set_plan_variant(plan->variant);
+    const int rc = conv_forward_impl(plan, input_dev, output_dev, batch, stream);
+    if (tuned) igemm_set_plan_variant(nullptr);
+    return rc;
+}
+
+static int conv_forward_impl(const shl_mi355x_conv_plan *plan, const void *input_dev, void *output_dev, int32_t batch,
+                             void *stream)
+{
     const shl_mi355x_conv_desc &d = plan->desc;
     ConvArgs a;
     int frc = fill_args(plan, input_dev, output_dev, batch, a);
@@ -744,51 +856,13 @@ int shl_mi355x_debug_trace(uint64_t *host, int32_t count)
     if (!host || count <= 0) return SHL_MI355X_EINVAL;
     const char *v = getenv("SHL_MI355X_IGEMM");  // which kernel's stamps: the producer / consumer kernel when it is forced
     if (v && !strcmp(v, "patch")) return patch_read_trace(reinterpret_cast<unsigned long long *>(host), count);
-    if (v && !strcmp(v, "res")) return res_read_trace(reinterpret_cast<unsigned long long *>(host), count);
-    const char *x = getenv("SHL_MI355X_PCX");
-    if (v && !strcmp(v, "pc") && x && x[0] == '1') return pcx_read_trace(reinterpret_cast<unsigned long long *>(host), count);
     if (v && !strcmp(v, "pc")) return pc_read_trace(reinterpret_cast<unsigned long long *>(host), count);
     return pp_read_trace(reinterpret_cast<unsigned long long *>(host), count);
 }
 
-/* depthwise 3x3 + pointwise 1x1 fused into one launch (dwpw_fused.hip); 1 when the pair qualifies */
-int shl_mi355x_dwpw_fusable(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw, int32_t batch)
-{
-    if (!dw || !pw) return 0;
-    static const char *off = getenv("SHL_MI355X_NO_FUSION");
-    if (off && off[0] == '1') return 0;
-    if (dw->desc.dtype != SHL_MI355X_I8 || pw->desc.dtype != SHL_MI355X_I8) return 0;
-    if (dw->desc.layout != SHL_MI355X_NHWC || pw->desc.layout != SHL_MI355X_NHWC) return 0;
-    ConvArgs a, b;
-    static char dummy[16];
-    if (fill_args(dw, dummy, dummy, batch, a) != SHL_MI355X_OK || fill_args(pw, dummy, dummy, batch, b) != SHL_MI355X_OK)
-        return 0;
-    return dwpw_fusable(a, b, dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12, pw->algo == SHL_MI355X_ALGO_IGEMM) ? 1 : 0;
-}
-
-int shl_mi355x_dwpw_forward(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw, const void *input_dev,
-                            void *output_dev, int32_t batch, void *stream)
-{
-    if (!dw || !pw || !input_dev || !output_dev) {
-        set_error("dwpw_forward: NULL argument");
-        return SHL_MI355X_EINVAL;
-    }
-    if (!shl_mi355x_dwpw_fusable(dw, pw, batch)) {
-        set_error("dwpw_forward: the pair does not qualify for the fused kernel");
-        return SHL_MI355X_ENOTSUP;
-    }
-    ConvArgs a, b;
-    int rc = fill_args(dw, input_dev, output_dev, batch, a);
-    if (rc == SHL_MI355X_OK) rc = fill_args(pw, input_dev, output_dev, batch, b);
-    if (rc != SHL_MI355X_OK) return rc;
-    if (a.M == 0) return SHL_MI355X_OK;
-    return launch_dwpw_fused(a, b, (hipStream_t)stream);
-}
-
-/* which fused kernel runs the pair: 0 none, 1 latency form (pwdw_fused.hip: small grids), 2 bandwidth form
- * (pwdw_stream.hip), 3 stem + depthwise (stemdw_fused.hip).  The bandwidth form is opt-in (SHL_MI355X_PWDW_STREAM=1: whenever the pair is
- * eligible): at batch 128 it only breaks even with the two stand-alone kernels for K <= 128 and loses
- * for deeper K (profiles/r01_notes.md), so large batches keep one launch per layer by default. */
+/* which fused kernel runs the pair: 0 none, 1 latency form (pwdw_fused.hip: small grids), 3 stem + depthwise
+ * (stemdw_fused.hip), 4 binary16 NCHW (pwdw_f16_nchw.hip).  (2 was the int8 bandwidth form for large batches: it only
+ * broke even with the two stand-alone kernels, csrc/parked/README.md; large batches keep one launch per layer.) */
 static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, const ConvArgs &a,
                            const ConvArgs &b)
 {
@@ -796,8 +870,6 @@ static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv
     if (pw->desc.dtype == SHL_MI355X_F16)  // binary16 NCHW (pwdw_f16_nchw.hip)
         return pw_igemm && dw->algo == SHL_MI355X_ALGO_DW && pwdw_f16_nchw_fusable(a, b) ? 4 : 0;
     if (pw->algo == SHL_MI355X_ALGO_STEM) return dw_dot4 && stemdw_fusable(a, b) ? 3 : 0;  // stem + depthwise
-    static const char *st = getenv("SHL_MI355X_PWDW_STREAM");
-    if (st && st[0] == '1' && pw_igemm && dw_dot4 && pwdw_stream_eligible(a, b)) return 2;
     return pwdw_fusable(a, b, pw_igemm, dw_dot4) ? 1 : 0;
 }
 
@@ -809,7 +881,7 @@ int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     static const char *sel = getenv("SHL_MI355X_PWDW");  // "0": keep pointwise and depthwise launches apart
     if ((off && off[0] == '1') || (sel && sel[0] == '0')) return 0;
     if (dw->desc.dtype != pw->desc.dtype || dw->desc.layout != pw->desc.layout) return 0;
-    // int8 NHWC (pwdw_fused.hip, stemdw_fused.hip, pwdw_stream.hip) or binary16 NCHW (pwdw_f16_nchw.hip)
+    // int8 NHWC (pwdw_fused.hip, stemdw_fused.hip) or binary16 NCHW (pwdw_f16_nchw.hip)
     const bool i8_nhwc = pw->desc.dtype == SHL_MI355X_I8 && pw->desc.layout == SHL_MI355X_NHWC;
     const bool f16_nchw = pw->desc.dtype == SHL_MI355X_F16 && pw->desc.layout == SHL_MI355X_NCHW;
     if (!i8_nhwc && !f16_nchw) return 0;
@@ -839,7 +911,6 @@ int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     switch (pwdw_kernel_for(pw, dw, a, b)) {
         case 4: return launch_pwdw_f16_nchw(a, b, (hipStream_t)stream);
         case 3: return launch_stemdw_fused(a, b, (hipStream_t)stream);
-        case 2: return launch_pwdw_stream(a, b, (hipStream_t)stream);
         default: return launch_pwdw_fused(a, b, (hipStream_t)stream);
     }
 }

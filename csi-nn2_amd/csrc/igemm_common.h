@@ -310,13 +310,9 @@ int launch_conv_igemm_pp(const ConvArgs &a, int dtype, int flavour, hipStream_t 
 int pc_flavour(const ConvArgs &a, int esize, bool forced);  // conv_igemm_pc.hip
 int launch_conv_igemm_pc(const ConvArgs &a, int dtype, int flavour, hipStream_t s);
 int pc_read_trace(unsigned long long *host, int count);
-bool pcx_applies(const ConvArgs &a);  // conv_igemm_pcx.hip: the pc kernel with one pixel staging per filter row
-int launch_conv_igemm_pcx(const ConvArgs &a, int dtype, int flavour, hipStream_t s);
-int pcx_read_trace(unsigned long long *host, int count);
-bool res_applies(const ConvArgs &a, int esize);  // conv_igemm_res.hip: persistent workgroups, resident weights (64-byte pixels)
-int launch_conv_igemm_res(const ConvArgs &a, hipStream_t s);
-int res_read_trace(unsigned long long *host, int count);
 const char *igemm_pick(const ConvArgs &a, int esize, int *flavour);
+void igemm_set_plan_variant(const char *v);  // nullptr: the selection rules; else "wave" | "tile" | "pp" | "pc" | "patch"
+bool igemm_env_override();                   // SHL_MI355X_IGEMM is set (A/B runs, tests): no tuning
 int pp_read_trace(unsigned long long *host, int count);
 int patch_read_trace(unsigned long long *host, int count);  // conv_igemm_patch.hip
 

@@ -42,7 +42,7 @@ struct dev_session {
     void *prev_stream; /* the session's stream before it became device resident */
     int prev_own;      /* ... and whether that was a stream of its own (else: the process default) */
     void *graph_exec;
-    unsigned char *fused;  /* per layer: 1 / 2 = runs fused with the next convolution (dw + pw / pw + dw) */
+    unsigned char *fused;  /* per layer: 2 = runs fused with the depthwise layer behind it (pointwise + depthwise) */
     unsigned char *folded; /* per layer: 1 = the relu / relu6 layer behind it runs in this convolution's epilogue */
     int nfused, nfolded;
     struct dev_session *next;
@@ -180,8 +180,9 @@ static struct shl_node *final_out(struct dev_session *ds, struct shl_ref_graph *
  *        the activation moves into the convolution's epilogue (folded[i] = 1, the relu layer is skipped): what a
  *        converter emits for a RISC-V target -- example/c906_mobilenetv1_f16.c is 28 csinn_conv2d + 27 csinn_relu --
  *        runs as 28 launches, not 55
- *   1x1 convolution -> depthwise 3x3   one launch of csrc/pwdw_fused.hip   (fused[i] = 2)
- *   depthwise 3x3 -> 1x1 convolution   one launch of csrc/dwpw_fused.hip   (fused[i] = 1, opt-in) */
+ *   1x1 convolution -> depthwise 3x3   one launch of csrc/pwdw_fused.hip (int8 NHWC) / pwdw_f16_nchw.hip (fused[i] = 2)
+ * (The other pairing, depthwise -> pointwise, recomputes the depthwise tile in every channel slice and measured
+ * slower beyond 64 channels: csrc/parked/README.md.) */
 static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
 {
     ds->fused = calloc((size_t)g->layer_index + 1, 1);
@@ -210,20 +211,16 @@ static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
             continue;
         }
         const int pw_dw = is_conv_op(a->type) && is_dw_op(b->type);
-        if ((!pw_dw && !(is_dw_op(a->type) && is_conv_op(b->type))) || consumers_of(g, mid) != 1) {
+        if (!pw_dw || consumers_of(g, mid) != 1) {
             i = j - 1;
             continue;
         }
         shl_mi355x_conv_plan *pa = shl_mi355x_registry_get(a->data), *pb = shl_mi355x_registry_get(b->data);
         struct csinn_tensor *in = a->in[0]->data;
-        if (pa && pb && pw_dw && shl_mi355x_pwdw_fusable(pa, pb, in->dim[0])) {
+        if (pa && pb && shl_mi355x_pwdw_fusable(pa, pb, in->dim[0])) {
             ds->fused[i] = 2;
             ds->nfused++;
             i = j + ds->folded[j]; /* the depthwise layer (and its activation) is taken */
-        } else if (pa && pb && !pw_dw && shl_mi355x_dwpw_fusable(pa, pb, in->dim[0])) {
-            ds->fused[i] = 1;
-            ds->nfused++;
-            i = j + ds->folded[j]; /* the pointwise layer (and its activation) is taken */
         } else {
             i = j - 1;
         }
@@ -247,9 +244,7 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
             struct shl_node *nx = g->layer[j];
             const int folded2 = ds->folded && ds->folded[j];
             struct dev_tensor *out2 = lookup(ds, folded2 ? g->layer[j + 1]->out[0] : nx->out[0]);
-            int (*fwd)(const shl_mi355x_conv_plan *, const shl_mi355x_conv_plan *, const void *, void *, int32_t,
-                       void *) = ds->fused[i] == 2 ? shl_mi355x_pwdw_forward : shl_mi355x_dwpw_forward;
-            int st = fwd(shl_mi355x_registry_get(n->data), shl_mi355x_registry_get(nx->data), in->dev, out2->dev,
+            int st = shl_mi355x_pwdw_forward(shl_mi355x_registry_get(n->data), shl_mi355x_registry_get(nx->data), in->dev, out2->dev,
                          in->shadow.dim[0], ds->stream);
             rc = st == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
             i = j + folded2;

@@ -255,17 +255,6 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
                             void *output_dev, int32_t batch, void *stream);
 
 /*
- * Depthwise 3x3 + pointwise 1x1 of a separable block as ONE launch (int8 NHWC, latency-bound
- * sizes): the int8 result of shl_ref_depthwise_conv2d_quant is formed in registers and consumed as
- * the MFMA operand of shl_ref_conv2d_quant -- same bits as running the two plans back to back, the
- * intermediate tensor is never written.  `input_dev` is the depthwise layer's input, `output_dev`
- * the pointwise layer's output.  shl_mi355x_dwpw_fusable() tells whether a pair of plans qualifies.
- */
-int shl_mi355x_dwpw_fusable(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw, int32_t batch);
-int shl_mi355x_dwpw_forward(const shl_mi355x_conv_plan *dw, const shl_mi355x_conv_plan *pw,
-                            const void *input_dev, void *output_dev, int32_t batch, void *stream);
-
-/*
  * Pointwise 1x1 + the depthwise 3x3 that consumes its output, as ONE launch (int8 NHWC): a workgroup
  * owns a 32-channel slice of shl_ref_conv2d_quant's output over a small pixel patch, keeps the int8
  * result in LDS and runs shl_ref_depthwise_conv2d_quant on those channels from there -- same bits as

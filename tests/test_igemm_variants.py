@@ -51,16 +51,10 @@ VARIANTS = [
     (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x128k64"), "pp"),
     (dict(SHL_MI355X_IGEMM="pp", SHL_MI355X_PP="256x128x2"), "pp"),
     # producer / consumer kernel with 128-byte K tiles (conv_igemm_pc.hip); takes C * esize % 128 == 0
-    # (SHL_MI355X_PCX=1: stride-1 "same" 3x3 shapes run its shifted-row form conv_igemm_pcx.hip)
     (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="256x128"), "pc"),
     (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="128x128"), "pc"),
     (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="256x128w16"), "pc"),
-    (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="256x128", SHL_MI355X_PCX="1"), "pc"),
-    (dict(SHL_MI355X_IGEMM="pc", SHL_MI355X_PC="128x128", SHL_MI355X_PCX="1"), "pc"),
     (dict(SHL_MI355X_IGEMM="pc"), "pc"),
-    # persistent workgroups with resident weights (conv_igemm_res.hip): int8, 64-byte pixels, Cout <= 64, stride 1
-    (dict(SHL_MI355X_IGEMM="res", SHL_MI355X_RES="1"), "res"),
-    (dict(SHL_MI355X_IGEMM="res", SHL_MI355X_RES="1", SHL_MI355X_RES_GROUPS="2"), "res"),
     # row-patch kernel (conv_igemm_patch.hip): int8 3x3 stride-1 "same", C % 64 == 0; NHWC and NCHW native; automatic
     # wave roles and every role assignment forced (pixel groups, channel blocks, K parts)
     (dict(SHL_MI355X_IGEMM="patch"), "patch"),
@@ -92,8 +86,6 @@ def _run_variant(variant):
     env["SHL_EXPECT_KERNEL"] = expect
     if expect in ("pp", "pc"):
         env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "30"
-    if expect == "res":
-        env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "16"
     if expect == "patch":
         env["SHL_EXPECT_FALLBACK"], env["SHL_EXPECT_MIN"] = "tile", "8" if extra.get("SHL_MI355X_PATCH") == "1,1,4" else "24"
     return subprocess.run([sys.executable, "-m", "pytest", SUITE, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
@@ -130,7 +122,7 @@ RESNET_3X3 = [dict(c=64, co=64, h=56, w=56), dict(c=128, co=128, h=56, w=56, str
               dict(c=128, co=128, h=28, w=28), dict(c=256, co=256, h=28, w=28, stride=(2, 2)),
               dict(c=256, co=256, h=14, w=14), dict(c=512, co=512, h=14, w=14, stride=(2, 2)),
               dict(c=512, co=512, h=7, w=7)]
-BLOCK_TILE_KERNELS = ("tile", "pp", "pc", "res", "halo", "patch")
+BLOCK_TILE_KERNELS = ("tile", "pp", "pc", "halo", "patch")
 
 
 @pytest.fixture(scope="module")

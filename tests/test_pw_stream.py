@@ -45,7 +45,7 @@ for i, kw in enumerate(SHAPES):
 
 
 def run(force):
-    env = dict(os.environ, SHL_MI355X_PWSTREAM=force)
+    env = dict(os.environ, SHL_MI355X_PWSTREAM=force, SHL_MI355X_TUNE="0")   # a kernel A/B: the selection is forced, not measured
     res = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
                          timeout=600, env=env)
     rows = [l.split() for l in res.stdout.splitlines() if l.startswith("CASE")]

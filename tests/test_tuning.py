@@ -1,0 +1,97 @@
+"""Plan-time choice of the implicit-GEMM family by measurement (csrc/conv_plan.hip:tune_plan).
+
+With SHL_MI355X_TUNE unset (the product default) a plan times the selection rules' pick against every family forced
+in turn on scratch tensors of its own shape and keeps the fastest.  Whatever it picks must give the same results: int8
+bit for bit against the oracle, binary16 within 1e-3; a second plan of the same shape must come from the cache (same
+pick, no timing); SHL_MI355X_IGEMM=<family> and SHL_MI355X_TUNE=0 must switch it off."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import golden_util
+from cases import pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHAPES = [
+    dict(c=64, co=64, h=28, w=28, n=8),                                  # 3x3 with a row-patch weight copy
+    dict(c=128, co=128, h=14, w=14, n=16, layout=cases.NCHW, act=1),    # NCHW: re-layout path vs the NCHW-native kernel
+    dict(c=256, co=256, h=14, w=14, n=4, stride=(2, 2)),                 # deep K, few tiles
+    dict(c=512, co=512, h=7, w=7, n=2, k=(1, 1), pad=(0, 0, 0, 0)),      # pointwise
+    dict(c=96, co=40, h=9, w=11, n=3, exact=False, per_channel=True),    # ragged everything, converter scales
+    dict(c=64, co=128, h=12, w=12, n=4, dtype="f16"),                    # binary16
+]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    fe = pkg.load_frontend("standalone")
+    hip, opt = pkg.load_backend(fe)
+    if hip.shl_mi355x_device_count() < 1:
+        pytest.fail("no gfx950 device visible: " + hip.shl_mi355x_last_error().decode())
+    return fe, hip, opt, cases.HipDevice(hip)
+
+
+@pytest.fixture
+def tuning_on(monkeypatch):
+    monkeypatch.delenv("SHL_MI355X_TUNE", raising=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(SHAPES)))
+def test_tuned_plans_compute_the_same_results(gpu, tuning_on, i):
+    fe, hip, opt, dev = gpu
+    case = cases.make_case(31000 + i, **SHAPES[i])
+    names = []
+    for rep in range(2):   # the second plan takes the cached pick
+        kept = []
+        got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+        names.append(opt.shl_mi355x_params_kernel_name(kept[0][0]).decode())
+        assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
+        if case["dtype"] == "int8":
+            n, worst = cases.mismatch_report(got, cases.oracle_run(case, "exact"))
+            assert n == 0, "%r via %s: %d mismatches (max %d)" % (SHAPES[i], names[-1], n, worst)
+        else:
+            golden_util.compare_f16_tol(got, cases.oracle_run(case, "f16"), "%r via %s" % (SHAPES[i], names[-1]))
+    assert names[0] == names[1], names
+
+
+SCRIPT = r"""
+import sys
+sys.path.insert(0, %(tests)r)
+import cases
+from cases import pkg
+fe = pkg.load_frontend("standalone")
+hip, opt = pkg.load_backend(fe)
+dev = cases.HipDevice(hip)
+case = cases.make_case(31100, c=128, co=128, h=28, w=28, n=32)
+kept = []
+got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+n, worst = cases.mismatch_report(got, cases.oracle_run(case, "exact"))
+print("RESULT", opt.shl_mi355x_params_kernel_name(kept[0][0]).decode(), n)
+"""
+
+
+@pytest.mark.gpu
+def test_the_tuner_reports_its_timings_and_can_be_switched_off():
+    base = {k: v for k, v in os.environ.items() if not k.startswith("SHL_MI355X_")}
+    script = SCRIPT % dict(tests=os.path.join(ROOT, "tests"))
+
+    def run(extra):
+        res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600,
+                             env=dict(base, SHL_MI355X_DEBUG_TUNE="1", **extra))
+        assert res.returncode == 0 and "RESULT" in res.stdout, res.stdout + res.stderr
+        return res.stdout.split("RESULT")[1].split(), [l for l in res.stderr.splitlines() if l.startswith("tune ")]
+
+    (name, bad), lines = run({})
+    assert bad == "0"
+    timed = [l.split(":")[1].split()[0] for l in lines]
+    assert timed[0] == "rules" and {"wave", "tile", "pp", "pc", "patch"} <= set(timed), lines
+    (name_off, bad), lines = run({"SHL_MI355X_TUNE": "0"})
+    assert bad == "0" and not lines
+    (name_forced, bad), lines = run({"SHL_MI355X_IGEMM": "tile"})
+    assert bad == "0" and not lines and "tile" in name_forced
