@@ -391,8 +391,21 @@ static int conv2d_channel_init_act(CSINN_CONV_ARGS, int act)
     struct shl_mi355x_conv_desc d;
     int rc = channel_desc(&d, input, output, kernel, params, act, "conv2d_channel");
     if (rc != CSINN_TRUE) return rc;
-    if (params->group != 1 || kernel->dim[1] != d.in_c) {
-        shl_debug_error("mi355x: conv2d_channel: grouped kernels go through GROUP_CONV2D_CHANNEL (not on the device)\n");
+    const int G = params->group > 0 ? params->group : 1;
+    if (G > 1) {
+        /* CSINN_OP_GROUP_CONV2D_CHANNEL*: shl_ref_group_conv2d_channel_nchw_quant (convolution_channel.c:257-301) runs
+         * the per-channel convolution on the G BLOCKS i * (N * C/G * H * W) of the buffers -- the usual grouped
+         * convolution for one image, G consecutive tensors for a batch (whose images past the first the x86 float path
+         * then never computes).  One image: one launch of the grouped direct kernel with the per-channel
+         * tables; batches are refused (next to the genuine library they fall through to it) */
+        if (d.batch != 1 || d.in_c % G || d.out_c % G || kernel->dim[1] != d.in_c / G) {
+            shl_debug_error("mi355x: group_conv2d_channel: one image, C and Cout multiples of the group count expected\n");
+            return CSINN_FALSE;
+        }
+        d.group = G;
+        d.algo = SHL_MI355X_ALGO_GROUP;
+    } else if (kernel->dim[1] != d.in_c) {
+        shl_debug_error("mi355x: conv2d_channel: kernel with %d input channels for a tensor of %d\n", kernel->dim[1], d.in_c);
         return CSINN_FALSE;
     }
     if (kernel->data == NULL || kernel->mtype == CSINN_MEM_TYPE_DMABUF) return CSINN_FALSE;
@@ -541,6 +554,8 @@ static int channel_exec(CSINN_CONV_ARGS, int (*init_act)(CSINN_CONV_ARGS, int), 
 CHANNEL_OP(conv2d_channel, conv2d_channel_init_act, SHL_MI355X_ACT_NONE, "conv2d_channel")
 CHANNEL_OP(conv2d_channel_relu, conv2d_channel_init_act, SHL_MI355X_ACT_RELU, "conv2d_channel_relu")
 CHANNEL_OP(conv2d_channel_relu6, conv2d_channel_init_act, SHL_MI355X_ACT_RELU6, "conv2d_channel_relu6")
+CHANNEL_OP(group_conv2d_channel, conv2d_channel_init_act, SHL_MI355X_ACT_NONE, "group_conv2d_channel")
+CHANNEL_OP(group_conv2d_channel_relu, conv2d_channel_init_act, SHL_MI355X_ACT_RELU, "group_conv2d_channel_relu")
 CHANNEL_OP(depthwise_conv2d_channel, dwconv_channel_init_act, SHL_MI355X_ACT_NONE, "depthwise_conv2d_channel")
 CHANNEL_OP(depthwise_conv2d_channel_relu, dwconv_channel_init_act, SHL_MI355X_ACT_RELU, "depthwise_conv2d_channel_relu")
 CHANNEL_OP(depthwise_conv2d_channel_relu6, dwconv_channel_init_act, SHL_MI355X_ACT_RELU6, "depthwise_conv2d_channel_relu6")

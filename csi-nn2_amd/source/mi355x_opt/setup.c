@@ -571,6 +571,10 @@ void shl_target_init_mi355x(void)
         shl_mi355x_conv2d_channel_relu_exec, shl_gref_conv2d_relu);
     reg(CSINN_DTYPE_INT8, CSINN_OP_CONV2D_CHANNEL_RELU6, shl_mi355x_conv2d_channel_relu6_init,
         shl_mi355x_conv2d_channel_relu6_exec, shl_gref_conv2d_relu6);
+    reg(CSINN_DTYPE_INT8, CSINN_OP_GROUP_CONV2D_CHANNEL, shl_mi355x_group_conv2d_channel_init,
+        shl_mi355x_group_conv2d_channel_exec, shl_gref_group_conv2d);
+    reg(CSINN_DTYPE_INT8, CSINN_OP_GROUP_CONV2D_CHANNEL_RELU, shl_mi355x_group_conv2d_channel_relu_init,
+        shl_mi355x_group_conv2d_channel_relu_exec, shl_gref_group_conv2d_relu);
     reg(CSINN_DTYPE_INT8, CSINN_OP_DEPTHWISE_CONV2D_CHANNEL, shl_mi355x_depthwise_conv2d_channel_init,
         shl_mi355x_depthwise_conv2d_channel_exec, shl_gref_depthwise_conv2d);
     reg(CSINN_DTYPE_INT8, CSINN_OP_DEPTHWISE_CONV2D_CHANNEL_RELU, shl_mi355x_depthwise_conv2d_channel_relu_init,

@@ -75,6 +75,10 @@ int shl_mi355x_conv2d_channel_relu_init(CSINN_CONV_ARGS);
 int shl_mi355x_conv2d_channel_relu_exec(CSINN_CONV_ARGS);
 int shl_mi355x_conv2d_channel_relu6_init(CSINN_CONV_ARGS);
 int shl_mi355x_conv2d_channel_relu6_exec(CSINN_CONV_ARGS);
+int shl_mi355x_group_conv2d_channel_init(CSINN_CONV_ARGS);      /* CSINN_OP_GROUP_CONV2D_CHANNEL{,_RELU}: one image */
+int shl_mi355x_group_conv2d_channel_exec(CSINN_CONV_ARGS);
+int shl_mi355x_group_conv2d_channel_relu_init(CSINN_CONV_ARGS);
+int shl_mi355x_group_conv2d_channel_relu_exec(CSINN_CONV_ARGS);
 int shl_mi355x_depthwise_conv2d_channel_init(CSINN_CONV_ARGS);
 int shl_mi355x_depthwise_conv2d_channel_exec(CSINN_CONV_ARGS);
 int shl_mi355x_depthwise_conv2d_channel_relu_init(CSINN_CONV_ARGS);

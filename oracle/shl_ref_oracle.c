@@ -480,7 +480,28 @@ int oracle_conv2d_channel_i8(const struct oracle_conv *c, const int8_t *input, c
                              const int32_t *bias, int8_t *output)
 {
     if (c->layout != ORACLE_NCHW) return -4; /* CSINN_UNSUPPORT_LAYOUT */
-    if (c->group != 1 || c->kernel_channels != c->out_c) return -2;
+    if (c->kernel_channels != c->out_c) return -2;
+    if (c->group > 1) {
+        /* shl_ref_group_conv2d_channel_nchw_quant (convolution_channel.c:257-301): group i is the plain per-channel
+         * convolution on the i-th BLOCK of the buffers -- input + i * (N * C/G * H * W), output + i * (N * Cout/G * Ho *
+         * Wo), kernel rows, bias and kernel records i * Cout/G .. -- i.e. the usual grouped convolution for N = 1 and G
+         * consecutive tensors for N > 1.  Restated literally. */
+        if (c->in_c % c->group || c->out_c % c->group) return -2;
+        struct oracle_conv s = *c;
+        s.group = 1;
+        s.in_c = c->in_c / c->group;
+        s.out_c = c->out_c / c->group;
+        s.kernel_channels = s.out_c;
+        const int64_t isz = in_elems(&s), osz = out_elems(&s), ksz = kernel_elems(&s);
+        for (int g = 0; g < c->group; ++g) {
+            s.kernel_scale = c->kernel_scale + (int64_t)g * s.out_c;
+            s.kernel_zp = c->kernel_zp + (int64_t)g * s.out_c;
+            int rc = oracle_conv2d_channel_i8(&s, input + g * isz, kernel + g * ksz, bias ? bias + (int64_t)g * s.out_c : NULL,
+                                              output + g * osz);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     const int64_t ni = in_elems(c), nw = kernel_elems(c), no = out_elems(c);
     float *fi = malloc(sizeof(float) * (size_t)(ni > 0 ? ni : 1));
     float *fw = malloc(sizeof(float) * (size_t)(nw > 0 ? nw : 1));

@@ -357,17 +357,20 @@ def mismatch_report(a, b):
 # (source/reference/convolution_channel.c).  No csinn_* entry point exists for these op ids: a
 # caller maps the callback itself (shl_op_callback_map) and calls cb->exec, which is what these helpers do.
 OP_CONV2D_CHANNEL, OP_DEPTHWISE_CONV2D_CHANNEL = 31, 38   # + 1 relu, + 2 relu6
+OP_GROUP_CONV2D_CHANNEL = 45                              # + 1 relu (the reference registers no relu6 form)
 
 
 def make_channel_case(seed, kind="conv", n=1, h=8, w=8, c=16, co=16, k=(3, 3), stride=(1, 1), pad=(1, 1, 1, 1),
-                      dilation=(1, 1), multiplier=1, act=0, exact=True, has_bias=True, kernel_zp=False):
-    """int8 NCHW problem with one kernel record per output channel.  kind: "conv" | "dw"."""
+                      dilation=(1, 1), multiplier=1, act=0, exact=True, has_bias=True, kernel_zp=False, groups=1):
+    """int8 NCHW problem with one kernel record per output channel.  kind: "conv" | "dw"; groups > 1 with kind "conv" is
+    CSINN_OP_GROUP_CONV2D_CHANNEL*."""
     rng = np.random.default_rng(seed)
     dw = kind == "dw"
     if dw:
         co = c * multiplier
     case = make_case(seed, layout=NCHW, n=n, h=h, w=w, c=c, co=co, k=k, stride=stride, pad=pad, dilation=dilation,
-                     depthwise=dw, multiplier=multiplier, act=act, per_channel=True, exact=exact, has_bias=has_bias)
+                     depthwise=dw, multiplier=multiplier, act=act, per_channel=True, exact=exact, has_bias=has_bias,
+                     groups=1 if dw else groups)
     case["chan_kind"] = kind
     case["k_zp"] = (rng.integers(-6, 7, co).astype(np.int32) if kernel_zp else np.zeros(co, dtype=np.int32))
     if dw:
@@ -435,8 +438,8 @@ def csinn_channel_run(fe, api, case, device=None, call_init=True, keep_params=No
         params = reuse_params[0]
     else:
         params = pkg.conv_params(fe, keep, api, pkg.LAYOUT_NCHW, case["stride"], case["pad"], case["dilation"],
-                                 case["c"] if dw else 1, 0, sess)
-    op = (OP_DEPTHWISE_CONV2D_CHANNEL if dw else OP_CONV2D_CHANNEL) + case["act"]
+                                 case["c"] if dw else case["group"], 0, sess)
+    op = (OP_DEPTHWISE_CONV2D_CHANNEL if dw else OP_GROUP_CONV2D_CHANNEL if case["group"] > 1 else OP_CONV2D_CHANNEL) + case["act"]
     fe.shl_op_callback_map.restype = C.c_int
     fe.shl_op_callback_map.argtypes = [C.c_void_p, C.c_int, C.c_int]
     rc = fe.shl_op_callback_map(params, op, pkg.DTYPE_INT8)

@@ -32,6 +32,11 @@ CHANNEL_CASES = [
     ("dw_no_bias_dilated", "dw", dict(c=6, has_bias=False, dilation=(2, 2), pad=(2, 2, 2, 2))),
     ("dw_5x3_asym_pad", "dw", dict(c=12, k=(5, 3), pad=(2, 1, 1, 0), n=3, h=9, w=10)),
     ("dw_512_14", "dw", dict(c=512, h=14, w=14, act=1)),
+    # CSINN_OP_GROUP_CONV2D_CHANNEL{,_RELU} (convolution_channel.c:257-301): one image (the block slicing + the x86 path's
+    # image-0-only bug make batches meaningless in the reference itself)
+    ("group4_3x3", "conv", dict(c=16, co=24, groups=4)),
+    ("group2_3x3_s2_relu", "conv", dict(c=8, co=8, groups=2, act=1, stride=(2, 2), h=11, w=9)),
+    ("group32_1x1_general", "conv", dict(c=64, co=64, groups=32, k=(1, 1), pad=(0, 0, 0, 0), exact=False)),
 ]
 
 
