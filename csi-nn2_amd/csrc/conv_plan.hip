@@ -376,7 +376,16 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         probe.M = (int32_t)((int64_t)d.batch * d.out_h * d.out_w);
         probe.N = d.batch;
         probe.out_nchw = d.layout == SHL_MI355X_NCHW && ((d.out_h * d.out_w * es) & 3) == 0;
-        const char *v = igemm_pick_name(probe, es);
+        // as shl_mi355x_conv_forward decides: an NCHW layer first asks the NCHW-native row-patch kernel (input AND output
+        // NCHW), everything else sees the NHWC view of the re-layout path
+        const char *v = nullptr;
+        if (probe.in_nchw) {
+            ConvArgs t = probe;
+            t.out_nchw = 1;
+            if (!strcmp(igemm_pick_name(t, es), "patch")) v = "patch";
+            probe.in_nchw = 0;
+        }
+        if (!v) v = igemm_pick_name(probe, es);
         if (!strcmp(v, "wave"))
             p->kernel_name = i8 ? "conv_igemm_wave_i8_mfma32x32x32" : "conv_igemm_wave_f16_mfma32x32x16";
         else if (!strcmp(v, "regs"))
