@@ -486,6 +486,9 @@ def main():
                    "device_memory": "C-ABI allocator (shl_mi355x_malloc)",
                    "ops_per_image": ops_per_image, "algorithmic_bytes_per_image": chain.total_bytes() // batch,
                    "device": arch.value.decode(), "compute_units": cus.value,
+                   "kernel_choice": ("selection rules only (SHL_MI355X_TUNE=0)" if os.environ.get("SHL_MI355X_TUNE", "")[:1] == "0"
+                                     else "forced family " + os.environ["SHL_MI355X_IGEMM"] if os.environ.get("SHL_MI355X_IGEMM")
+                                     else "measured per plan at creation (conv_plan.hip:tune_plan: rules vs every implicit-GEMM family, cached per shape)"),
                    # what proves N distinct devices took part: every rank's PCI bus id (hipDeviceGetPCIBusId through the
                    # C-ABI, gathered over the bootstrap group) and the rank count RCCL itself reports for the communicator
                    "device_bus_ids": par.LAST_BROADCAST.get("bus_ids") or [par.device_bus_id(hip)],
