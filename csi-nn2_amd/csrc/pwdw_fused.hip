@@ -48,6 +48,14 @@ struct PwDwArgs {
     int32_t nsub;              // K sub-steps in all = C / 32
     uint32_t rw_magic;         // ceil(2^20 / rw): j / rw == (j * rw_magic) >> 20 for j < 4096
     uint32_t bw_magic;         // same for bw
+    // workgroup id -> (slice, rectangle), XCD aware (hardware hands workgroup L of a 1-D grid to XCD L % 8): the eight
+    // XCDs form xg slice groups x 8 / xg rectangle groups, so that an XCD's L2 fetches the activations of 1 / (8 / xg)
+    // of the rectangles and the weights of 1 / xg of the slices.  xg = 0: plain 3-D grid (slice, tx, ty).
+    int32_t xg, xg_log2;       // slice groups: 1, 2, 4 or 8
+    int32_t spg;               // slices per group = slices / xg
+    uint32_t spg_magic;        // j / spg == (j * spg_magic) >> 20 for j < 4096
+    uint32_t tx_magic;         // same for tiles_x
+    int32_t nrect;             // rectangles in all = tiles_x * tiles_y * N
 };
 
 // MTW: MFMA tiles per wave (upper bound), NSW: K sub-steps per wave (upper bound), MAXT: threads (the
@@ -62,9 +70,17 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar control around MFMA
     const int frow = lane & 31, fhalf = lane >> 5;
-    const int slice = blockIdx.x;
-    const int tx = blockIdx.y;
-    int ty = blockIdx.z, n = 0;
+    int slice = blockIdx.x, tx = blockIdx.y, ty = blockIdx.z, n = 0;
+    if (f.xg) {
+        const int L = blockIdx.x;
+        const int x = L & 7, j = L >> 3;                        // XCD, index among that XCD's workgroups
+        const int b = (int)(((uint32_t)j * f.spg_magic) >> 20);
+        slice = (x & (f.xg - 1)) * f.spg + (j - b * f.spg);  // a group = spg ADJACENT slices
+        const int rect = b * (8 >> f.xg_log2) + (x >> f.xg_log2);
+        if (rect >= f.nrect) return;
+        ty = (int)(((uint32_t)rect * f.tx_magic) >> 20);
+        tx = rect - ty * f.tiles_x;
+    }
     if (d.N > 1) {
         n = ty / f.tiles_y;
         ty -= n * f.tiles_y;
@@ -253,6 +269,39 @@ static bool choose_rect(const ConvArgs &q, const ConvArgs &d, PwDwArgs &f)
     f.nsub = nsub;
     f.rw_magic = ((1u << 20) + f.rw - 1) / f.rw;
     f.bw_magic = ((1u << 20) + f.bw - 1) / f.bw;
+    // Which XCDs share what.  HBM-side bytes of the launch ~ xg x activations + (8 / xg) x weights (every slice group
+    // fetches the rectangles' pixels, every rectangle group the slices' weights; measured on the plain grid: 2.97x
+    // the algorithmic bytes over MobileNetV1's twelve pairs, profiles/r03_h_pmc_traffic.json): take the cheapest
+    // admissible split.  Admissible = a slice group is a run of ADJACENT slices covering whole 128-byte lines of the
+    // NHWC output (four slices): with the lines of a pixel written by one L2 the chain is 1.5 us shorter than with
+    // the same lines pieced together from four or eight L2s at the kernel boundary (72.6 -> 71.1 us; strided groups of
+    // the same sizes: 72.1 - 74.0; profiles/r04_notes.md).
+    {
+        const int S = (int)slices;
+        const int64_t R = (int64_t)f.tiles_x * f.tiles_y * d.N;
+        static const char *xe = getenv("SHL_MI355X_PWDW_XG");  // 0 (plain grid) | 1 | 2 | 4 | 8: A/B
+        const int forced = xe ? atoi(xe) : -1;
+        const double act = (double)q.N * q.H * q.W * q.C, wts = (double)q.C * q.Co;
+        int best_g = 0;
+        double best_c = 1e30;
+        for (int g = 1; g <= 8; g <<= 1) {
+            if (S % g) continue;
+            if (forced > 0 && g != forced) continue;
+            if (forced <= 0 && g > 1 && ((S / g) & 3) != 0) continue;  // whole 128-byte lines of the output per XCD (below)
+            const int rpg = 8 / g;
+            const int64_t per_xcd = (int64_t)(S / g) * ((R + rpg - 1) / rpg);
+            if (per_xcd >= 4096 || R >= 4096) continue;
+            const double c = g * act + rpg * wts;
+            if (c < best_c) best_c = c, best_g = g;
+        }
+        if (forced == 0) best_g = 0;
+        f.xg = best_g;
+        f.xg_log2 = best_g == 8 ? 3 : (best_g == 4 ? 2 : (best_g == 2 ? 1 : 0));
+        f.spg = best_g ? S / best_g : S;
+        f.spg_magic = ((1u << 20) + f.spg - 1) / f.spg;
+        f.tx_magic = ((1u << 20) + f.tiles_x - 1) / f.tiles_x;
+        f.nrect = (int32_t)R;
+    }
     return true;
 }
 
@@ -283,7 +332,11 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         set_error("pwdw_fused: the pair does not qualify");
         return SHL_MI355X_ENOTSUP;
     }
-    const dim3 grid((unsigned)(q.Co >> 5), (unsigned)f.tiles_x, (unsigned)(f.tiles_y * d.N));
+    dim3 grid((unsigned)(q.Co >> 5), (unsigned)f.tiles_x, (unsigned)(f.tiles_y * d.N));
+    if (f.xg) {
+        const int rpg = 8 / f.xg;
+        grid = dim3((unsigned)(8 * f.spg * ((f.nrect + rpg - 1) / rpg)), 1, 1);
+    }
     const size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
 #define SHL_PWDW(NSWV, MAXT)                                                                                         \
     do {                                                                                                       \
