@@ -964,10 +964,10 @@ const char *igemm_pick(const ConvArgs &a, int esize, int *flavour)
     if (flavour) *flavour = -1;
     if (!ov[0] && conv_gemv_pick(a, esize)) return "gemv";
     const bool forced_patch = !strcmp(ov, "patch");
-    if ((forced_patch || !ov[0]) && esize == 1 && a.w_patch) {  // 3x3 stride-1 "same" from one staged row patch (conv_igemm_patch.hip)
+    if ((forced_patch || !ov[0]) && a.w_patch) {  // 3x3 stride-1 "same" from one staged row patch (conv_igemm_patch.hip; binary16: NHWC)
         if (forced_patch) {
             ConvArgs t = a;
-            if ((a.act == SHL_MI355X_ACT_NONE || a.act_clamp) && patch_setup(t)) return "patch";
+            if ((esize == 2 || a.act == SHL_MI355X_ACT_NONE || a.act_clamp) && patch_setup(t)) return "patch";
         } else if (patch_auto(a)) {
             return "patch";
         }

@@ -42,9 +42,20 @@
 namespace shl {
 
 // =================================================================================================== host side
+static int pt_esize(const shl_mi355x_conv_desc &d) { return d.dtype == SHL_MI355X_I8 ? 1 : 2; }
+
 bool patch_supports(const shl_mi355x_conv_desc &d)
 {
-    if (d.dtype != SHL_MI355X_I8 || d.group != 1) return false;
+    if (d.group != 1) return false;
+    if (d.dtype == SHL_MI355X_F16) {
+        // binary16: stride 1, NHWC tensors (the stride-2 form and the NCHW staging transpose BYTES); an NCHW layer meets
+        // the kernel on the NHWC view of conv_forward's re-layout path
+        static const char *f16_env = getenv("SHL_MI355X_PATCH_F16");  // "0": off (A/B)
+        if (f16_env && f16_env[0] == '0') return false;
+        if (d.stride_h != 1 || d.stride_w != 1) return false;
+    } else if (d.dtype != SHL_MI355X_I8) {
+        return false;
+    }
     if (d.kernel_h != 3 || d.kernel_w != 3 || d.dilation_h != 1 || d.dilation_w != 1) return false;
     if (d.pad_top != 1 || d.pad_left != 1) return false;
     if (d.stride_h == 2 && d.stride_w == 2) {
@@ -53,9 +64,9 @@ bool patch_supports(const shl_mi355x_conv_desc &d)
     } else if (d.stride_h != 1 || d.stride_w != 1 || d.out_h != d.in_h || d.out_w != d.in_w) {
         return false;
     }
-    if (d.in_c % 64 != 0 || d.in_w > PT_PIX) return false;
-    if (d.layout == SHL_MI355X_NHWC && d.out_c % 16 != 0) return false;  // 16-byte stores of 16 channels
-    if (d.in_zp < -128 || d.in_zp > 127) return false;
+    if ((d.in_c * pt_esize(d)) % 64 != 0 || d.in_w > PT_PIX) return false;
+    if ((d.layout == SHL_MI355X_NHWC || d.dtype == SHL_MI355X_F16) && d.out_c % 16 != 0) return false;  // 16-byte stores of 16 (binary16: 2 x 8) channels
+    if (d.dtype == SHL_MI355X_I8 && (d.in_zp < -128 || d.in_zp > 127)) return false;
     return true;
 }
 
@@ -133,7 +144,7 @@ int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, in
     static const char *pair_env = getenv("SHL_MI355X_PATCH_PAIR");  // "0": off (A/B), "1": whenever the tiles pair up (tests)
     const int64_t tiles = (int64_t)nt_m * ps->nt_n;
     const bool pays = (pair_env && pair_env[0] == '1') || (double)((tiles + 511) / 512) * 1.7 < (double)((tiles + 255) / 256);
-    if (!(pair_env && pair_env[0] == '0') && PT_NW8(geom) && C == kc && kp == 1 && nt_m % 2 == 0 && total_rows % tr == 0 &&
+    if (!(pair_env && pair_env[0] == '0') && !PT_F16(geom) && PT_NW8(geom) && C == kc && kp == 1 && nt_m % 2 == 0 && total_rows % tr == 0 &&
         ((int64_t)(nt_m / 2) * tr) % H == 0 && pays)
         ps->pair_dn = (int)((int64_t)(nt_m / 2) * tr / H);
     return 1;
@@ -220,9 +231,11 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     if (!patch_supports(d) || batch <= 0) return 0;
     static const char *env = getenv("SHL_MI355X_PATCH");  // "pg,ob,kp" forces the roles (tests, A/B)
     const bool s2 = d.stride_h == 2;
-    const int kc = (d.in_c % 128 == 0 && !s2) ? 128 : 64;  // stride 2: two 64-channel patches of one input row per tile row fit LDS
+    const bool f16 = d.dtype == SHL_MI355X_F16;
+    const int cbytes = d.in_c * pt_esize(d);  // the kernel's "channels" are the bytes of a pixel
+    const int kc = (cbytes % 128 == 0 && !s2) ? 128 : 64;  // stride 2: two 64-channel patches of one input row per tile row fit LDS
     const int u = kc / 32;
-    const bool nchw = d.layout == SHL_MI355X_NCHW;
+    const bool nchw = d.layout == SHL_MI355X_NCHW && !f16;  // binary16 NCHW layers: the NHWC view
     static const char *s2_env = getenv("SHL_MI355X_PATCH_S2");  // "0": no stride-2 form (A/B)
     if (s2 && s2_env && s2_env[0] == '0') return 0;
     // NHWC keeps its stride-2 layers on the block-tile kernels (28 / 22 us against 32 / 32 for ResNet-50's at batch 128:
@@ -234,10 +247,10 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         int pg = 0, ob = 0, kp = 0;
         if (sscanf(env, "%d,%d,%d", &pg, &ob, &kp) == 3 && pg * ob * kp == 4 && u % kp == 0 && pg != 4 && !(pg == 2 && kp == 2)) {
             PatchShape ps;
-            int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0);
+            int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0) | (f16 ? 1 << 23 | 1 << 20 : 0);
             if (s2 && !PT_NW8(g)) return 0;  // the stride-2 form has eight waves
-            if (!s2 && !patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) g &= ~(1 << 20);  // four waves take two NCHW rounds
-            return patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps) ? g : 0;
+            if (!s2 && !f16 && !patch_shape(batch, d.in_h, d.in_w, cbytes, d.out_c, nchw, g, &ps)) g &= ~(1 << 20);  // four waves take two NCHW rounds
+            return patch_shape(batch, d.in_h, d.in_w, cbytes, d.out_c, nchw, g, &ps) ? g : 0;
         }
     }
     static const int cand[][3] = {{1, 4, 1}, {2, 2, 1}, {1, 2, 2}, {1, 1, 4}};
@@ -249,12 +262,12 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         if (u % kp != 0) continue;
         if (ob > 1 && ob / 2 >= ocblks) continue;  // half of the channel blocks of a tile would be empty
         PatchShape ps;
-        int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0);
+        int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0) | (f16 ? 1 << 23 | 1 << 20 : 0);  // binary16: eight waves
         if (s2 && !PT_NW8(g)) return 0;  // the stride-2 form has eight waves
-        if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) {
-            if (s2) continue;
+        if (!patch_shape(batch, d.in_h, d.in_w, cbytes, d.out_c, nchw, g, &ps)) {
+            if (s2 || f16) continue;
             g &= ~(1 << 20);  // four waves take two NCHW staging rounds
-            if (!patch_shape(batch, d.in_h, d.in_w, d.in_c, d.out_c, nchw, g, &ps)) continue;
+            if (!patch_shape(batch, d.in_h, d.in_w, cbytes, d.out_c, nchw, g, &ps)) continue;
         }
         const int64_t tiles = (int64_t)ps.nt_m * ps.nt_n;
         const double rounds = (double)((tiles + 255) / 256);
@@ -273,14 +286,17 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
 size_t patch_weight_bytes(const shl_mi355x_conv_desc &d, int geom)
 {
     const int ocblks = (d.out_c + 31) / 32;
-    return (size_t)ocblks * 32 * 9 * d.in_c + 9 * 1024;  // + eight fragments of read-ahead past the last K step
+    return (size_t)ocblks * 32 * 9 * d.in_c * pt_esize(d) + 9 * 1024;  // + eight fragments of read-ahead past the last K step
 }
 
 // [channel block][K part][stage][tap][sub-step of the part][lane][16 B]: lane = (channel & 31) | (K half << 5)
 void patch_pack_weights(const shl_mi355x_conv_desc &d, int geom, const int8_t *src, int8_t *dst)
 {
     const int kc = PT_KC(geom), kp = PT_KP(geom);
-    const int u = kc / 32, ui_n = u / kp, nstg = d.in_c / kc, C = d.in_c;
+    // binary16: the same walk with two bytes per channel -- a K row is C * 2 bytes, a fragment piece 8 channels
+    const int es = pt_esize(d);
+    const int C = d.in_c * es;
+    const int u = kc / 32, ui_n = u / kp, nstg = C / kc;
     const int ocblks = (d.out_c + 31) / 32;
     memset(dst, 0, patch_weight_bytes(d, geom));
     for (int ocb = 0; ocb < ocblks; ++ocb)
@@ -296,10 +312,10 @@ void patch_pack_weights(const shl_mi355x_conv_desc &d, int geom, const int8_t *s
                             const int c0 = st * kc + usub * 32 + (lane >> 5) * 16;
                             const int ky = tap / 3, kx = tap % 3;
                             for (int b = 0; b < 16; ++b) {
-                                const int c = c0 + b;
-                                const size_t s = d.layout == SHL_MI355X_NHWC ? (((size_t)oc * 3 + ky) * 3 + kx) * C + c
-                                                                             : (((size_t)oc * C + c) * 3 + ky) * 3 + kx;
-                                frag[lane * 16 + b] = src[s];
+                                const int cb = c0 + b, c = cb / es;  // byte of the K row, channel
+                                const size_t e = d.layout == SHL_MI355X_NHWC ? (((size_t)oc * 3 + ky) * 3 + kx) * d.in_c + c
+                                                                             : (((size_t)oc * d.in_c + c) * 3 + ky) * 3 + kx;
+                                frag[lane * 16 + b] = src[e * es + cb % es];
                             }
                         }
                     }
@@ -314,14 +330,16 @@ bool patch_setup(ConvArgs &a)
     if ((a.out_nchw != 0) != (a.in_nchw != 0)) return false;
     if (!a.in_nchw && a.Co % 16 != 0) return false;
     PatchShape ps;
-    if (!patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps)) return false;
+    const int cbytes = a.C * (PT_F16(a.pt_geom) ? 2 : 1);
+    if (PT_F16(a.pt_geom) && (a.in_nchw || a.sh != 1 || a.sw != 1)) return false;
+    if (!patch_shape(a.N, a.H, a.W, cbytes, a.Co, a.in_nchw != 0, a.pt_geom, &ps)) return false;
     a.pt_rows = ps.rows;
     a.pt_prows = ps.prows;
     a.pt_bufb = ps.bufb;
     a.pt_nitc = ps.nitc;
     a.pt_spr = ps.spr;
     a.pt_ntm = ps.pair_dn ? ps.nt_m / 2 : ps.nt_m;
-    a.pt_pair_in = ps.pair_dn * a.C * a.H * a.W;  // < 2^31: patch_shape
+    a.pt_pair_in = ps.pair_dn * cbytes * a.H * a.W;  // < 2^31: patch_shape
     a.pt_pair_pix = ps.pair_dn * a.H * a.W;
     const bool s2 = PT_S2(a.pt_geom);
     const int HO = s2 ? a.H / 2 : a.H, WO = s2 ? a.W / 2 : a.W;
@@ -333,7 +351,7 @@ bool patch_setup(ConvArgs &a)
     a.pt_rspr = 1.0f / (float)ps.spr;
     a.pt_rntn = 1.0f / (float)ps.nt_n;
     a.pt_rHW = 1.0f / (float)(HO * WO);
-    if (!a.in_nchw && (int64_t)a.M * a.Co >= 20ll << 20) a.pt_geom |= 1 << 22;  // PT_NT: large NHWC outputs past L2
+    if (!a.in_nchw && !PT_F16(a.pt_geom) && (int64_t)a.M * a.Co >= 20ll << 20) a.pt_geom |= 1 << 22;  // PT_NT: large NHWC outputs past L2
     return true;
 }
 
@@ -344,11 +362,12 @@ bool patch_auto(const ConvArgs &a, bool vs_wave)
     static const char *env = getenv("SHL_MI355X_PATCH");
     if (env && env[0] == '0') return false;
     // literal dequantise-relu-requantise epilogues stay with the older kernels (two epilogue builds here)
-    if (a.act != SHL_MI355X_ACT_NONE && !a.act_clamp) return false;
+    const bool f16 = PT_F16(a.pt_geom);
+    if (!f16 && a.act != SHL_MI355X_ACT_NONE && !a.act_clamp) return false;
     ConvArgs t = a;
     if (!patch_setup(t)) return false;
     PatchShape ps;
-    patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
+    patch_shape(a.N, a.H, a.W, a.C * (f16 ? 2 : 1), a.Co, a.in_nchw != 0, a.pt_geom, &ps);
     // fewer tiles than that: the latency-oriented kernels.  Measured over batches 8 .. 256 (tools/dev/batch_sweep.sh): NCHW
     // wins from 96 tiles (the alternative is a re-layout pass around another kernel), NHWC only once most CUs have a
     // tile (64 -> 64 @56 at batch 16 = 128 tiles: 10.6 us against the tile kernel's 8.4)
@@ -377,15 +396,18 @@ int patch_read_trace(unsigned long long *host, int count)
 int launch_conv_igemm_patch(const ConvArgs &a0, hipStream_t s)
 {
     ConvArgs a = a0;
-    if (!patch_setup(a) || (a.act != SHL_MI355X_ACT_NONE && !a.act_clamp)) {
+    const bool f16 = PT_F16(a.pt_geom);
+    if (!patch_setup(a) || (!f16 && a.act != SHL_MI355X_ACT_NONE && !a.act_clamp)) {
         set_error("conv_igemm_patch: the layer does not fit the row-patch kernel");
         return SHL_MI355X_ENOTSUP;
     }
+    if (f16) a.C *= 2, a.in_zp = 0;  // the kernel's a.C is the pixel size in bytes; the padding value is 0.0
     PatchShape ps;
     patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
     const unsigned tiles = (unsigned)((ps.pair_dn ? ps.nt_m / 2 : ps.nt_m) * ps.nt_n);
     g_last_nchw = a.in_nchw != 0;
-    const int rc = a.in_nchw ? patch_launch_nchw(a, tiles, ps.lds, s) : patch_launch_nhwc(a, tiles, ps.lds, s);
+    const int rc = f16 ? patch_launch_nhwc_f16(a, tiles, ps.lds, s)
+                       : (a.in_nchw ? patch_launch_nchw(a, tiles, ps.lds, s) : patch_launch_nhwc(a, tiles, ps.lds, s));
     if (rc != SHL_MI355X_OK) return rc;
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;

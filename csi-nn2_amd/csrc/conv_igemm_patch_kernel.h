@@ -26,6 +26,7 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 #define PT_NW8(g) (((g) >> 20) & 1)  // eight waves (two per SIMD) instead of four
 #define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (stage = (channel group, filter row))
 #define PT_NT(g) (((g) >> 22) & 1)   // NHWC output stored non-temporally (set per launch by patch_setup)
+#define PT_F16(g) (((g) >> 23) & 1)  // binary16 (NHWC, stride 1): the same bytes through v_mfma_f32_32x32x16_f16, fp32 epilogue
 
 // x / d for x < 2^22 (q is within one of the quotient after the float multiply)
 __device__ __forceinline__ uint32_t pt_div(uint32_t x, uint32_t d, float rcp)
@@ -65,9 +66,16 @@ static __device__ unsigned long long g_pt_span[2 * 1024];  // SHL_MI355X_DEBUG=3
 // Wo + 1 + ox) and a block of 32 consecutive outputs reads consecutive slots.  Three K steps x U sub-steps per stage;
 // the top padding row (oy = 0, ky = 0) is the zero point selected at the LDS write (flag in bit 31 of the item's
 // destination), odd input rows are fetched twice (L2).  Weight stream order is the stride-1 one.
-template <int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW, int NBW>
+// kF16: binary16 tensors (NHWC, stride 1, no pair mode).  Everything up to the matrix instruction is byte arithmetic --
+// a.C is the pixel size in BYTES (the host doubles it), KC bytes of a pixel per stage are KC / 2 channels, a 16-byte
+// fragment piece is 8 channels -- and the fragment layouts of v_mfma_f32_32x32x16_f16 and v_mfma_i32_32x32x32_i8 are the
+// same bytes (lane (row, half) = bytes 16 half .. +15 of the row's 32-byte K slab).  Different: fp32 accumulators, K
+// parts summed in fp32 (part order: deterministic), epilogue = + bias, relu / relu6, the reference's f32 -> f16
+// rounding (common.h:finish_f16), two 16-byte stores of 8 channels per lane and block.
+template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW, int NBW>
 __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, const int h)
 {
+    static_assert(!kF16 || (!kNchw && !kPair && !kS2), "binary16: NHWC, stride 1");
     int trace_k = 0;
     auto mark = [&]() {
         if ((a.debug & 32) && blockIdx.x == 0 && threadIdx.x == 0 && trace_k < 64) g_pt_trace[trace_k++] = __builtin_amdgcn_s_memtime();
@@ -174,8 +182,11 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // epilogue tables of the four waves (written after the row tables are dead): 32 multipliers + 32 biases each
     float *const epi_tab = reinterpret_cast<float *>(smem + 2 * bufb + PT_TRASH) + wv * 96;
     // requested now, used at the very end
-    const float t_mult = a.mult[ocb * 32 + frow], t_bias = a.bias[ocb * 32 + frow];
-    const int32_t t_acc = a.acc_init[ocb * 32 + frow];
+    const float t_bias = a.bias[ocb * 32 + frow];
+    float t_mult = 0.0f;
+    if constexpr (!kF16) t_mult = a.mult[ocb * 32 + frow];
+    int32_t t_acc = 0;
+    if constexpr (!kF16) t_acc = a.acc_init[ocb * 32 + frow];
     if constexpr (kS2) {
         // prow_tab[pr] = offset of input row 2 oy (the ky = 1 row) of tile row pr | (oy == 0), or -1 past the last row
         for (int pr = tid; pr < a.pt_prows; pr += NT) {
@@ -472,14 +483,15 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // ---- accumulators start at zero; the plan's acc_init (= -zp_in * sum(w)) is added in the epilogue, once, after
     // the K parts have been summed (initial values held in registers made the allocator split accumulators into
     // VGPRs and spill)
-    v16i acc[NB];
+    using acc_t = typename AccT<!kF16>::type;  // v16i / v16f
+    acc_t acc[NB];
     auto zero_acc = [&]() {
         // 13 MFMAs on zero operands with the constant 0 as C instead of 208 register writes
         v4i z = {0, 0, 0, 0};
         asm volatile("" : "+v"(z));
-        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const acc_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(z, z, zero16, 0, 0, 0);
+        for (int j = 0; j < NB; ++j) acc[j] = mfma<!kF16>(z, z, zero16);
     };
     zero_acc();
 
@@ -571,7 +583,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             if constexpr (kNchw)
                 acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[j], fa[F % FR], acc[j], 0, 0, 0);  // rows = pixels
             else
-                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[F % FR], rb[j], acc[j], 0, 0, 0);  // rows = channels
+                acc[j] = mfma<!kF16>(fa[F % FR], rb[j], acc[j]);  // rows = channels
             __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (kStage && kTwo && F == FW) {
@@ -629,9 +641,9 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         e_rem = m00 - m24(e_n, OHW);
         e_ptr = out + ((int64_t)(m24(e_n, a.Co) + (uint32_t)(ocb * 32 + frow)) * OHW + e_rem);
     } else {
-        e_ptr = out + (int64_t)(pixbase + hb * 32 + frow) * a.Co + (ocb * 32 + fhalf * 16);
+        e_ptr = out + ((int64_t)(pixbase + hb * 32 + frow) * a.Co + (ocb * 32 + fhalf * 16)) * (kF16 ? 2 : 1);
     }
-    const int64_t e_step = kNchw ? 32 : (int64_t)32 * a.Co;
+    const int64_t e_step = kNchw ? 32 : (int64_t)32 * a.Co * (kF16 ? 2 : 1);
     const int64_t e_wrap = (int64_t)(a.Co - 1) * OHW;
     auto advance_on = [&](char *&p, uint32_t &rem) {
         p += e_step;
@@ -654,7 +666,49 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     uint4 sv[NB];
     char *const e_ptr0 = e_ptr;
     const uint32_t e_rem0 = e_rem;
-    auto finalize = [&](int j, const v16i &c) {
+    auto finalize = [&](int j, const acc_t &c) {
+        if constexpr (kF16) {
+            // rows 8 g + 4 fhalf + e of the lane's pixel -> binary16 pairs; after the half swaps a lane holds channels
+            // 16 fhalf .. +15 of its pixel: 32 contiguous bytes of the NHWC output
+            uint2 pk2[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float x[4] = {__fadd_rn(c[4 * g + 0], bi[g].x), __fadd_rn(c[4 * g + 1], bi[g].y), __fadd_rn(c[4 * g + 2], bi[g].z),
+                              __fadd_rn(c[4 * g + 3], bi[g].w)};
+                if (a.scale_out) {
+                    pk2[g].x = (uint32_t)finish_f16(c[4 * g + 0], bi[g].x, a) | (uint32_t)finish_f16(c[4 * g + 1], bi[g].y, a) << 16;
+                    pk2[g].y = (uint32_t)finish_f16(c[4 * g + 2], bi[g].z, a) | (uint32_t)finish_f16(c[4 * g + 3], bi[g].w, a) << 16;
+                } else {
+                    if (a.act != SHL_MI355X_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            x[e] = x[e] > 0.0f ? x[e] : 0.0f;
+                            if (a.act == SHL_MI355X_ACT_RELU6) x[e] = fminf(x[e], 6.0f);
+                        }
+                    }
+                    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+                    uint32_t p0 = pack2_f16_ref(x[0], x[1], lo, hi), p1 = pack2_f16_ref(x[2], x[3], lo, hi);
+                    if (!pack_f16_ref_ok(lo, hi)) {
+                        p0 = float_to_f16_bits_literal_nb(x[0]) | float_to_f16_bits_literal_nb(x[1]) << 16;
+                        p1 = float_to_f16_bits_literal_nb(x[2]) | float_to_f16_bits_literal_nb(x[3]) << 16;
+                    }
+                    pk2[g] = make_uint2(p0, p1);
+                }
+            }
+            const auto a02 = __builtin_amdgcn_permlane32_swap(pk2[0].x, pk2[2].x, false, false);
+            const auto b02 = __builtin_amdgcn_permlane32_swap(pk2[0].y, pk2[2].y, false, false);
+            const auto a13 = __builtin_amdgcn_permlane32_swap(pk2[1].x, pk2[3].x, false, false);
+            const auto b13 = __builtin_amdgcn_permlane32_swap(pk2[1].y, pk2[3].y, false, false);
+            if (a.debug & 2) return;
+            const int pl = (hb + j) * 32 + frow;
+            const int m = pixbase + pl;
+            const int oc = ocb * 32 + fhalf * 16;
+            if (ocb_ok && pl < RW && m < a.M && oc < a.Co) {
+                reinterpret_cast<uint4 *>(e_ptr)[0] = make_uint4(a02[0], b02[0], a02[1], b02[1]);  // channels +0 .. +7
+                reinterpret_cast<uint4 *>(e_ptr)[1] = make_uint4(a13[0], b13[0], a13[1], b13[1]);  // channels +8 .. +15
+            }
+            return;
+        } else {
         uint32_t pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -692,6 +746,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             sv[j] = v;
             slow_mask |= __builtin_amdgcn_ballot_w64(!fast) != 0 ? 1u << j : 0u;
         }
+        }  // !kF16
     };
     // the general NCHW store of block j (second pass): dst / rem = the lane's first output of the block.  Runs for the
     // last block of EVERY tile whose pixel count is not a multiple of 32 (392 = 14 x 28 = 7 x 56) on the waves that finish
@@ -786,8 +841,9 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                 if (j % KP != kp) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const v4i v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                        *reinterpret_cast<v4i *>(mine + ((j - rb) * 4 + g) * 1024 + lane * 16) = v;
+                        using e4_t = std::conditional_t<kF16, float4, v4i>;
+                        const e4_t v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                        *reinterpret_cast<e4_t *>(mine + ((j - rb) * 4 + g) * 1024 + lane * 16) = v;
                     }
                 }
             });
@@ -795,18 +851,26 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             static_for<re - rb>([&](auto jc) {
                 constexpr int j = rb + decltype(jc)::value;
                 if (j % KP == kp) {
-                    v16i c = acc[j];
+                    acc_t c = acc[j];
 #pragma unroll
                     for (int o = 1; o < KP; ++o) {
                         const int other = wave + ((kp + o) % KP - kp) * (oldmap ? 2 : 1);  // same role and half, another K part
                         const char *src = smem + other * (CH * 4096) + (j - rb) * 4096 + lane * 16;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const v4i v = *reinterpret_cast<const v4i *>(src + g * 1024);
-                            c[4 * g] += v[0];
-                            c[4 * g + 1] += v[1];
-                            c[4 * g + 2] += v[2];
-                            c[4 * g + 3] += v[3];
+                            if constexpr (kF16) {
+                                const float4 v = *reinterpret_cast<const float4 *>(src + g * 1024);
+                                c[4 * g] += v.x;
+                                c[4 * g + 1] += v.y;
+                                c[4 * g + 2] += v.z;
+                                c[4 * g + 3] += v.w;
+                            } else {
+                                const v4i v = *reinterpret_cast<const v4i *>(src + g * 1024);
+                                c[4 * g] += v[0];
+                                c[4 * g + 1] += v[1];
+                                c[4 * g + 2] += v[2];
+                                c[4 * g + 3] += v[3];
+                            }
                         }
                     }
                     finalize(j, c);
@@ -825,67 +889,70 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW>
+template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_patch_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (NW == 4) {
-        patch_body<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 4, PT_NB>(a, smem, 0);
+        patch_body<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 4, PT_NB>(a, smem, 0);
     } else {
         // the two halves are two straight-line bodies (7 and 6 pixel blocks) behind ONE wave-uniform branch; both pass
         // the same sequence of workgroup barriers
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         if (((((a.debug & 64) != 0) != (kNchw && (kPair || KP == 4))) ? w & 1 : w >> 2) == 0)
-            patch_body<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 7>(a, smem, 0);
+            patch_body<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 7>(a, smem, 0);
         else
-            patch_body<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 6>(a, smem, 1);
+            patch_body<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 6>(a, smem, 1);
     }
 }
 
-template <int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW>
+template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW>
 static void patch_launch_nw(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
-    auto kernel = conv_igemm_patch_kernel<EPI, kNchw, kPair, kS2, KC, PG, OB, KP, NW>;
+    auto kernel = conv_igemm_patch_kernel<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, NW>;
     static LdsOptIn opted;
     lds_opt_in(opted, reinterpret_cast<const void *>(kernel), PT_LDS_MAX);
     hipLaunchKernelGGL(kernel, dim3(tiles), dim3(NW * 64), lds, s, a);
 }
 
-template <int EPI, bool kNchw, int KC, int PG, int OB, int KP>
+template <bool kF16, int EPI, bool kNchw, int KC, int PG, int OB, int KP>
 static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
-    if (PT_S2(a.pt_geom)) {
-        if constexpr (KC == 64 && KP <= 2) patch_launch_nw<EPI, kNchw, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
+    if constexpr (kF16) {  // stride 1, no pair mode, eight waves (the host sets the bit: patch_choose_geom)
+        patch_launch_nw<true, 0, false, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+    } else if (PT_S2(a.pt_geom)) {
+        if constexpr (KC == 64 && KP <= 2) patch_launch_nw<false, EPI, kNchw, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
     } else if (PT_NW8(a.pt_geom)) {
         if constexpr (KP == 1) {  // pair mode exists for eight waves, one K part
-            if (a.pt_pair_in) return patch_launch_nw<EPI, kNchw, true, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+            if (a.pt_pair_in) return patch_launch_nw<false, EPI, kNchw, true, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
         }
-        patch_launch_nw<EPI, kNchw, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+        patch_launch_nw<false, EPI, kNchw, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
     } else {
-        patch_launch_nw<EPI, kNchw, false, false, KC, PG, OB, KP, 4>(a, tiles, lds, s);
+        patch_launch_nw<false, EPI, kNchw, false, false, KC, PG, OB, KP, 4>(a, tiles, lds, s);
     }
 }
 
-template <bool kNchw, int KC, int PG, int OB, int KP>
+template <bool kF16, bool kNchw, int KC, int PG, int OB, int KP>
 static void patch_launch_geom(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
     if constexpr ((KC / 32) % KP == 0) {
-        if (a.div_exact != 0) patch_launch_one<3, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
-        else patch_launch_one<0, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
+        if constexpr (kF16) patch_launch_one<true, 0, false, KC, PG, OB, KP>(a, tiles, lds, s);
+        else if (a.div_exact != 0) patch_launch_one<false, 3, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
+        else patch_launch_one<false, 0, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
     }
 }
 
 // every geometry of one layout (one translation unit per layout: the 40 kernels of a layout take ~2 minutes)
-template <bool kNchw>
+template <bool kNchw, bool kF16 = false>
 static int patch_launch_layout(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
     const int kc = PT_KC(a.pt_geom), key = PT_PG(a.pt_geom) * 100 + PT_OB(a.pt_geom) * 10 + PT_KP(a.pt_geom);
 #define SHL_PT(KCV)                                                                \
     switch (key) {                                                                 \
-        case 141: patch_launch_geom<kNchw, KCV, 1, 4, 1>(a, tiles, lds, s); break; \
-        case 221: patch_launch_geom<kNchw, KCV, 2, 2, 1>(a, tiles, lds, s); break; \
-        case 122: patch_launch_geom<kNchw, KCV, 1, 2, 2>(a, tiles, lds, s); break; \
-        case 114: patch_launch_geom<kNchw, KCV, 1, 1, 4>(a, tiles, lds, s); break; \
+        case 141: patch_launch_geom<kF16, kNchw, KCV, 1, 4, 1>(a, tiles, lds, s); break; \
+        case 221: patch_launch_geom<kF16, kNchw, KCV, 2, 2, 1>(a, tiles, lds, s); break; \
+        case 122: patch_launch_geom<kF16, kNchw, KCV, 1, 2, 2>(a, tiles, lds, s); break; \
+        case 114: patch_launch_geom<kF16, kNchw, KCV, 1, 1, 4>(a, tiles, lds, s); break; \
         default: return SHL_MI355X_ENOTSUP;                                        \
     }
     if (kc == 128) {
@@ -909,6 +976,7 @@ static int patch_read_trace_layout(unsigned long long *host, int count)
 // one entry point per layout, defined in its translation unit
 int patch_launch_nhwc(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s);
 int patch_launch_nchw(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s);
+int patch_launch_nhwc_f16(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s);  // conv_igemm_patch_f16.hip
 int patch_read_trace_nhwc(unsigned long long *host, int count);
 int patch_read_trace_nchw(unsigned long long *host, int count);
 

@@ -202,7 +202,7 @@ static const char *family_kernel_name(const char *v, bool i8)
     if (!strcmp(v, "tile")) return i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
     if (!strcmp(v, "pp")) return i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
     if (!strcmp(v, "pc")) return i8 ? "conv_igemm_pc_i8_mfma32x32x32" : "conv_igemm_pc_f16_mfma32x32x16";
-    return "conv_igemm_patch_i8_mfma32x32x32";
+    return i8 ? "conv_igemm_patch_i8_mfma32x32x32" : "conv_igemm_patch_f16_mfma32x32x16";
 }
 
 struct TuneResult {
@@ -385,6 +385,11 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             if (!strcmp(igemm_pick_name(t, es), "patch")) v = "patch";
             probe.in_nchw = 0;
         }
+        if (!v && es == 2 && d.layout == SHL_MI355X_NCHW && probe.w_patch) {  // binary16 NCHW: the row-patch kernel on the NHWC view (conv_forward)
+            ConvArgs t = probe;
+            t.out_nchw = 0;
+            if (!strcmp(igemm_pick_name(t, es), "patch")) v = "patch";
+        }
         if (!v) v = igemm_pick_name(probe, es);
         if (!strcmp(v, "wave"))
             p->kernel_name = i8 ? "conv_igemm_wave_i8_mfma32x32x32" : "conv_igemm_wave_f16_mfma32x32x16";
@@ -393,7 +398,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         else if (!strcmp(v, "gemv"))
             p->kernel_name = i8 ? "conv_gemv_i8_dot4" : "conv_gemv_f16_fma";
         else if (!strcmp(v, "patch"))
-            p->kernel_name = "conv_igemm_patch_i8_mfma32x32x32";
+            p->kernel_name = i8 ? "conv_igemm_patch_i8_mfma32x32x32" : "conv_igemm_patch_f16_mfma32x32x16";
         else if (!strcmp(v, "pp"))
             p->kernel_name = i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
         else if (!strcmp(v, "res")) {
@@ -836,7 +841,9 @@ static int conv_forward_impl(const shl_mi355x_conv_plan *plan, const void *input
             a.in = plan->scratch_in;
             // the tile kernel's epilogue stores NCHW itself; planes whose byte size is not a multiple of
             // 4 (7x7 int8) would fall to element stores there and are cheaper through the re-layout pass
-            if (igemm_fuses_nchw_out(a, es) && ((a.Ho * a.Wo * es) & 3) == 0) {
+            // (binary16 3x3: when the row-patch kernel takes the NHWC view it is worth the second re-layout pass)
+            const bool f16_patch = es == 2 && a.w_patch && !strcmp(igemm_pick_name(a, es), "patch");
+            if (!f16_patch && igemm_fuses_nchw_out(a, es) && ((a.Ho * a.Wo * es) & 3) == 0) {
                 a.out_nchw = 1;
                 return launch_conv_igemm(a, d.dtype, SHL_MI355X_NHWC, s);
             }

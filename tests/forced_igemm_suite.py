@@ -67,7 +67,7 @@ SHAPES = [
     dict(c=128, co=96, h=14, w=14, n=8, act=1),
     dict(c=64, co=32, h=7, w=7, n=32),
 ]
-F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19]
+F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19, 23, 24, 25, 26, 27, 28, 29]  # from 23: the row-patch shapes (binary16: NHWC native)
 
 EXPECT = os.environ.get("SHL_EXPECT_KERNEL", "")          # the forced kernel family ...
 FALLBACK = os.environ.get("SHL_EXPECT_FALLBACK", "")      # ... or, for shapes it does not take, this one
