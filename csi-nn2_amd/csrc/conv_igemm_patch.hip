@@ -233,8 +233,8 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     const bool s2 = d.stride_h == 2;
     const bool f16 = d.dtype == SHL_MI355X_F16;
     const int cbytes = d.in_c * pt_esize(d);  // the kernel's "channels" are the bytes of a pixel
-    const int kc = (cbytes % 128 == 0 && !s2) ? 128 : 64;  // stride 2: two 64-channel patches of one input row per tile row fit LDS
-    const int u = kc / 32;
+    int kc = (cbytes % 128 == 0 && !s2) ? 128 : 64;  // stride 2: two 64-channel patches of one input row per tile row fit LDS
+    int u = kc / 32;
     const bool nchw = d.layout == SHL_MI355X_NCHW && !f16;  // binary16 NCHW layers: the NHWC view
     static const char *s2_env = getenv("SHL_MI355X_PATCH_S2");  // "0": no stride-2 form (A/B)
     if (s2 && s2_env && s2_env[0] == '0') return 0;
@@ -257,6 +257,12 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     const int ocblks = (d.out_c + 31) / 32;
     int best = 0;
     double best_cost = 0;
+    // binary16: a pixel is twice the bytes, and a stage's patch is bounded by what one round of staging items moves
+    // (64 KB): with 128-byte stages 64 channels @56 get 3 rows per pixel group (168 of 416 pixels, 1 195 tiles); with
+    // 64-byte stages 7 rows (512 tiles, two stages).  Both stage sizes are costed; ties keep the larger.
+    for (int kc_try = kc; kc_try >= 64; kc_try -= 64) {
+    if (kc_try != kc && !f16) break;
+    kc = kc_try, u = kc / 32;
     for (const auto &c : cand) {
         const int pg = c[0], ob = c[1], kp = c[2];
         if (u % kp != 0) continue;
@@ -279,6 +285,7 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         if (dbg) fprintf(stderr, "patch geom %d,%d,%d nw%d%s: rows %d prows %d tiles %d x %d lds %d nitc %d pair %d cost %.3f\n", pg, ob, kp, PT_NW8(g) ? 8 : 4,
                          s2 ? " s2" : "", ps.rows, ps.prows, ps.nt_m, ps.nt_n, ps.lds, ps.nitc, ps.pair_dn, total);
         if (!best || total < best_cost - 1e-9) best = g, best_cost = total;
+    }
     }
     return best;
 }
@@ -372,14 +379,16 @@ bool patch_auto(const ConvArgs &a, bool vs_wave)
     // wins from 96 tiles (the alternative is a re-layout pass around another kernel), NHWC only once most CUs have a
     // tile (64 -> 64 @56 at batch 16 = 128 tiles: 10.6 us against the tile kernel's 8.4)
     const bool s2 = PT_S2(a.pt_geom);
-    if ((int64_t)ps.nt_m * ps.nt_n < ((s2 || (!a.in_nchw && !vs_wave)) ? 192 : 96)) return false;
+    // (binary16: the block-tile kernels are further behind -- 256 -> 256 @14 at batch 8 26 us against 33, profiles/r04_f16_patch_kbench.txt)
+    if ((int64_t)ps.nt_m * ps.nt_n < ((s2 || (!a.in_nchw && !vs_wave && !f16)) ? 192 : 96)) return false;
     // the stride-2 form beyond 256 input channels is >= 24 stages of three K steps: 512 -> 512 @14 at batch 256 takes 94 us
     // against 52 through the re-layout pass + producer / consumer kernel
     if (s2 && a.C > 256) return false;
     // NHWC with four K parts (512 channels @7 at batch 128): nine K steps per stage and the exchange of partial sums
     // leave it behind the producer / consumer kernel (25.4 vs 22.4 us); NCHW takes it anyway -- the alternative there
     // is two re-layout passes around that kernel (39 vs 47 us)
-    if (!a.in_nchw && PT_KP(a.pt_geom) == 4 && !vs_wave) return false;
+    // (binary16: 39 us against 68 through the tile kernel)
+    if (!a.in_nchw && PT_KP(a.pt_geom) == 4 && !vs_wave && !f16) return false;
     return true;
 }
 
