@@ -531,6 +531,7 @@ def main():
             for tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, chained_x, steps_x in (
                     ("configs[2]", "resnet50 3x3 set int8 NCHW batch 128", wl.RESNET50_3X3, 128, "int8", "NCHW", "mfma", False, 20),
                     ("configs[2] (NHWC view)", "resnet50 3x3 set int8 NHWC batch 128", wl.RESNET50_3X3, 128, "int8", "NHWC", "mfma", False, 20),
+                    ("configs[2] (binary16 NHWC view)", "resnet50 3x3 set binary16 NHWC batch 128", wl.RESNET50_3X3, 128, "f16", "NHWC", "mfma", False, 10),
                     ("configs[3]", "mobilenetv1 fp16 NCHW batch 1 (c906_mobilenetv1_f16 shapes)", wl.MOBILENETV1, 1, "f16", "NCHW", "hbm", True, 50),
                     ("configs[1] (throughput view)", "mobilenetv1 int8 NHWC batch 128, every layer its own launch", wl.MOBILENETV1, 128,
                      "int8", "NHWC", "hbm", True, 20)):
