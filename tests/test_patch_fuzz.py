@@ -7,6 +7,8 @@ stride-2 form (even planes), activations, per-channel and converter scales.  Run
 forced (SHL_MI355X_IGEMM=patch; the switch is read once per process) and, in a second one, with pair mode forced
 wherever the tiles pair up.  SHL_FUZZ_N=<count> draws more (default 40 per process), SHL_FUZZ_BYTES=<input bytes> larger
 batches (default 600 000; 300 cases at the default and 120 at 8 MB were run once in round 3).
+A third process draws binary16 shapes (SHL_FUZZ_DTYPE=f16: channel counts that are multiples of 32, both layouts -- NCHW
+layers meet the kernel on the NHWC view --, stride 1, relu / none) and compares at 1e-3 relative with the oracle.
 """
 import os
 import subprocess
@@ -35,8 +37,23 @@ def draw(i):
                 act=int(rng.choice([0, 1, 2])), per_channel=bool(rng.random() < 0.4), exact=bool(rng.random() < 0.6))
 
 
+F16 = os.environ.get("SHL_FUZZ_DTYPE") == "f16"
+
+
+def draw_f16(i):
+    rng = np.random.default_rng(88000 + i)
+    layout = "NCHW" if rng.random() < 0.35 else "NHWC"
+    c = int(rng.choice([32, 64, 64, 96, 128, 160, 256]))
+    co = int(rng.integers(1, 13)) * 16
+    h, w = int(rng.integers(2, 41)), int(rng.integers(2, 61))
+    budget = int(os.environ.get("SHL_FUZZ_BYTES", "600000"))
+    n = int(max(1, min(rng.integers(1, 48 * max(1, budget // 600000)), budget // (h * w * c * 2))))
+    return dict(layout=layout, c=c, co=co, h=h, w=w, n=n, act=int(rng.choice([0, 1])))
+
+
 if INNER:
     import cases
+    import golden_util
     from cases import pkg
 
     @pytest.fixture(scope="module")
@@ -53,14 +70,17 @@ if INNER:
     @pytest.mark.parametrize("i", range(N_CASES))
     def test_random_shape_is_bit_exact(gpu, i):
         fe, hip, opt, dev = gpu
-        kw = draw(i)
+        kw = draw_f16(i) if F16 else draw(i)
         layout = cases.NCHW if kw.pop("layout") == "NCHW" else cases.NHWC
-        case = cases.make_case(77000 + i, layout=layout, **kw)
+        case = cases.make_case(77000 + i, layout=layout, **(dict(kw, dtype="f16") if F16 else kw))
         kept = []
         got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
         name = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
         assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
         SEEN["patch"] += "patch" in name
+        if F16:
+            golden_util.compare_f16_tol(got, cases.oracle_run(case, "f16"), "case %d %r via %s" % (i, kw, name))
+            return
         count, worst = cases.mismatch_report(got, cases.oracle_run(case, "exact"))
         assert count == 0, "case %d %r via %s: %d mismatches (max %d)" % (i, draw(i), name, count, worst)
 
@@ -69,7 +89,8 @@ if INNER:
         assert SEEN["patch"] >= N_CASES * 2 // 3, SEEN
 else:
     @pytest.mark.gpu
-    @pytest.mark.parametrize("extra", [{}, {"SHL_MI355X_PATCH_PAIR": "1"}], ids=["forced", "forced-pair-mode"])
+    @pytest.mark.parametrize("extra", [{}, {"SHL_MI355X_PATCH_PAIR": "1"}, {"SHL_FUZZ_DTYPE": "f16"}],
+                             ids=["forced", "forced-pair-mode", "forced-binary16"])
     def test_patch_kernel_random_shapes(extra):
         env = {k: v for k, v in os.environ.items() if not k.startswith("SHL_MI355X_")}
         env.update(SHL_MI355X_IGEMM="patch", SHL_FUZZ_INNER="1", **extra)
