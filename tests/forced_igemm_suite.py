@@ -129,6 +129,22 @@ def test_forced_variant_fp16_within_tolerance(gpu, idx, layout):
     golden_util.compare_f16_tol(got, cases.oracle_run(case, "f16"), "fp16 shape %d %s via %s" % (idx, layout, kname))
 
 
+@pytest.mark.parametrize("scale,act", [(0.5, 2), (0.37, 1), (1.0, 2)])
+@pytest.mark.parametrize("idx", [0, 16, 24])
+def test_forced_variant_fp16_output_scale_and_relu6(gpu, idx, scale, act):
+    """binary16 with an output scale != 1 and a fused relu / relu6 (the literal epilogue of common.h:finish_f16: the clamp
+    acts on the dequantised stored value) through the forced family -- the row-patch kernel's own epilogue included"""
+    kw = dict(SHAPES[idx])
+    kw.pop("per_channel", None)
+    kw["act"] = act
+    case = cases.make_case(8700 + idx, dtype="f16", layout=NHWC, **kw)
+    case["out_scale"] = scale
+    case["input"] = (case["input"].astype(np.float32) * 3).astype(np.float16)   # reach beyond 6
+    got, kname = _run(gpu, case)
+    _note(kname)
+    golden_util.compare_f16_tol(got, cases.oracle_run(case, "f16"), "fp16 shape %d scale %g act %d via %s" % (idx, scale, act, kname))
+
+
 def test_zz_the_forced_family_was_exercised():
     """runs last (file order): the forced kernel family must have taken its share of the cases"""
     if EXPECT:
