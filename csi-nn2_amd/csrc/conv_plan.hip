@@ -426,6 +426,12 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     } else if (algo == SHL_MI355X_ALGO_STEM) {
         w_bytes = stem_weight_bytes(d);
         p->kernel_name = "conv_stem_i8_dot4";
+        {  // the plan's batch decides the name (conv_stem.hip:launch_conv_stem picks per call)
+            ConvArgs t = {};
+            t.N = d.batch, t.H = d.in_h, t.W = d.in_w, t.C = d.in_c, t.Co = d.out_c, t.dh = d.dilation_h, t.dw = d.dilation_w;
+            t.M = (int32_t)((int64_t)d.batch * d.out_h * d.out_w);
+            if (stem_mfma_pick(t)) p->kernel_name = "conv_stem_i8_mfma32x32x32";
+        }
     } else if (algo == SHL_MI355X_ALGO_DW) {
         p->kernel_name = d.dtype == SHL_MI355X_I8 ? "dwconv_nhwc_i8" : "dwconv_nhwc_f16";
         if (d.layout == SHL_MI355X_NCHW) p->kernel_name = d.dtype == SHL_MI355X_I8 ? "dwconv3x3_nchw_i8" : "dwconv3x3_nchw_f16";

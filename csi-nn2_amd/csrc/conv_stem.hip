@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_stem_i8_mfma_kernel(ConvArgs a, int 
 }
 
 // the MFMA form: bandwidth-bound sizes, whole 16-channel pieces, index ranges of the float divisions / buffer offsets
-static bool stem_mfma_pick(const ConvArgs &a)
+bool stem_mfma_pick(const ConvArgs &a)
 {
     static const char *env = getenv("SHL_MI355X_STEM_MFMA");  // "0" never, "1" whenever the shape allows (A/B, tests)
     if (env && env[0] == '0') return false;

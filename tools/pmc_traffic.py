@@ -37,6 +37,7 @@ FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kern
     ("conv_igemm_tile_kernel<false", "conv_igemm_tile_f16_mfma32x32x16"),
     ("conv_igemm_regs_kernel<true", "conv_igemm_regs_i8_mfma32x32x32"),
     ("conv_igemm_regs_kernel<false", "conv_igemm_regs_f16_mfma32x32x16"),
+    ("conv_stem_i8_mfma_kernel", "conv_stem_i8_mfma32x32x32"),
     ("conv_stem_i8_kernel", "conv_stem_i8_dot4"),
     ("dwconv_nhwc_kernel<true", "dwconv_nhwc_i8"),
     ("dwconv3x3_i8_dot4_kernel", "dwconv_nhwc_i8"),
