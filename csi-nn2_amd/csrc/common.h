@@ -485,6 +485,9 @@ int launch_dwconv_nchw(const ConvArgs &a, int dtype, hipStream_t s);
 // pointwise 1x1 + the depthwise 3x3 that consumes it in one launch (pwdw_fused.hip)
 bool pwdw_fusable(const ConvArgs &pw, const ConvArgs &dw, int pw_is_igemm, int dw_dot4_packed);
 int launch_pwdw_fused(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
+// binary16 NCHW: the 3-channel stem + the depthwise 3x3 consuming it in one launch (stemdw_f16_nchw.hip)
+bool stemdw_f16_nchw_fusable(const ConvArgs &stem, const ConvArgs &dw);
+int launch_stemdw_f16_nchw(const ConvArgs &stem, const ConvArgs &dw, hipStream_t s);
 bool stem_mfma_pick(const ConvArgs &a);  // conv_stem.hip: the matrix-core form runs this problem (plan naming)
 // stem 3x3 (3 -> 32) + the depthwise 3x3 consuming it in one launch (stemdw_fused.hip)
 bool pwdw_f16_nchw_fusable(const ConvArgs &pw, const ConvArgs &dw);  // binary16 NCHW form (pwdw_f16_nchw.hip)

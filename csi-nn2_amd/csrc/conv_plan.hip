@@ -892,14 +892,17 @@ int shl_mi355x_debug_trace(uint64_t *host, int32_t count)
 }
 
 /* which fused kernel runs the pair: 0 none, 1 latency form (pwdw_fused.hip: small grids), 3 stem + depthwise
- * (stemdw_fused.hip), 4 binary16 NCHW (pwdw_f16_nchw.hip).  (2 was the int8 bandwidth form for large batches: it only
+ * (stemdw_fused.hip), 4 binary16 NCHW (pwdw_f16_nchw.hip), 5 binary16 NCHW stem + depthwise (stemdw_f16_nchw.hip).  (2 was the int8 bandwidth form for large batches: it only
  * broke even with the two stand-alone kernels, csrc/parked/README.md; large batches keep one launch per layer.) */
 static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, const ConvArgs &a,
                            const ConvArgs &b)
 {
     const int pw_igemm = pw->algo == SHL_MI355X_ALGO_IGEMM, dw_dot4 = dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12;
-    if (pw->desc.dtype == SHL_MI355X_F16)  // binary16 NCHW (pwdw_f16_nchw.hip)
-        return pw_igemm && dw->algo == SHL_MI355X_ALGO_DW && pwdw_f16_nchw_fusable(a, b) ? 4 : 0;
+    if (pw->desc.dtype == SHL_MI355X_F16) {  // binary16 NCHW (pwdw_f16_nchw.hip, stemdw_f16_nchw.hip)
+        if (dw->algo != SHL_MI355X_ALGO_DW) return 0;
+        if (pw_igemm) return pwdw_f16_nchw_fusable(a, b) ? 4 : 0;
+        return pw->algo == SHL_MI355X_ALGO_DIRECT && stemdw_f16_nchw_fusable(a, b) ? 5 : 0;
+    }
     if (pw->algo == SHL_MI355X_ALGO_STEM) return dw_dot4 && stemdw_fusable(a, b) ? 3 : 0;  // stem + depthwise
     return pwdw_fusable(a, b, pw_igemm, dw_dot4) ? 1 : 0;
 }
@@ -940,6 +943,7 @@ int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     if (rc != SHL_MI355X_OK) return rc;
     if (b.M == 0) return SHL_MI355X_OK;
     switch (pwdw_kernel_for(pw, dw, a, b)) {
+        case 5: return launch_stemdw_f16_nchw(a, b, (hipStream_t)stream);
         case 4: return launch_pwdw_f16_nchw(a, b, (hipStream_t)stream);
         case 3: return launch_stemdw_fused(a, b, (hipStream_t)stream);
         default: return launch_pwdw_fused(a, b, (hipStream_t)stream);

@@ -218,7 +218,7 @@ class LayerChain:
         if len(idx) == 1:
             return self.entries[idx[0]]["kernel_name"]
         if self.dtype != "int8":
-            return "pwdw_f16_nchw"
+            return "pwdw_f16_nchw" if "igemm" in self.entries[idx[0]]["kernel_name"] or "1x1" in self.entries[idx[0]]["kernel_name"] else "stemdw_f16_nchw"
         return "stemdw_fused_i8" if self.entries[idx[0]]["kernel_name"].startswith("conv_stem") else "pwdw_fused_i8"
 
     def unit_name(self, u):

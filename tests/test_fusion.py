@@ -144,6 +144,46 @@ def test_stem_depthwise_pair_equals_the_two_kernels_and_the_oracle(gpu, i):
         opt.shl_mi355x_release_params(p)
 
 
+F16_STEM_PAIRS = [dict(hw=32, dw_stride=1), dict(hw=45, dw_stride=2, n=2, co=24), dict(hw=224, dw_stride=1, relu=(1, 0)),
+                  dict(hw=19, dw_stride=1, co=16, stem_stride=1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(F16_STEM_PAIRS)), ids=["hw%d_s%d" % (p["hw"], p["dw_stride"]) for p in F16_STEM_PAIRS])
+def test_fp16_nchw_stem_depthwise_pair_equals_the_two_kernels(gpu, i):
+    """binary16 NCHW: conv 3x3 (3 -> Cout <= 32) + the depthwise layer consuming it (csrc/stemdw_f16_nchw.hip) -- the same
+    operations in the same order on the same rounded intermediate: exactly the bytes of the two stand-alone launches,
+    which are within 1e-3 of the oracle's two-layer replay"""
+    fe, hip, opt = gpu
+    kw = F16_STEM_PAIRS[i]
+    n, relu, co, ss = kw.get("n", 1), kw.get("relu", (1, 1)), kw.get("co", 32), kw.get("stem_stride", 2)
+    st = cases.make_case(900 + i, n=n, h=kw["hw"], w=kw["hw"], c=3, co=co, stride=(ss, ss), act=relu[0], dtype="f16", layout=cases.NCHW)
+    dw = cases.make_case(950 + i, n=n, h=st["ho"], w=st["wo"], c=co, depthwise=True, stride=(kw["dw_stride"],) * 2,
+                         act=relu[1], dtype="f16", layout=cases.NCHW)
+    dev = cases.HipDevice(hip)
+    keep = []
+    mid = cases.csinn_run(fe, pkg.API_MI355X, st, device=dev, keep_params=keep)
+    dw["input"] = mid
+    want = cases.csinn_run(fe, pkg.API_MI355X, dw, device=dev, keep_params=keep)
+    golden_util = __import__("golden_util")
+    golden_util.compare_f16_tol(mid, cases.oracle_run(st, "f16"), "stand-alone stem vs oracle")
+    golden_util.compare_f16_tol(want, cases.oracle_run(dw, "f16"), "stand-alone depthwise vs oracle (fed the GPU's intermediate)")
+    plan_st, plan_dw = (opt.shl_mi355x_registry_get(p) for p, _ in keep)
+    assert hip.shl_mi355x_pwdw_fusable(plan_st, plan_dw, n) == 1
+    d_in = dev.alloc(st["input"].nbytes)
+    dev.upload(d_in, st["input"])
+    d_out = dev.alloc(want.nbytes)
+    hip.shl_mi355x_memset(d_out, 0x55, want.nbytes, None)
+    pkg.check(hip.shl_mi355x_pwdw_forward(plan_st, plan_dw, d_in, d_out, n, None), hip, "pwdw_forward(f16 stem)")
+    got = dev.download(d_out, want.shape, np.float16)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), "fused vs stand-alone: %d of %d binary16 words differ" % (
+        int((got.view(np.uint16) != want.view(np.uint16)).sum()), got.size)
+    dev.free(d_in)
+    dev.free(d_out)
+    for p, _ in keep:
+        opt.shl_mi355x_release_params(p)
+
+
 @pytest.mark.gpu
 def test_pairs_that_do_not_qualify_are_refused(gpu):
     fe, hip, opt = gpu

@@ -43,6 +43,7 @@ FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kern
     ("dwconv3x3_i8_dot4_kernel", "dwconv_nhwc_i8"),
     ("dwpw_fused_kernel", "dwpw_fused_i8"),
     ("pwdw_f16_nchw_kernel", "pwdw_f16_nchw"),
+    ("stemdw_f16_nchw_kernel", "stemdw_f16_nchw"),
     ("conv_group_direct_kernel", "conv_group_direct"),
     ("pwdw_fused_kernel", "pwdw_fused_i8"),
     ("stemdw_fused_kernel", "stemdw_fused_i8"),
