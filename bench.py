@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X CSI-NN2 backend.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (no launcher: N > 1 spawns N ranks itself, rank r on GPU r)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks from the launcher)
 
 Workload (BASELINE.json configs[1]): MobileNetV1 int8 NHWC, batch 1 per
 GPU -- the 28 convolution layers of example/c906_mobilenetv1_f16.c (conv1, 13 x (depthwise 3x3 +
@@ -390,10 +390,59 @@ def emit(result):
     print(json.dumps(result), flush=True)
 
 
+def launch_plan(gpus, environ):
+    """What `bench.py --gpus N` does about ranks.  "run": this process IS a rank (N = 1, or an external launcher --
+    torch.distributed.run -- already set RANK / WORLD_SIZE); ("spawn", N): no launcher in sight, so this process becomes
+    one: N children, one rank per GPU.  A WORLD_SIZE that contradicts --gpus is an error, not something to guess about."""
+    ws = environ.get("WORLD_SIZE")
+    if ws is not None and "RANK" in environ:
+        if int(ws) != gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (gpus, ws))
+        return ("run", int(ws))
+    if gpus <= 1:
+        return ("run", 1)
+    return ("spawn", gpus)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command line with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would export), rank r on GPU r.  Rank 0
+    inherits stdout (its JSON line stays the last line written); the other ranks' stdout goes to stderr.  Any rank
+    failing fails the run: its siblings are terminated by PID and the exit code is the first non-zero one."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
+    mode, nranks = launch_plan(args.gpus, os.environ)
+    if mode == "spawn":
+        return spawn_ranks(nranks)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -452,6 +501,12 @@ def main():
         par.assert_replicas_agree(chain, torch, dist, hip)
     elif sharded:
         bcast = par.broadcast_weights_one_rank(chain, hip, opt)  # the same C entry points with a communicator of one
+
+    if world > 1 and not single_dev:
+        # N ranks must mean N devices and an RCCL communicator of N: anything else is not the run that was asked for
+        got_dev, got_nr = par.LAST_BROADCAST.get("distinct_devices"), par.LAST_BROADCAST.get("rccl_nranks")
+        if got_dev != world or got_nr != world:
+            raise SystemExit("bench.py --gpus %d: %s distinct devices, RCCL communicator of %s ranks (%s)" % (world, got_dev, got_nr, bcast))
 
     stream = hip.shl_mi355x_stream_create()
     chain.capture(stream)

@@ -190,3 +190,50 @@ def test_bench_shards_a_total_batch_over_two_ranks_on_one_device():
     assert len(ids) == 2 and ids[0] == ids[1] and ids[0] and line["config"]["distinct_devices"] == 1
     assert "share device " + ids[0] in line["config"]["parallelism"], line["config"]["parallelism"]
     assert line["config"]["rccl_nranks"] is None
+
+
+def test_bench_gpus_flag_decides_between_running_and_spawning():
+    """`python bench.py --gpus N` with no launcher must start N ranks itself (the flag was parsed and
+    ignored); under torch.distributed.run (RANK / WORLD_SIZE exported) the process is a rank and must not spawn again;
+    a WORLD_SIZE that contradicts --gpus is refused."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(cases.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launch_plan(1, {}) == ("run", 1)
+    assert bench.launch_plan(8, {}) == ("spawn", 8)
+    assert bench.launch_plan(2, {"WORLD_SIZE": "2"}) == ("spawn", 2)  # a stray WORLD_SIZE without RANK is no launcher
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}) == ("run", 8)
+    assert bench.launch_plan(1, {"WORLD_SIZE": "1", "RANK": "0"}) == ("run", 1)
+    with pytest.raises(SystemExit):
+        bench.launch_plan(8, {"WORLD_SIZE": "2", "RANK": "0"})
+
+
+def test_bench_spawned_ranks_failure_is_loud():
+    """a rank that dies takes the run with it: without a GPU every spawned rank exits non-zero, and so must the parent
+    (and quickly -- no rank may be left waiting on a rendezvous)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = "-1"
+    env["ROCR_VISIBLE_DEVICES"] = "-1"
+    res = subprocess.run([sys.executable, os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-configs"], capture_output=True, text=True, timeout=300, env=env, cwd=cases.ROOT)
+    assert res.returncode != 0
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_spawns_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` -- the exact form the driver uses for N = 1 -- runs TWO ranks (here both on the box's one
+    GPU, SHL_BENCH_SINGLE_DEVICE) and reports n_gpus == 2; rank 0's JSON line is the last line of stdout."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["SHL_BENCH_SINGLE_DEVICE"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--windows", "2",
+                          "--no-cpu-baseline", "--no-configs"], capture_output=True, text=True, timeout=900, env=env, cwd=cases.ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert "replicas x2" in line["config"]["parallelism"] and "broadcast" in line["config"]["parallelism"]
+    assert len(line["config"]["device_bus_ids"]) == 2 and line["config"]["process_group"].startswith("gloo")
+    assert line["value"] > 0
