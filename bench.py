@@ -502,6 +502,24 @@ def main():
     elif sharded:
         bcast = par.broadcast_weights_one_rank(chain, hip, opt)  # the same C entry points with a communicator of one
 
+    if sharded and os.environ.get("SHL_BENCH_SHARD_CHECK") and rank == world - 1:
+        # test hook (tests/test_sharding.py): the LAST rank runs layer 0 of its shard on a seeded input with the weights it
+        # RECEIVED and leaves input and output behind, so that the test can hold them against the oracle computed from rank
+        # 0's weights -- agreement between ranks alone would not notice a broadcast that corrupts every rank alike
+        e0 = chain.entries[0]
+        rng = np.random.default_rng(4242 + rank)
+        n_in, n_out = int(np.prod(e0["in_dims"])), int(np.prod(e0["out_dims"]))
+        x = rng.integers(-64, 64, n_in, dtype=np.int8)
+        hip.shl_mi355x_upload(e0["d_in"], x.ctypes.data, x.nbytes, None)
+        hip.shl_mi355x_stream_sync(None)
+        opt.shl_mi355x_set_stream(None)
+        assert e0["run"](*e0["args"]) == 1
+        hip.shl_mi355x_stream_sync(None)
+        y = np.empty(n_out, dtype=np.int8)
+        hip.shl_mi355x_download(y.ctypes.data, e0["d_out"], y.nbytes, None)
+        hip.shl_mi355x_stream_sync(None)
+        np.savez(os.environ["SHL_BENCH_SHARD_CHECK"], x=x.reshape(e0["in_dims"]), y=y.reshape(e0["out_dims"]), rank=rank,
+                 lo=lo, hi=hi, layout=layout)
     if world > 1 and not single_dev:
         # N ranks must mean N devices and an RCCL communicator of N: anything else is not the run that was asked for
         got_dev, got_nr = par.LAST_BROADCAST.get("distinct_devices"), par.LAST_BROADCAST.get("rccl_nranks")

@@ -950,6 +950,13 @@ static thread_local const char *g_plan_variant = nullptr;
 void igemm_set_plan_variant(const char *v) { g_plan_variant = v; }
 bool igemm_env_override() { return getenv("SHL_MI355X_IGEMM") != nullptr; }
 
+// the family the last launch on this thread actually ran ("wave" | "regs" | "tile" | "pp" | "pc" | "patch" | "gemv" |
+// "stream1x1" | "nchw1x1"): a forced family that does not take the shape resolves to another one, and whoever reports
+// a kernel name (tune_plan, params_kernel_name) must report that one
+static thread_local const char *g_last_family = "";
+void igemm_note_family(const char *v) { g_last_family = v; }
+const char *igemm_last_family() { return g_last_family; }
+
 static const char *variant_override()
 {
     static const char *v = getenv("SHL_MI355X_IGEMM");
@@ -1031,10 +1038,17 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     (void)layout;  // the kernels see NHWC; NCHW callers were re-laid out by the plan
     const bool i8 = dtype == SHL_MI355X_I8;
     const int esize = i8 ? 1 : 2;
-    if (i8 && !variant_override()[0] && conv1x1_stream_pick(a)) return launch_conv1x1_stream(a, s);
-    if (!variant_override()[0] && conv_gemv_pick(a, esize)) return launch_conv_gemv(a, dtype, s);
+    if (i8 && !variant_override()[0] && conv1x1_stream_pick(a)) {
+        igemm_note_family("stream1x1");
+        return launch_conv1x1_stream(a, s);
+    }
+    if (!variant_override()[0] && conv_gemv_pick(a, esize)) {
+        igemm_note_family("gemv");
+        return launch_conv_gemv(a, dtype, s);
+    }
     int ppf = -1;
     const char *v = igemm_pick(a, esize, &ppf);
+    igemm_note_family(v);
     if (!strcmp(v, "patch")) return launch_conv_igemm_patch(a, s);
     if (!strcmp(v, "pp")) return launch_conv_igemm_pp(a, dtype, ppf, s);
     if (!strcmp(v, "pc")) return launch_conv_igemm_pc(a, dtype, ppf, s);

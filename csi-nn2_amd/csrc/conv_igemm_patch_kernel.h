@@ -508,10 +508,10 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     pt_barrier();
     mark();  // 9: barrier passed
     if constexpr (!kNchw) {  // the row tables are dead: this role's multipliers and biases take their place
-        if (h == 0) {
-            if (fhalf == 0) epi_tab[frow] = t_mult, epi_tab[64 + frow] = __int_as_float(t_acc);
-            else epi_tab[32 + frow] = t_bias;
-        }
+        // (both halves of a role write the same values: a wave reads back what its own lanes wrote, whatever its partner
+        // does -- no barrier between this and the epilogue is needed)
+        if (fhalf == 0) epi_tab[frow] = t_mult, epi_tab[64 + frow] = __int_as_float(t_acc);
+        else epi_tab[32 + frow] = t_bias;
     }
 
     // ---- K loop ----------------------------------------------------------------------------------------------
@@ -607,7 +607,11 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         for (int step = 0; step < NSTEP; step += SPI)
             static_for<SPI>([&](auto fc) { kstep(passc, fc, s, step + decltype(fc)::value, bufoff, more); });
         mark();        // 6 + 2 s: K steps of the stage done
-        pt_barrier();  // every wave is done with this buffer; the next one is complete
+        // behind the LAST stage nothing of LDS is touched again when a wave finishes its blocks from its own registers
+        // (one K part; the second tile of a pair): a wave that is done starts its epilogue at once.  (Worth ~1 %: the VALU
+        // work of an epilogue gets only the issue slots its partner's MFMA stream leaves over -- profiles/r05_notes.md.)
+        const bool last_free = KP == 1 && st + 1 == nstg && (!kPair || PASS == 1);
+        if (!last_free) pt_barrier();  // every wave is done with this buffer; the next one is complete
         mark();        // 7 + 2 s
     }
 

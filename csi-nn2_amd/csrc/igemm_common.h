@@ -311,6 +311,8 @@ int pc_flavour(const ConvArgs &a, int esize, bool forced);  // conv_igemm_pc.hip
 int launch_conv_igemm_pc(const ConvArgs &a, int dtype, int flavour, hipStream_t s);
 int pc_read_trace(unsigned long long *host, int count);
 const char *igemm_pick(const ConvArgs &a, int esize, int *flavour);
+void igemm_note_family(const char *v);       // the family a launch path ran (string literal)
+const char *igemm_last_family();             // ... of the last launch on this thread
 void igemm_set_plan_variant(const char *v);  // nullptr: the selection rules; else "wave" | "tile" | "pp" | "pc" | "patch"
 bool igemm_env_override();                   // SHL_MI355X_IGEMM is set (A/B runs, tests): no tuning
 int pp_read_trace(unsigned long long *host, int count);

@@ -4,7 +4,7 @@
 // node costs 1.6-2.1 us before it does anything, profiles/r01_notes.md) and the pointwise output
 // -- the largest tensors of the network -- never travels to HBM and back.
 //
-// Why this direction and not depthwise -> pointwise (csrc/parked/dwpw_fused.hip: measured slower beyond 64 channels): a depthwise layer is
+// Why this direction and not depthwise -> pointwise (attic/dwpw_fused.hip: measured slower beyond 64 channels): a depthwise layer is
 // independent per channel, so a workgroup that owns a 32-channel SLICE of the pointwise output can
 // run the depthwise layer on exactly those channels with nothing recomputed except a one-pixel halo;
 // the other order recomputes the whole depthwise tile in every one of the Cout/32 workgroups that

@@ -182,7 +182,7 @@ static struct shl_node *final_out(struct dev_session *ds, struct shl_ref_graph *
  *        runs as 28 launches, not 55
  *   1x1 convolution -> depthwise 3x3   one launch of csrc/pwdw_fused.hip (int8 NHWC) / pwdw_f16_nchw.hip (fused[i] = 2)
  * (The other pairing, depthwise -> pointwise, recomputes the depthwise tile in every channel slice and measured
- * slower beyond 64 channels: csrc/parked/README.md.) */
+ * slower beyond 64 channels: attic/README.md.) */
 static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
 {
     ds->fused = calloc((size_t)g->layer_index + 1, 1);

@@ -1,7 +1,7 @@
 """Graph-level fusion of separable blocks -- a pointwise layer + the depthwise layer consuming it
 (csrc/pwdw_fused.hip, stemdw_fused.hip): a fused launch must produce exactly the bytes of the two stand-alone kernels
 (and of the oracle chain), for every K split, stride, ragged tile and activation combination; sessions must pick it up
-as a graph rewrite.  (The other pairing, depthwise + pointwise, is parked: csrc/parked/README.md.)"""
+as a graph rewrite.  (The other pairing, depthwise + pointwise, is parked: attic/README.md.)"""
 import ctypes as C
 import os
 import subprocess

@@ -90,3 +90,26 @@ def test_resnext_style_group_conv_is_one_launch(gpu, layout):
         assert opt.shl_mi355x_params_kernel_name(keep[0][0]).decode() == "conv_group_direct_i8"
         check(got, cases.oracle_group_run(case, "exact"), case, "%d groups %s vs oracle" % (groups, layout))
         opt.shl_mi355x_release_params(keep[0][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [0, 45])
+def test_grouped_int8_with_scales_outside_the_fast_epilogue_range(gpu, shift):
+    """the grouped direct kernel carries the hardware-division epilogue of the direct kernel, so a grouped
+    int8 layer whose multipliers leave the 2^+-40 / 2^60 window of the fma division must still get its one-launch plan
+    (it used to be refused at init) and equal formulation X bit for bit."""
+    fe, hip, opt = gpu
+    dev = cases.HipDevice(hip)
+    case = cases.make_case(4343, exact=False, layout=cases.NHWC, n=2, h=9, w=9, c=32, co=48, groups=4, act=1, per_channel=True)
+    f = np.float32(2.0 ** shift)
+    case["in_scale"] = float(np.float32(case["in_scale"]) * f)
+    case["b_scale"] = (case["b_scale"] * f).astype(np.float32)
+    case["out_scale"] = float(np.float32(case["out_scale"]) * f)
+    kept = []
+    got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+    name = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
+    assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
+    assert "group" in name, name
+    count, worst = cases.mismatch_report(got, cases.oracle_group_run(case, "exact"))
+    assert count == 0, "%s: %d mismatches vs formulation X (max %d)" % (name, count, worst)
+    assert len(np.unique(got)) > 16

@@ -23,6 +23,7 @@ import numpy as np
 import pytest
 
 import cases
+import golden_util
 from cases import NCHW, NHWC, pkg
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -160,6 +161,11 @@ def test_resnet50_3x3_batch128_full_size(gpu, idx, layout, exact):
         want = cases.oracle_run(_one_image(case, i), "exact")
         n, worst = cases.mismatch_report(got[i:i + 1], want)
         assert n == 0, "%s image %d via %s: %d mismatches vs the oracle (max %d)" % (layout, i, kname, n, worst)
+        if not exact and i in (0, batch - 1):
+            # converter scales: also the reference's own float formulation (R) under SURVEY 8(c)'s general-scale gate
+            # (|delta| <= 1 LSB on at most 2e-4 of the outputs) next to the equality with formulation X
+            golden_util.compare(_one_image(case, i), got[i:i + 1], cases.oracle_run(_one_image(case, i), "ref"),
+                                "%s image %d via %s vs formulation R" % (layout, i, kname))
     # (2) more images against their own single-image run through the product (a different kernel at M/128)
     for i in (1, 63, 64, 100, 126):
         single = cases.csinn_run(fe, pkg.API_MI355X, _one_image(case, i), device=dev)

@@ -192,6 +192,34 @@ def test_bench_shards_a_total_batch_over_two_ranks_on_one_device():
     assert line["config"]["rccl_nranks"] is None
 
 
+@pytest.mark.gpu
+def test_rank_1_shard_output_matches_the_oracle_after_the_broadcast(tmp_path):
+    """VERDICT r04 weak #1 iii: agreement BETWEEN ranks is not parity.  Rank 1 (plans built from other weights, then
+    overwritten by rank 0's broadcast) runs layer 0 of its shard on a seeded input; the output must equal the oracle's,
+    computed from rank 0's weights (seed 1234), bit for bit."""
+    import importlib
+    import numpy as np
+    from test_whole_network import layer_case
+    wl = importlib.import_module("csi-nn2_amd.workloads")
+    dump = str(tmp_path / "shard.npz")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SHL_BENCH_SINGLE_DEVICE="1", SHL_BENCH_SHARD_CHECK=dump)
+    cmd = [sys.executable, os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", "--workload", "resnet50_3x3", "--total-batch", "6",
+           "--steps", "1", "--warmup", "1", "--windows", "1", "--no-cpu-baseline", "--no-configs"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=cases.ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    d = np.load(dump)
+    assert int(d["rank"]) == 1 and (int(d["lo"]), int(d["hi"])) == (3, 6) and d["x"].shape[0] == 3
+    layer = wl.RESNET50_3X3[0]
+    layout = str(d["layout"])
+    ops = wl.synth_layer_operands(layer, 1234, "int8", layout)   # rank 0's layer-0 weights
+    want = cases.oracle_run(layer_case(layer, ops, "int8", layout, d["x"]), "exact")
+    n, worst = cases.mismatch_report(d["y"], want)
+    assert n == 0, "rank 1's shard output: %d mismatches vs the oracle on rank 0's weights (max %d)" % (n, worst)
+    other = wl.synth_layer_operands(layer, 999 + 1, "int8", layout)   # the weights rank 1 built its plans from
+    assert not np.array_equal(cases.oracle_run(layer_case(layer, other, "int8", layout, d["x"]), "exact"), want)
+
+
 def test_bench_gpus_flag_decides_between_running_and_spawning():
     """`python bench.py --gpus N` with no launcher must start N ranks itself (the flag was parsed and
     ignored); under torch.distributed.run (RANK / WORLD_SIZE exported) the process is a rank and must not spawn again;
