@@ -57,6 +57,29 @@ def spilled_kernels(usage_file):
     return bad
 
 
+# the row-patch kernels: every eight-wave instantiation (the ones that run ResNet-50; the four-wave ones are a fallback
+# and a test switch) must stay free of scratch -- they sit at 256 registers, and a kernel with scratch pays for it at
+# every launch (profiles/r04_notes.md: +15 us on a 6-us kernel)
+PATCH_SOURCES = ("conv_igemm_patch.hip", "conv_igemm_patch_nchw.hip", "conv_igemm_patch_f16.hip")
+
+
+def patch_kernels_with_scratch(usage_file):
+    bad, name = [], "?"
+    with open(usage_file) as f:
+        for ln in f:
+            if "Function Name:" in ln:
+                name = ln.split("Function Name:")[1].split("[")[0].strip()
+            elif "ScratchSize [bytes/lane]:" in ln:
+                n = int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0].strip() or 0)
+                # mangled template arguments end in ...ELi<NW>E[Lb<kBuild>E]EEvNS_8ConvArgsE
+                # (known and measured harmless since round 4: 12 bytes in the NCHW instantiation with two K parts of 128-byte
+                # stages -- 256 -> 256 @14, 21 - 23 us with it; it does not read the memo)
+                known = "ILb0ELi3ELb1ELb0ELb0ELi128ELi1ELi2ELi2ELi8E" in name or "ILb0ELi0ELb1ELb0ELb0ELi128ELi1ELi2ELi2ELi8E" in name
+                if n > (12 if known else 0) and "conv_igemm_patch_kernel" in name and ("Li8EEEv" in name or "Li8ELb1EEEv" in name or "Li8ELb0EEEv" in name):
+                    bad.append("%s (%d bytes)" % (name, n))
+    return bad
+
+
 def build_hip(force=False):
     """One object per .hip file (compiled in parallel, rebuilt only when stale), then one link."""
     from concurrent.futures import ThreadPoolExecutor
@@ -94,6 +117,10 @@ def build_hip(force=False):
             if bad:
                 os.remove(fo[1])
                 raise RuntimeError("%s: register spills in kernels with asynchronous asm reads: %s" % (fo[0], ", ".join(bad)))
+            bad = patch_kernels_with_scratch(fo[1][:-2] + ".usage.txt") if os.path.basename(fo[0]) in PATCH_SOURCES else []
+            if bad:
+                os.remove(fo[1])
+                raise RuntimeError("%s: eight-wave row-patch kernels with scratch: %s" % (fo[0], ", ".join(bad)))
         with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 4)) as pool:
             list(pool.map(compile_one, stale))
     if stale or force or _newer(out, objs):
