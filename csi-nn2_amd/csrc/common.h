@@ -468,6 +468,8 @@ void dwconv_dot4_pack(const shl_mi355x_conv_desc &d, const int8_t *hwo, uint32_t
 bool dwconv_mfma_pick(int64_t M, int C, int H, int W, int Ho, int Wo, int sh, int sw);
 int launch_dwconv_mfma(const ConvArgs &a, hipStream_t s);
 // pointwise int8 NHWC with the weight slice in registers, for bandwidth-bound sizes (conv1x1_stream.hip)
+bool conv1x1_resident_pick(const ConvArgs &a);   // conv1x1_resident.hip: deep-K pointwise, persistent workgroups, weights in registers
+int launch_conv1x1_resident(const ConvArgs &a, hipStream_t s);
 bool conv1x1_stream_pick(const ConvArgs &a);
 int launch_conv1x1_stream(const ConvArgs &a, hipStream_t s);
 int launch_dwconv_channel(const ConvArgs &a, hipStream_t s);  // dwconv_channel.hip

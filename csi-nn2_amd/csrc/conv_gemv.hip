@@ -81,8 +81,6 @@ __global__ __launch_bounds__(256) void conv_gemv_kernel(ConvArgs a)
 // 1x1, stride 1, no padding, at most 8 pixels, K rows of whole 16-byte chunks
 bool conv_gemv_pick(const ConvArgs &a, int esize)
 {
-    static const char *env = getenv("SHL_MI355X_GEMV");  // "0": keep the MFMA wave kernel (A/B)
-    if (env && env[0] == '0') return false;
     return a.Kh * a.Kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 && a.H == a.Ho && a.W == a.Wo && a.M >= 1 &&
            a.M <= 8 && (a.C * esize) % 16 == 0 && !a.out_nchw;
 }

@@ -1038,6 +1038,10 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
     (void)layout;  // the kernels see NHWC; NCHW callers were re-laid out by the plan
     const bool i8 = dtype == SHL_MI355X_I8;
     const int esize = i8 ? 1 : 2;
+    if (i8 && !variant_override()[0] && conv1x1_resident_pick(a)) {
+        igemm_note_family("resident1x1");
+        return launch_conv1x1_resident(a, s);
+    }
     if (i8 && !variant_override()[0] && conv1x1_stream_pick(a)) {
         igemm_note_family("stream1x1");
         return launch_conv1x1_stream(a, s);
@@ -1066,8 +1070,6 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         const int64_t tiles = (int64_t)((a.M + 31) / 32) * ((a.Co + 31) / 32);
         // fewer tiles than CUs and at least 8 sub-steps of K: one tile per block, K split 4 ways
         splitk = tiles <= 256 && a.kstride >= 256;
-        static const char *ks_env = getenv("SHL_MI355X_SPLITK");  // A/B override
-        if (ks_env) splitk = ks_env[0] == '1' && a.kstride >= 128;
         grid = dim3((unsigned)(splitk ? tiles : (tiles + 3) / 4));
         kind = 0;
     } else if (!strcmp(v, "regs")) {

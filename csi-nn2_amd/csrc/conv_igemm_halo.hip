@@ -491,8 +491,7 @@ int launch_conv_igemm_halo(const ConvArgs &a_in, int dtype, int tile, hipStream_
 {
     const bool i8 = dtype == SHL_MI355X_I8;
     const int esize = i8 ? 1 : 2;
-    static const char *ring_env = getenv("SHL_MI355X_RING");  // A/B: weight ring depth 4 | 6
-    int nst = ring_env && ring_env[0] == '4' ? 4 : 6;
+    int nst = 6;  // weight ring depth
     // 256 x 64 tile with a short K (ResNet-50's first stage: 9 steps): a 10-deep ring holds every
     // weight slab -> the kernel's "resident" mode (one hand-over, no per-step barriers)
     if (tile == 1 && (a_in.Kh * a_in.Kw) * (a_in.C * esize / BKB) <= 10) nst = 10;
@@ -524,8 +523,7 @@ int launch_conv_igemm_halo(const ConvArgs &a_in, int dtype, int tile, hipStream_
     // Beyond ~half the LDS the patch is mostly halo (strided convolutions: (2*rows+1) input rows per
     // output row) and one block per CU loses more than the saved traffic wins: measured slower than
     // the tile kernel on the ResNet-50 stride-2 layers
-    static const char *big_env = getenv("SHL_MI355X_HALO_BIG");
-    if (lds > (big_env && big_env[0] == '1' ? 160 : 96) * 1024) return SHL_MI355X_ENOTSUP;
+    if (lds > 96 * 1024) return SHL_MI355X_ENOTSUP;
     const int epi = i8 ? epi_code(a) : 0;
     const dim3 grid((unsigned)((((int64_t)a.M + tbm - 1) / tbm) * ((a.Co + tbn - 1) / tbn)));
 #define SHL_HALO_EPI(MI, WRV, WCV, NS)                                                                         \

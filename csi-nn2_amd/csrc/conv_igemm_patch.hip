@@ -236,8 +236,6 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     int kc = (cbytes % 128 == 0 && !s2) ? 128 : 64;  // stride 2: two 64-channel patches of one input row per tile row fit LDS
     int u = kc / 32;
     const bool nchw = d.layout == SHL_MI355X_NCHW && !f16;  // binary16 NCHW layers: the NHWC view
-    static const char *s2_env = getenv("SHL_MI355X_PATCH_S2");  // "0": no stride-2 form (A/B)
-    if (s2 && s2_env && s2_env[0] == '0') return 0;
     // NHWC keeps its stride-2 layers on the block-tile kernels (28 / 22 us against 32 / 32 for ResNet-50's at batch 128:
     // a stage is only six K steps long and the staging loads of the next one do not arrive in that time); NCHW saves
     // the re-layout pass in front of them (53 -> 36 us, 40 -> 38 us).  Forced (tests): both layouts

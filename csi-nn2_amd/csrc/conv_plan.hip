@@ -207,6 +207,7 @@ static const char *family_kernel_name(const char *v, bool i8)
     if (!strcmp(v, "gemv")) return i8 ? "conv_gemv_i8_dot4" : "conv_gemv_f16_fma";
     if (!strcmp(v, "regs")) return i8 ? "conv_igemm_regs_i8_mfma32x32x32" : "conv_igemm_regs_f16_mfma32x32x16";
     if (!strcmp(v, "stream1x1")) return "conv1x1_stream_i8_mfma32x32x32";
+    if (!strcmp(v, "resident1x1")) return "conv1x1_resident_i8_mfma32x32x32";
     if (!strcmp(v, "nchw1x1")) return i8 ? "conv1x1_nchw_i8" : "conv1x1_nchw_f16";
     if (!strcmp(v, "wave")) return i8 ? "conv_igemm_wave_i8_mfma32x32x32" : "conv_igemm_wave_f16_mfma32x32x16";
     if (!strcmp(v, "tile")) return i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
@@ -459,7 +460,13 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
             p->kernel_name = i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
         if (i8 && d.layout == SHL_MI355X_NHWC) {  // pointwise at bandwidth-bound sizes (conv1x1_stream.hip)
             probe.w_frag = &probe;  // the copy is made below for exactly these shapes
+            probe.div_exact = i8_div_exact, probe.div_fma = i8_div_fma, probe.act = d.act;
+            {
+                float lo, hi;
+                probe.act_clamp = d.act != SHL_MI355X_ACT_NONE && derive_act_clamp(d, &lo, &hi);
+            }
             if (conv1x1_stream_pick(probe)) p->kernel_name = "conv1x1_stream_i8_mfma32x32x32";
+            if (conv1x1_resident_pick(probe)) p->kernel_name = "conv1x1_resident_i8_mfma32x32x32";
         }
     } else if (algo == SHL_MI355X_ALGO_STEM) {
         w_bytes = stem_weight_bytes(d);

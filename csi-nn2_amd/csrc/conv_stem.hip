@@ -292,8 +292,6 @@ int launch_conv_stem(const ConvArgs &a, hipStream_t s)
         // a few tiles per wave amortise the weight fragment and table loads; enough waves to fill the chip twice over
         int tpw = tiles / (256 * 4 * 8);
         tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
-        static const char *tpw_env = getenv("SHL_MI355X_STEM_TPW");  // tiles per wave (A/B)
-        if (tpw_env && atoi(tpw_env) > 0) tpw = atoi(tpw_env);
         const int waves = (tiles + tpw - 1) / tpw;
         const dim3 grid((unsigned)((waves + 3) / 4));
 #define SHL_STEMM(E)                                                                                              \

@@ -392,16 +392,12 @@ int launch_conv1x1_nchw(const ConvArgs &a, int dtype, hipStream_t s)
     const dim3 grid((unsigned)((a.Co + 31) / 32), (unsigned)(a.N * ptiles));
     // more waves as long as each still gets >= 2 K sub-steps of 32 bytes (f16: 8 from K = 256, 16 from
     // K = 512; int8: from K = 512 / 1024).  MobileNetV1 fp16 NCHW batch 1: 512 -> 512 @14 8.9 -> 6.9 us with 8
-    static const char *env = getenv("SHL_MI355X_NCHW_WAVES");  // 4 | 8 | 16 (A/B)
     const int nsub = a.kstride / 32;
-    int threads = nsub >= 32 ? 1024 : (nsub >= 16 ? 512 : 256);
-    if (env) threads = 64 * atoi(env);
-    if (threads != 256 && threads != 512 && threads != 1024) threads = 256;
+    const int threads = nsub >= 32 ? 1024 : (nsub >= 16 ? 512 : 256);
     // B operand staged in LDS + transposing reads whenever the staging fits (K <= 1024 f16 / 2048 int8)
     const int nw = threads / 64, per = (nsub + nw - 1) / nw;
     const size_t lds = (size_t)nw * per * 1024;
-    static const char *tr_env = getenv("SHL_MI355X_NCHW_TR");  // "0": the gather kernel (A/B)
-    if (lds <= 64 * 1024 && !(tr_env && tr_env[0] == '0')) {
+    if (lds <= 64 * 1024) {
         static LdsOptIn opted[2];
         const int ki = dtype == SHL_MI355X_I8 ? 0 : 1;
         lds_opt_in(opted[ki], ki == 0 ? reinterpret_cast<const void *>(conv1x1_nchw_tr_kernel<true>)

@@ -206,16 +206,11 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int waves_per_group()
-{
-    static const char *env = getenv("SHL_MI355X_PWDW_WAVES");  // 4 | 8 (A/B)
-    return env && env[0] == '8' ? 8 : 4;  // 8 waves measured slower on 11 of the 12 MobileNetV1 pairs
-}
+static int waves_per_group() { return 4; }  // (8 waves measured slower on 11 of the 12 MobileNetV1 pairs: profiles/r01_notes.md)
 static int ks_for(int nsub, int nwaves)
 {
-    const int ks = nsub >= 8 ? 4 : (nsub >= 4 ? 2 : 1);
-    static const char *k8 = getenv("SHL_MI355X_PWDW_KS8");  // A/B: 8-way K split with 8 waves
-    return nwaves == 8 && nsub >= 16 && k8 && k8[0] == '1' ? 8 : ks;
+    (void)nwaves;
+    return nsub >= 8 ? 4 : (nsub >= 4 ? 2 : 1);
 }
 constexpr int PWDW_MTW = 4;  // tiles per wave the kernels are instantiated for
 

@@ -226,8 +226,7 @@ static void geometry(const ConvArgs &a, const ConvArgs &d, StemDwF16Args &f)
 
 bool stemdw_f16_nchw_fusable(const ConvArgs &a, const ConvArgs &d)
 {
-    static const char *off = getenv("SHL_MI355X_STEMDW_F16");  // "0": the two layers keep their own launches (A/B)
-    if ((off && off[0] == '0') || !shapes(a, d)) return false;
+    if (!shapes(a, d)) return false;
     StemDwF16Args f;
     geometry(a, d, f);
     const int64_t tx = (d.Wo + f.bw - 1) / f.bw, ty = (d.Ho + f.bh - 1) / f.bh;

@@ -1,0 +1,13 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."
+OUT=gpurun_out/r05_exp5; mkdir -p $OUT
+export SHL_MI355X_TUNE=0
+( timeout 1200 python -m pytest tests/test_pw_resident.py tests/test_pw_stream.py -m gpu -q 2>&1 | tail -15 ) | tee $OUT/parity.txt
+LAYERS=8,10,12,14,24,26
+for R in 0 1; do echo "== PWRES $R"; SHL_MI355X_PWRES=$R timeout 300 python tools/kbench.py --set mobilenet --batch 128 --layers $LAYERS 2>&1 | tail -7; done | tee $OUT/kbench.txt
+for R in 0 default; do
+  echo "== pass PWRES $R"
+  if [ $R = 0 ]; then export SHL_MI355X_PWRES=0; else unset SHL_MI355X_PWRES; fi
+  timeout 300 python bench.py --batch 128 --no-fuse --no-configs --no-cpu-baseline --steps 20 --windows 3 2>/dev/null \
+    | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('PASS ms', d['ms_per_step']); [print(' ', k, v['launches'], round(v['us_total'],1)) for k,v in d['kernels'].items()]"
+done 2>&1 | tee $OUT/pass.txt
