@@ -26,10 +26,12 @@ SHAPES = [
     dict(c=512, co=512, h=9, w=11, n=20, exact=False, per_channel=True, act=1),   # converter scales (the fma division); 1 980 pixels
     dict(c=512, co=256, h=5, w=7, n=37, exact=False),               # 1 295 pixels: 15 in the last tile; one channel block
     dict(c=1024, co=512, h=3, w=3, n=130),                          # 1 170 pixels
+    dict(c=256, co=256, h=14, w=14, n=12, act=1),                   # K = 256: tiles of 64 pixels (two blocks), 2 352 pixels
+    dict(c=128, co=256, h=9, w=11, n=40, exact=False, act=1),       # K = 128: tiles of 128 pixels (four blocks), 3 960 pixels: 120 in the last tile
+    dict(c=256, co=512, h=7, w=7, n=50),                            # 2 450 pixels: 18 in the last tile
     dict(c=512, co=768, h=8, w=8, n=24),                            # three channel blocks do not divide an XCD's 32: another kernel
-    dict(c=256, co=256, h=14, w=14, n=12),                          # K = 256: eight MFMAs per epilogue -- stays with the stream kernel
 ]
-RESIDENT = 6   # the first six take the kernel when forced
+RESIDENT = 9   # the first nine take the kernel when forced
 for i, kw in enumerate(SHAPES):
     case = cases.make_case(5200 + i, k=(1, 1), pad=(0, 0, 0, 0), **kw)
     keep = []
@@ -48,7 +50,7 @@ def run(force):
     res = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
                          timeout=900, env=env)
     rows = [l.split() for l in res.stdout.splitlines() if l.startswith("CASE")]
-    assert len(rows) == 8, res.stdout + res.stderr
+    assert len(rows) == 10, res.stdout + res.stderr
     return rows
 
 
@@ -56,7 +58,7 @@ def run(force):
 def test_resident_pointwise_is_bit_exact_and_equals_the_kernels_it_replaces():
     resident, generic = run("1"), run("0")
     for i, (r, g) in enumerate(zip(resident, generic)):
-        if i < 6:
+        if i < 9:
             assert r[2] == "conv1x1_resident_i8_mfma32x32x32", r
         else:
             assert r[2] != "conv1x1_resident_i8_mfma32x32x32", r
