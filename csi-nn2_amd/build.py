@@ -75,6 +75,11 @@ def patch_kernels_with_scratch(usage_file):
                 # (known and measured harmless since round 4: 12 bytes in the NCHW instantiation with two K parts of 128-byte
                 # stages -- 256 -> 256 @14, 21 - 23 us with it; it does not read the memo)
                 known = "ILb0ELi3ELb1ELb0ELb0ELi128ELi1ELi2ELi2ELi8E" in name or "ILb0ELi0ELb1ELb0ELb0ELi128ELi1ELi2ELi2ELi8E" in name
+                # the stride-2 NCHW instantiations (round 5: a stride-1 layer on the half-resolution grid) carry three more
+                # scalars than their stride-1 twins at 253 of 256 registers: 14 spilled registers, 60 bytes -- measured WITH
+                # them: 128 -> 128 @56 stride 2 at batch 128 34.1 - 35.2 -> 30.7 - 31.0 us (profiles/r05_notes.md)
+                if "ELb1ELb0ELb1ELi128E" in name and n <= 64:
+                    continue
                 if n > (12 if known else 0) and "conv_igemm_patch_kernel" in name and ("Li8EEEv" in name or "Li8ELb1EEEv" in name or "Li8ELb0EEEv" in name):
                     bad.append("%s (%d bytes)" % (name, n))
     return bad

@@ -48,7 +48,7 @@ bool patch_supports(const shl_mi355x_conv_desc &d)
 {
     if (d.group != 1) return false;
     if (d.dtype == SHL_MI355X_F16) {
-        // binary16: stride 1, NHWC tensors (the stride-2 form and the NCHW staging transpose BYTES); an NCHW layer meets
+        // binary16: stride 1, NHWC tensors (the NCHW staging -- which the stride-2 form builds on -- transposes BYTES); an NCHW layer meets
         // the kernel on the NHWC view of conv_forward's re-layout path
         static const char *f16_env = getenv("SHL_MI355X_PATCH_F16");  // "0": off (A/B)
         if (f16_env && f16_env[0] == '0') return false;
@@ -85,27 +85,12 @@ int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, in
     const int kc = PT_KC(geom), pg = PT_PG(geom), ob = PT_OB(geom), kp = PT_KP(geom);
     const int pitch = kc + 16, slots = kc / 16;
     const int tr = rows * pg;
-    if (PT_S2(geom)) {
-        // stride 2: rows are OUTPUT rows; the patch of a stage is one input row (W + 1 pixels) per tile row
-        const int64_t orows = (int64_t)n * (H / 2);
-        const int nt = (int)((orows + tr - 1) / tr);
-        const int prows = (int)(orows < tr ? orows : tr);
-        const int bufb = (((prows * (W + 1) + 1) * pitch) + 255) & ~255;
-        int lds = 2 * bufb + PT_TRASH + PT_TABLES;
-        if (prows > 512) return 0;
-        if (kp > 1 && lds < 4 * 8 * 4096) lds = 4 * 8 * 4096;
-        if (lds > PT_LDS_MAX) return 0;
-        if (!nchw && (int64_t)prows * W * slots > PT_NIT * 256) return 0;
-        int spr = 1;
-        if (nchw) {
-            spr = (W + 15) / 16;
-            if ((int64_t)prows * spr * (kc / 8) > 512) return 0;  // one round of items for the eight waves
-        }
-        ps->rows = rows, ps->prows = prows, ps->bufb = bufb, ps->lds = lds, ps->nt_m = nt;
-        ps->nt_n = (((Co + 31) / 32) + ob - 1) / ob;
-        ps->nitc = 1, ps->spr = spr, ps->pair_dn = 0;
-        return 1;
-    }
+    // stride 2 = the stride-1 geometry on the half-resolution grid (conv_igemm_patch_kernel.h: kS2): H, W below are the grid's,
+    // TW the tensor's row length (NCHW runs are rows of the tensor)
+    const bool s2 = PT_S2(geom) != 0;
+    const int TW = W;
+    if (s2) H /= 2, W /= 2;
+    const int kcp = s2 ? kc / 4 : kc;  // channels of the tensor per stage
     const int64_t total_rows = (int64_t)n * H;
     const int nt_m = (int)((total_rows + tr - 1) / tr);
     int prows = 0, runs = 0;
@@ -127,10 +112,10 @@ int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, in
     if (!nchw && (int64_t)prows * W * slots > PT_NIT * 256) return 0;
     int nitc = 1, spr = 1;
     if (nchw) {
-        const int maxrun = (rows * pg + 2 < H ? rows * pg + 2 : H) * W;
+        const int maxrun = (rows * pg + 2 < H ? rows * pg + 2 : H) * (s2 ? 2 * TW : W);
         spr = (maxrun + 15) / 16;
         const int nw8 = PT_NW8(geom);
-        const int items = runs * spr * (kc / (nw8 ? 8 : 16));
+        const int items = runs * spr * (kcp / (nw8 ? 8 : 16));
         nitc = (items + (nw8 ? 511 : 255)) / (nw8 ? 512 : 256);
         if (nitc > (nw8 ? 1 : 2)) return -1;
     }
@@ -144,7 +129,7 @@ int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, in
     static const char *pair_env = getenv("SHL_MI355X_PATCH_PAIR");  // "0": off (A/B), "1": whenever the tiles pair up (tests)
     const int64_t tiles = (int64_t)nt_m * ps->nt_n;
     const bool pays = (pair_env && pair_env[0] == '1') || (double)((tiles + 511) / 512) * 1.7 < (double)((tiles + 255) / 256);
-    if (!(pair_env && pair_env[0] == '0') && !PT_F16(geom) && PT_NW8(geom) && C == kc && kp == 1 && nt_m % 2 == 0 && total_rows % tr == 0 &&
+    if (!(pair_env && pair_env[0] == '0') && !PT_F16(geom) && !s2 && PT_NW8(geom) && C == kc && kp == 1 && nt_m % 2 == 0 && total_rows % tr == 0 &&
         ((int64_t)(nt_m / 2) * tr) % H == 0 && pays)
         ps->pair_dn = (int)((int64_t)(nt_m / 2) * tr / H);
     return 1;
@@ -184,8 +169,8 @@ bool patch_shape(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchS
 bool patch_shape_uncached(int n, int H, int W, int C, int Co, bool nchw, int geom, PatchShape *ps)
 {
     const int kc = PT_KC(geom), pg = PT_PG(geom);
-    if (!kc || C % kc != 0) return false;
     const bool s2 = PT_S2(geom);
+    if (!kc || C % (s2 ? kc / 4 : kc) != 0) return false;
     const int HO = s2 ? H / 2 : H, WO = s2 ? W / 2 : W;  // output plane
     const int64_t total_rows = (int64_t)n * HO;
     if ((int64_t)n * H + n >= (1 << 22) || (int64_t)n * H * W >= (1 << 24) || (int64_t)n * C >= (1 << 24)) return false;  // 24-bit multiplies
@@ -233,17 +218,15 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     const bool s2 = d.stride_h == 2;
     const bool f16 = d.dtype == SHL_MI355X_F16;
     const int cbytes = d.in_c * pt_esize(d);  // the kernel's "channels" are the bytes of a pixel
-    int kc = (cbytes % 128 == 0 && !s2) ? 128 : 64;  // stride 2: two 64-channel patches of one input row per tile row fit LDS
+    int kc = (cbytes % 128 == 0 || s2) ? 128 : 64;  // stride 2: a patch pixel is four planes of 32 channels
     int u = kc / 32;
     const bool nchw = d.layout == SHL_MI355X_NCHW && !f16;  // binary16 NCHW layers: the NHWC view
-    // NHWC keeps its stride-2 layers on the block-tile kernels (28 / 22 us against 32 / 32 for ResNet-50's at batch 128:
-    // a stage is only six K steps long and the staging loads of the next one do not arrive in that time); NCHW saves
-    // the re-layout pass in front of them (53 -> 36 us, 40 -> 38 us).  Forced (tests): both layouts
-    static const char *forced_env = getenv("SHL_MI355X_IGEMM");
-    if (s2 && !nchw && !(forced_env && !strcmp(forced_env, "patch"))) return 0;
+    // NHWC keeps its stride-2 layers on the block-tile kernels (28 / 22 / 23 us for ResNet-50's at batch 128); NCHW saves the
+    // re-layout passes around them
+    if (s2 && !nchw) return 0;
     if (env && env[0] && env[0] != '0' && env[0] != '1') {
         int pg = 0, ob = 0, kp = 0;
-        if (sscanf(env, "%d,%d,%d", &pg, &ob, &kp) == 3 && pg * ob * kp == 4 && u % kp == 0 && pg != 4 && !(pg == 2 && kp == 2)) {
+        if (sscanf(env, "%d,%d,%d", &pg, &ob, &kp) == 3 && pg * ob * kp == 4 && u % kp == 0 && pg != 4 && !(pg == 2 && kp == 2) && !(s2 && kp != 1)) {
             PatchShape ps;
             int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0) | (f16 ? 1 << 23 | 1 << 20 : 0);
             if (s2 && !PT_NW8(g)) return 0;  // the stride-2 form has eight waves
@@ -263,7 +246,7 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     kc = kc_try, u = kc / 32;
     for (const auto &c : cand) {
         const int pg = c[0], ob = c[1], kp = c[2];
-        if (u % kp != 0) continue;
+        if (u % kp != 0 || (s2 && kp != 1)) continue;  // (stride 2: one K sub-step per tap and stage)
         if (ob > 1 && ob / 2 >= ocblks) continue;  // half of the channel blocks of a tile would be empty
         PatchShape ps;
         int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0) | (f16 ? 1 << 23 | 1 << 20 : 0);  // binary16: eight waves
@@ -277,8 +260,11 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         const double rounds = (double)((tiles + 255) / 256);
         // per tile and wave: a K loop over K / kp for 13 pixel blocks + fixed costs (prologue, epilogue; the exchange
         // of partial sums for K parts)
-        // (stride 2: a barrier per three K steps with two K parts, per six with one)
-        const double total = rounds * (1.0 / kp + 0.12 + (kp > 1 ? 0.04 : 0.0) + (s2 && kp > 1 ? 0.10 : 0.0));
+        // (stride 2 has one K part: what separates its candidates is how much of a 13-block wave they fill -- 256 -> 256 @28
+        // is 128 tiles of 28 rows with four channel blocks per tile, or 256 tiles of 2 x 14 rows with two: the second puts a
+        // tile on every CU)
+        const double fill = s2 ? (double)ps.rows * (d.in_w / 2) / PT_PIX : 1.0;
+        const double total = rounds * fill * (1.0 / kp + 0.12 + (kp > 1 ? 0.04 : 0.0));
         static const char *dbg = getenv("SHL_MI355X_DEBUG_GEOM");
         if (dbg) fprintf(stderr, "patch geom %d,%d,%d nw%d%s: rows %d prows %d tiles %d x %d lds %d nitc %d pair %d cost %.3f\n", pg, ob, kp, PT_NW8(g) ? 8 : 4,
                          s2 ? " s2" : "", ps.rows, ps.prows, ps.nt_m, ps.nt_n, ps.lds, ps.nitc, ps.pair_dn, total);
@@ -297,7 +283,7 @@ size_t patch_weight_bytes(const shl_mi355x_conv_desc &d, int geom)
 // [channel block][K part][stage][tap][sub-step of the part][lane][16 B]: lane = (channel & 31) | (K half << 5)
 void patch_pack_weights(const shl_mi355x_conv_desc &d, int geom, const int8_t *src, int8_t *dst)
 {
-    const int kc = PT_KC(geom), kp = PT_KP(geom);
+    const int kc = PT_S2(geom) ? PT_KC(geom) / 4 : PT_KC(geom), kp = PT_KP(geom);  // (stride 2: 32-channel stages)
     // binary16: the same walk with two bytes per channel -- a K row is C * 2 bytes, a fragment piece 8 channels
     const int es = pt_esize(d);
     const int C = d.in_c * es;
@@ -349,10 +335,10 @@ bool patch_setup(ConvArgs &a)
     const bool s2 = PT_S2(a.pt_geom);
     const int HO = s2 ? a.H / 2 : a.H, WO = s2 ? a.W / 2 : a.W;
     if (s2 && (a.Ho != HO || a.Wo != WO)) return false;
-    a.pt_rW = 1.0f / (float)a.W;
+    a.pt_rW = 1.0f / (float)WO;  // the grid the patch geometry lives on = the output plane
     a.pt_rH = 1.0f / (float)HO;
     a.pt_rOW = 1.0f / (float)WO;
-    a.pt_rH1 = 1.0f / (float)(a.H + 1);
+    a.pt_rH1 = 1.0f / (float)(HO + 1);
     a.pt_rspr = 1.0f / (float)ps.spr;
     a.pt_rntn = 1.0f / (float)ps.nt_n;
     a.pt_rHW = 1.0f / (float)(HO * WO);
@@ -378,10 +364,9 @@ bool patch_auto(const ConvArgs &a, bool vs_wave)
     // tile (64 -> 64 @56 at batch 16 = 128 tiles: 10.6 us against the tile kernel's 8.4)
     const bool s2 = PT_S2(a.pt_geom);
     // (binary16: the block-tile kernels are further behind -- 256 -> 256 @14 at batch 8 26 us against 33, profiles/r04_f16_patch_kbench.txt)
+    // (stride 2: from 192 -- ResNet-50's 512 -> 512 @14 is 128 tiles of 16 stages, slower than the re-layout passes around the
+    // producer / consumer kernel)
     if ((int64_t)ps.nt_m * ps.nt_n < ((s2 || (!a.in_nchw && !vs_wave && !f16)) ? 192 : 96)) return false;
-    // the stride-2 form beyond 256 input channels is >= 24 stages of three K steps: 512 -> 512 @14 at batch 256 takes 94 us
-    // against 52 through the re-layout pass + producer / consumer kernel
-    if (s2 && a.C > 256) return false;
     // NHWC with four K parts (512 channels @7 at batch 128): nine K steps per stage and the exchange of partial sums
     // leave it behind the producer / consumer kernel (25.4 vs 22.4 us); NCHW takes it anyway -- the alternative there
     // is two re-layout passes around that kernel (39 vs 47 us)

@@ -24,7 +24,7 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 #define PT_OB(g) (((g) >> 12) & 0xf)
 #define PT_KP(g) (((g) >> 16) & 0xf)
 #define PT_NW8(g) (((g) >> 20) & 1)  // eight waves (two per SIMD) instead of four
-#define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (stage = (channel group, filter row))
+#define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (a stride-1 layer on the half-resolution grid, four planes per pixel)
 #define PT_NT(g) (((g) >> 22) & 1)   // NHWC output stored non-temporally (set per launch by patch_setup)
 #define PT_F16(g) (((g) >> 23) & 1)  // binary16 (NHWC, stride 1): the same bytes through v_mfma_f32_32x32x16_f16, fp32 epilogue
 
@@ -59,13 +59,15 @@ static __device__ unsigned long long g_pt_span[2 * 1024];  // SHL_MI355X_DEBUG=3
 // channel block, K part) split 7 + 6 between them (half h; NBW = this wave's blocks): the prologue and the epilogue are
 // long dependent scalar / VALU chains that a wave alone on its SIMD runs at ~6 cycles per instruction, and they are
 // half as long per wave and interleave with the partner's.  At most 256 registers per wave then: 7 x 16 accumulators.
-// kS2: 3x3 STRIDE-2 (pad 1 top / left, even H and W).  A full 3x3 patch of 13 pixel blocks would be four times the
-// stride-1 one; here a stage is (64 channels, ONE filter row ky): the patch holds, for every output row of the tile,
-// the single input row 2 oy + ky - 1, de-interleaved by column parity -- [left pad][odd columns][even columns] -- so
-// that the three taps of the row are again constant offsets (kx = 0: slot ox, kx = 2: slot ox + 1, kx = 1: slot
-// Wo + 1 + ox) and a block of 32 consecutive outputs reads consecutive slots.  Three K steps x U sub-steps per stage;
-// the top padding row (oy = 0, ky = 0) is the zero point selected at the LDS write (flag in bit 31 of the item's
-// destination), odd input rows are fetched twice (L2).  Weight stream order is the stride-1 one.
+// kS2: 3x3 STRIDE-2 (pad 1 top / left, even H and W) as a STRIDE-1 layer on the half-resolution grid (round 5; the earlier
+// form staged one filter row per stage -- three K steps between barriers, one register set of staging loads in flight --
+// and ran the NCHW layers at 21 % MFMA-busy).  Input pixel (2 r + py, 2 x + px) is "plane (py, px)" of grid pixel (r, x): a
+// patch pixel holds the four planes of KC / 4 = 32 channels each (space to depth, done by the staging's addresses), and
+// tap (ky, kx) of the stride-2 filter reads plane (ky != 1, kx != 1) of the grid pixel (ky != 0, kx != 0) rows / columns
+// further on than tap (0, 0) -- a constant LDS offset again.  Only the top / left taps reach outside (plane-1 rows / columns
+// of grid row / column -1): the shared padding column and the padding rows between images of the stride-1 geometry serve
+// them.  Everything else -- geometry, tables, padding, K loop (nine K steps per 32-channel stage), epilogue -- IS the
+// stride-1 code on the (H / 2) x (W / 2) grid; the weight stream is the stride-1 one with 32-channel stages.
 // kF16: binary16 tensors (NHWC, stride 1, no pair mode).  Everything up to the matrix instruction is byte arithmetic --
 // a.C is the pixel size in BYTES (the host doubles it), KC bytes of a pixel per stage are KC / 2 channels, a 16-byte
 // fragment piece is 8 channels -- and the fragment layouts of v_mfma_f32_32x32x16_f16 and v_mfma_i32_32x32x32_i8 are the
@@ -93,20 +95,23 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     constexpr int NP = kNchw ? CI : NIT;     // staging pieces per round (loads, and again writes)
     constexpr bool kTwo = kNchw && NW == 4;  // NCHW staging may take a second round of items (eight waves: the host
                                              // falls back to four when one round does not cover a stage)
-    constexpr int FR = ((NW == 8 && kNchw) || kS2) ? 3 : 9;  // weight fragment ring (256 registers per wave: NCHW staging needs the rest)
-    constexpr int U = KC / 32;          // 32-byte K sub-steps per tap and stage
+    constexpr int FR = (NW == 8 && kNchw) ? 3 : 9;  // weight fragment ring (256 registers per wave: NCHW staging needs the rest)
+    constexpr int KCP = kS2 ? KC / 4 : KC;  // bytes of a TENSOR pixel per stage (kS2: a patch pixel is four planes of them)
+    constexpr int U = KCP / 32;         // 32-byte K sub-steps per tap and stage
     constexpr int UI = U / KP;          // ... of which this wave takes every KP-th
-    constexpr int TAPS = kS2 ? 3 : 9;   // filter taps per stage
+    constexpr int TAPS = 9;             // filter taps per stage
     constexpr int NSTEP = TAPS * UI;    // K steps (13 MFMAs each) per stage and wave
-    constexpr int SPI = kS2 ? NSTEP : 9;  // steps per iteration of the K loop (the weight ring's index is static)
-    constexpr int FW = kS2 ? 1 : 4, FL = kS2 ? 2 : 5;  // steps that carry the next stage's LDS writes / the loads of the one after
+    constexpr int SPI = 9;              // steps per iteration of the K loop (the weight ring's index is static)
+    constexpr int FW = 4, FL = 5;       // steps that carry the next stage's LDS writes / the loads of the one after
     constexpr int NF = NSTEP * NB;      // MFMAs per stage and wave
     constexpr int PITCH = KC + 16;
     constexpr int SLOTS = KC / 16;
-    constexpr int CG = KC / CI;         // channel groups per stage (NCHW staging)
+    constexpr int CG = KCP / CI;        // channel groups per stage (NCHW staging)
     static_assert(U % KP == 0, "K parts split the sub-steps of a tap");
     static_assert(NSTEP % SPI == 0 && SPI % FR == 0, "weight fragment ring");
-    static_assert(!kS2 || (NW == 8 && !kPair), "the stride-2 form: eight waves");
+    // (NCHW only: NHWC stride-2 layers run faster on the ping-pong / producer-consumer kernels -- 22 - 28 us against 32 for
+    // ResNet-50's at batch 128 -- and the NHWC instantiations of this form needed 28 bytes of scratch)
+    static_assert(!kS2 || (kNchw && NW == 8 && !kPair && KC == 128 && KP == 1), "the stride-2 form: NCHW, eight waves, 32 channels x four planes per stage");
     // every kernel argument the kernel will ever read, requested NOW in one batch: left to the compiler the scalar
     // loads are sunk to their first uses, and each of the half dozen groups then costs its own 500 - 1 000 cycles of
     // argument-segment latency in a prologue that nothing overlaps
@@ -129,8 +134,10 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     const int wv = NW == 8 ? (oldmap ? wave >> 1 : wave & 3) : wave;
     const int kp = wv % KP, ob = (wv / KP) % OB, pg = wv / (KP * OB);
     const int hb = h * HB;                      // first pixel block of this wave inside the pixel group
-    const int W = a.W, H = a.H, W1 = W + 1, H1 = H + 1, HW = H * W;
-    const int OW = kS2 ? a.Wo : W, OH = kS2 ? a.Ho : H, OHW = OH * OW;  // output plane (= input plane at stride 1)
+    // W, H: the grid the patch geometry lives on = the OUTPUT plane (the input plane at stride 1); TW, TH: the input tensor's
+    const int W = kS2 ? a.Wo : a.W, H = kS2 ? a.Ho : a.H, W1 = W + 1, H1 = H + 1, HW = H * W;
+    const int TW = a.W, TH = a.H, THW = TH * TW;
+    const int OW = W, OH = H, OHW = HW;
     const int R = a.pt_rows, TR = PG * R, RW = R * OW;
     const int total_rows = a.N * OH;  // output rows
     const int ocblks = (a.Co + 31) >> 5;
@@ -149,16 +156,15 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // same tables.  The second tile's patch is staged into the other buffer under the first one's K loop like a second
     // stage, and one prologue (~7 000 cycles that nothing overlaps) serves both.  The two passes are two copies of the
     // code: the staging registers are dead in the second one, and the epilogue needs them
-    const int nstg = kPair ? 1 : (kS2 ? 3 : 1) * (a.C / KC);
+    const int nstg = kPair ? 1 : a.C / KCP;
     constexpr int NPASS = kPair ? 2 : 1;
     const uint32_t bufb = (uint32_t)a.pt_bufb;
     const float rW = a.pt_rW, rH = a.pt_rH, rH1 = a.pt_rH1, rOW = a.pt_rOW;  // reciprocals from the host (a division is ~12 instructions); rH = 1 / OH
     // "virtual" rows: every image is followed by ONE padding row (bottom halo of its last row = top halo of the
     // next image's first row): v(g) = g + g / H.  Patch row pr holds virtual row v0 + pr.
-    // (kS2: no halo and no virtual rows -- patch row pr = tile row pr)
-    const int v0 = kS2 ? row0 : row0 + (int)pt_div((uint32_t)row0, H, rH) - 1;
+    const int v0 = row0 + (int)pt_div((uint32_t)row0, H, rH) - 1;
     const int last_row = (row0 + TR < total_rows ? row0 + TR : total_rows) - 1;
-    const int prows = kS2 ? last_row - row0 + 1 : last_row + (int)pt_div((uint32_t)last_row, H, rH) - v0 + 2;
+    const int prows = last_row + (int)pt_div((uint32_t)last_row, H, rH) - v0 + 2;
 
     mark();  // 1: tile decoded
     // ---- weights: this wave's fragment stream, 1 KiB per K step; a ring of nine fragments = eight steps
@@ -187,16 +193,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     if constexpr (!kF16) t_mult = a.mult[ocb * 32 + frow];
     int32_t t_acc = 0;
     if constexpr (!kF16) t_acc = a.acc_init[ocb * 32 + frow];
-    if constexpr (kS2) {
-        // prow_tab[pr] = offset of input row 2 oy (the ky = 1 row) of tile row pr | (oy == 0), or -1 past the last row
-        for (int pr = tid; pr < a.pt_prows; pr += NT) {
-            const uint32_t g = (uint32_t)(row0 + pr);
-            const uint32_t n = pt_div(g, OH, rH), oy = g - m24(n, OH);
-            const bool ok = (int)g < total_rows;
-            const uint32_t off = kNchw ? m24(m24(n, a.C), HW) + m24(2 * oy, W) : m24(m24(m24(n, H) + 2 * oy, W), a.C);
-            prow_tab[pr] = ok ? (int32_t)(off | (oy == 0 ? 1u : 0u)) : -1;
-        }
-    } else if (wave == 0) {
+    if (wave == 0) {
         int ninv = 0;
         for (int pr = lane; pr < ((a.pt_prows + 63) & ~63); pr += 64) {
             const int v = v0 + pr;
@@ -204,6 +201,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             const uint32_t n = pt_div(vv, H1, rH1), y = vv - n * H1;
             const bool in_patch = pr < a.pt_prows;
             const bool ok = pr < prows && v >= 0 && y < (uint32_t)H && n < (uint32_t)a.N;
+            // (NCHW items do not read the offset, only whether the row exists)
             if (in_patch) prow_tab[pr] = ok ? (int32_t)(m24(m24(n, H) + y, W) * (kNchw ? 1 : a.C)) : -1;
             const uint64_t bad = __ballot(in_patch && !ok);
             if (in_patch && !ok) inv_tab[ninv + __popcll(bad & ((1ull << lane) - 1))] = (uint16_t)pr;
@@ -225,60 +223,8 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     constexpr int NSRC = kNchw ? (kTwo ? 2 : 1) : NIT;
     constexpr int NDST = kNchw ? (kTwo ? 32 : 16) : NIT;
     uint32_t s_src[NSRC], s_dst[NDST];
-    uint32_t s_top = 0;  // kS2, NCHW: bit 31 = the item's row is a top row (oy == 0)
     const uint32_t trash = 2 * bufb + lane * 16 + (wave & 3) * 1024;
-    if constexpr (kS2 && !kNchw) {
-        // item = (patch row, input pixel x, 16-byte slot); the pixel lands in its parity's half of the row
-        constexpr int PS = NT / SLOTS;
-        const uint32_t slot = tid % SLOTS;
-        uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - m24(pr, W);
-        const uint32_t dpr = pt_div(PS, W, rW), dx = PS - m24(dpr, W);
-        const uint32_t last = (uint32_t)a.pt_prows - 1;
-        int32_t row[NIT];
-        uint32_t prs[NIT], xs[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            prs[it] = pr, xs[it] = x;
-            row[it] = prow_tab[pr < last ? pr : last];
-            x += dx, pr += dpr;
-            if (x >= (uint32_t)W) x -= W, ++pr;
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const bool ok = row[it] >= 0 && prs[it] <= last;
-            const uint32_t pos = (xs[it] & 1) ? (xs[it] + 1) >> 1 : (uint32_t)OW + 1 + (xs[it] >> 1);
-            // offset of the ky = 1 row (2 oy); the loads go through a descriptor whose base is one input row in front
-            // of the tensor, + ky rows as the scalar offset
-            s_src[it] = ok ? ((uint32_t)row[it] & ~1u) + m24(xs[it], a.C) + slot * 16 : m24(W, a.C);
-            s_dst[it] = ok ? (m24(m24(prs[it], W1) + pos, PITCH) + slot * 16) | ((uint32_t)row[it] << 31) : trash;
-        }
-    } else if constexpr (kS2) {
-        // item = (patch row, 8-channel group, 16-pixel segment of the input row): consecutive lanes = the segments of a
-        // row, then the channel groups of the stage
-        const uint32_t spr = (uint32_t)a.pt_spr;
-        const uint32_t rest = pt_div(tid, spr, a.pt_rspr), seg = tid - m24(rest, spr);
-        const uint32_t cg = rest % CG, pr = rest / CG;
-        const uint32_t last = (uint32_t)a.pt_prows - 1;
-        const int32_t row = prow_tab[pr < last ? pr : last];
-        const bool run_ok = pr <= last && row >= 0;
-        const int total = a.N * a.C * HW;  // < 2^31 (checked on the host)
-        int k0 = (int)seg * 16;
-        int off = (int)((uint32_t)row & ~1u) + (int)m24(cg * CI, HW) + k0;
-        // the window of the LAST channel of the LAST stage (ky = 2: one row further) must end inside the tensor
-        const int over = run_ok ? off + (a.C - KC + CI - 1) * HW + W + 16 - total : 0;
-        if (over > 0) off -= over, k0 -= over;
-        if (!run_ok || off < 0) off = W;  // (the stage offset reaches one row back)
-        s_src[0] = (uint32_t)off;  // the ky = 1 row (2 oy)
-        const uint32_t top = run_ok ? (uint32_t)row << 31 : 0u;
-        s_top = top;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const int x = k0 + b;
-            const bool ok = run_ok && x >= (int)seg * 16 && x < W;
-            const uint32_t pos = (x & 1) ? (uint32_t)(x + 1) >> 1 : (uint32_t)OW + 1 + ((uint32_t)x >> 1);
-            s_dst[b] = ok ? (m24(m24(pr, W1) + pos, PITCH) + cg * CI) | top : trash;
-        }
-    } else if constexpr (!kNchw) {
+    if constexpr (!kNchw) {
         constexpr int PS = NT / SLOTS;  // pixels between a lane's consecutive items
         const uint32_t slot = tid % SLOTS;
         uint32_t pr = pt_div(tid / SLOTS, W, rW), x = tid / SLOTS - m24(pr, W);
@@ -307,7 +253,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         const uint32_t nf = pt_div((uint32_t)(v0 + 1), H1, rH1);
         const uint32_t spr = (uint32_t)a.pt_spr;
         const float rspr = a.pt_rspr;
-        const int total = a.N * a.C * HW;  // < 2^31 (checked on the host)
+        const int total = a.N * a.C * THW;  // < 2^31 (checked on the host)
         if constexpr (kTwo) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) s_dst[16 + q] = trash;
@@ -326,13 +272,14 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             const int lo = (int)m24(n, H1), hi = lo + H - 1;
             const int va = v0 > lo ? v0 : lo, vb = v0 + prows - 1 < hi ? v0 + prows - 1 : hi;
             const bool run_ok = it < a.pt_nitc && n < (uint32_t)a.N && vb >= va;
-            const int ya = va - lo, runlen = run_ok ? (int)m24(vb - va + 1, W) : 0;
+            // (kS2: a grid row is two input rows -- the run is twice as many rows of the plane, each TW pixels)
+            const int ya = va - lo, runlen = run_ok ? (int)m24(vb - va + 1, kS2 ? 2 * TW : W) : 0;
             int k0 = (int)seg * 16;
             // byte offset of (image n, channel cg * 16, row ya, pixel k0) in the NCHW tensor; the window of the LAST
             // channel of the LAST stage must end inside the tensor: slide the window back (its first bytes then
             // belong to pixels in front of the segment and are dropped)
-            int off = (int)m24(m24(n, a.C) + cg * CI, HW) + (int)m24(ya, W) + k0;
-            const int over = run_ok ? off + (kPair ? a.pt_pair_in : 0) + (a.C - KC + CI - 1) * HW + 16 - total : 0;
+            int off = (int)m24(m24(n, a.C) + cg * CI, THW) + (int)m24(kS2 ? 2 * ya : ya, TW) + k0;
+            const int over = run_ok ? off + (kPair ? a.pt_pair_in : 0) + (a.C - KCP + CI - 1) * THW + 16 - total : 0;
             if (over > 0) {
                 off -= over;
                 k0 -= over;
@@ -341,15 +288,33 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             s_src[it] = (uint32_t)off;
             // pixel k of the run is patch pixel (row lo + ya + k / W - v0, k % W): one division, then increments
             const uint32_t kf = k0 < 0 ? 0u : (uint32_t)k0;
-            uint32_t yy = pt_div(kf, W, rW), x = kf - yy * W;
+            // (yy, x) = input row of the run and input pixel; kS2: grid pixel (yy / 2, x / 2), plane (yy & 1, x & 1)
+            uint32_t yy = pt_div(kf, TW, kS2 ? 0.5f * rW : rW), x = kf - yy * TW;
             const uint32_t pr0 = (uint32_t)(lo + ya - v0);
+            if constexpr (kS2) {
+                // LDS offset = row term (grid row yy / 2, plane row yy & 1) + column term (grid column x / 2 + 1, plane column
+                // x & 1), both advanced by additions: the sixteen products of the direct form tipped the instantiation into scratch
+                auto rowterm = [&](uint32_t y2) { return m24(m24(pr0 + (y2 >> 1), W1), PITCH) + (y2 & 1) * (2 * KCP) + cg * CI; };
+                uint32_t rt = rowterm(yy), ct = m24((x >> 1) + 1, PITCH) + (x & 1) * KCP;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int k = k0 + b;
-                const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
-                s_dst[it * 16 + b] = ok ? m24(m24(pr0 + yy, W1) + x + 1, PITCH) + cg * CI : trash;
-                if (k >= 0) {
-                    if (++x == (uint32_t)W) x = 0, ++yy;
+                for (int b = 0; b < 16; ++b) {
+                    const int k = k0 + b;
+                    const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
+                    s_dst[it * 16 + b] = ok ? rt + ct : trash;
+                    if (k >= 0) {
+                        ct += (x & 1) ? (uint32_t)(PITCH - KCP) : (uint32_t)KCP;
+                        if (++x == (uint32_t)TW) x = 0, ++yy, rt = rowterm(yy), ct = PITCH;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int k = k0 + b;
+                    const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
+                    s_dst[it * 16 + b] = ok ? m24(m24(pr0 + yy, W1) + x + 1, PITCH) + cg * CI : trash;
+                    if (k >= 0) {
+                        if (++x == (uint32_t)W) x = 0, ++yy;
+                    }
                 }
             }
         }
@@ -358,49 +323,27 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // ---- staging of one stage, cut into NP pieces so that the K loop can place them one per MFMA slot:
     // NHWC sd[q] = item q's 16 bytes; NCHW sd[c] = 16 pixels of channel c of the lane's channel group
     v4i sd[NP];
-    // (kS2: the base lies one input row in front of the tensor, the stage adds ky rows)
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(static_cast<const char *>(a.in) - (kS2 && !kNchw ? (ptrdiff_t)W * a.C : 0)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(static_cast<const char *>(a.in)), 0, 0x7fffffff, 0x00020000);
     uint32_t tr_o[4][CI / 4];  // NCHW: the four pixels of one dword column, transposed
     const uint32_t zp4 = (uint32_t)(a.in_zp & 0xff) * 0x01010101u;
     auto stage_load_one = [&](int stage, int it, auto qc) {
         constexpr int q = decltype(qc)::value;
         // NHWC: buffer loads (descriptor + 32-bit lane offset + scalar stage offset): as plain global loads the
         // optimiser turns the loop-invariant lane offsets into 64-bit pointers held across the K loop
-        // kPair: staging `stage` = the only stage of tile `stage`.  kS2: stage = (channel group, filter row ky)
-        if constexpr (kS2) {
-            const int cgs = (stage * 43) >> 7, ky = stage - 3 * cgs;  // stage / 3 for stage < 128
-            if constexpr (!kNchw) {
-                // ky = 0 of a top row (flagged) would start in front of the tensor: read the row itself (replaced at the write)
-                const uint32_t o = s_src[q] + ((ky == 0 && (int32_t)s_dst[q] < 0) ? (uint32_t)(W * a.C) : 0u);
-                sd[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)o, cgs * KC + ky * (W * a.C), 0));
-            } else {
-                // ky = 0 of a top row would start in front of the tensor: read the row itself (replaced at the write)
-                const char *base = static_cast<const char *>(a.in) + ((size_t)cgs * KC * HW + (size_t)(ky * W)) - W;
-                const uint32_t o = s_src[0] + ((ky == 0 && (int32_t)s_top < 0) ? (uint32_t)W : 0u);
-                sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * HW))));
-            }
-        } else if constexpr (!kNchw) {
-            sd[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)s_src[q], kPair ? stage * a.pt_pair_in : stage * KC, 0));
+        // kPair: staging `stage` = the only stage of tile `stage`
+        if constexpr (!kNchw) {
+            sd[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)s_src[q], kPair ? stage * a.pt_pair_in : stage * KCP, 0));
         } else {
-            const char *base = static_cast<const char *>(a.in) + (kPair ? (size_t)stage * (uint32_t)a.pt_pair_in : (size_t)stage * KC * HW);
+            const char *base = static_cast<const char *>(a.in) + (kPair ? (size_t)stage * (uint32_t)a.pt_pair_in : (size_t)stage * KCP * THW);
             const uint32_t o = (!kTwo || it == 0) ? s_src[0] : s_src[NSRC - 1];
-            sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * HW))));
+            sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * THW))));
         }
     };
-    // top: (kS2) the stage being written is a ky = 0 one -- flagged items (rows with oy == 0) get the zero point
-    auto stage_write_one = [&](uint32_t bufoff, int it, auto qc, bool top = false) {
+    auto stage_write_one = [&](uint32_t bufoff, int it, auto qc) {
         constexpr int q = decltype(qc)::value;
         if constexpr (!kNchw) {
-            uint32_t d = s_dst[q];
-            v4i v = sd[q];
-            if constexpr (kS2) {
-                const bool t = top && (int32_t)d < 0;
-                d &= 0x7fffffffu;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = t ? (int)zp4 : v[e];
-            }
-            *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = v;
+            const uint32_t d = s_dst[q];
+            *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = sd[q];
         } else {
             // piece q = (dword column jd, channel quad ca): one 4 x 4 byte block of the CI channels x 16 pixels ->
             // 16 pixels x CI channels transposition; after the last quad the column's four pixels go out
@@ -415,18 +358,13 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             if constexpr (ca == QC - 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    uint32_t d = (!kTwo || it == 0) ? s_dst[4 * jd + e] : s_dst[NDST - 16 + 4 * jd + e];
-                    bool t = false;
-                    if constexpr (kS2) {
-                        t = top && (int32_t)d < 0;
-                        d &= 0x7fffffffu;
-                    }
+                    const uint32_t d = (!kTwo || it == 0) ? s_dst[4 * jd + e] : s_dst[NDST - 16 + 4 * jd + e];
                     char *dp = smem + (d >= 2 * bufb ? d : d + bufoff);
                     if constexpr (CI == 16) {
                         const v4i v = {(int)tr_o[e][0], (int)tr_o[e][1], (int)tr_o[e][2], (int)tr_o[e][3]};
                         *reinterpret_cast<v4i *>(dp) = v;
                     } else {
-                        *reinterpret_cast<uint2 *>(dp) = make_uint2(t ? zp4 : tr_o[e][0], t ? zp4 : tr_o[e][1]);
+                        *reinterpret_cast<uint2 *>(dp) = make_uint2(tr_o[e][0], tr_o[e][1]);
                     }
                 }
             }
@@ -449,7 +387,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             *reinterpret_cast<v4i *>(smem + (sb / SLOTS ? bufb : 0u) + m24(m24(pr, W1), PITCH) + (sb % SLOTS) * 16) = zv;
         }
         const uint32_t per_row = (uint32_t)W * S2;
-        const uint32_t n1 = kS2 ? 0u : (uint32_t)*inv_cnt * per_row;  // (kS2: only the left padding column)
+        const uint32_t n1 = (uint32_t)*inv_cnt * per_row;
         const float rper = a.pt_rW * (1.0f / S2);  // exact: S2 is a power of two
         for (uint32_t u = tid; u < n1; u += NT) {
             const uint32_t i = pt_div(u, per_row, rper), r2 = u - m24(i, per_row);
@@ -470,8 +408,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
 #pragma unroll
         for (int j = 0; j < NB; ++j) {  // thirteen table reads, then the arithmetic
             const bool ok = (uint32_t)((hb + j) * 32 + frow) < (uint32_t)RW && row0 + pg * R + (int)r < total_rows;
-            if constexpr (kS2) prow[j] = ok ? pg * R + r + 1 : 1;  // the tile row itself
-            else prow[j] = trow_tab[ok ? pg * R + r : 0];          // patch row of the pixel's own input row (>= 1)
+            prow[j] = trow_tab[ok ? pg * R + r : 0];  // patch row of the pixel's own (grid) row (>= 1)
             xs[j] = ok ? x : 0;
             x += d32x, r += d32r;
             if (x >= (uint32_t)OW) x -= OW, ++r;
@@ -496,7 +433,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     zero_acc();
 
     mark();  // 7: pixel offsets computed
-    static_for<NP>([&](auto qc) { stage_write_one(0, 0, qc, kS2); });
+    static_for<NP>([&](auto qc) { stage_write_one(0, 0, qc); });
     if constexpr (kTwo) {
         if (a.pt_nitc > 1) {
             static_for<NP>([&](auto qc) { stage_load_one(0, 1, qc); });
@@ -523,10 +460,18 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     v4i rb[NB];
     auto tap_off = [&](int step) -> uint32_t {  // LDS offset of a K step's (tap, sub-step); wave-uniform
         const int tap = step / UI, ui = step - tap * UI;
-        if constexpr (kS2)  // kx = 0: slot ox, kx = 1: the even half (Wo + 1 + ox), kx = 2: slot ox + 1
-            return m24((uint32_t)(tap == 1 ? OW + 1 : tap == 0 ? 0 : 1), PITCH) + ui * (KP * 32);
         const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
         return m24((uint32_t)(ty * W1 + tx), PITCH) + ui * (KP * 32);
+    };
+    // kS2 (nine steps per stage = one loop iteration: the step IS the tap, a compile-time constant): filter tap (ky, kx) reads
+    // grid pixel (ky != 0, kx != 0) further on than tap (0, 0)'s, plane (ky != 1, kx != 1).  (As run-time scalar arithmetic per
+    // step the instantiation went into scratch.)
+    const uint32_t w1p = m24((uint32_t)W1, PITCH);
+    auto tap_off_s2 = [&](auto tc) -> uint32_t {
+        constexpr int tap = decltype(tc)::value;
+        constexpr int ky = tap / 3, kx = tap % 3;
+        constexpr int gx = kx != 0, plane = (ky != 1) * 2 + (kx != 1);
+        return (ky != 0 ? w1p : 0u) + gx * PITCH + plane * KCP;
     };
     // ONE loop body for every step (nine steps per iteration: the weight ring's index is static): the accumulators
     // have a single chain of definitions through the loop, and the staging pieces of the next stage sit in small
@@ -536,7 +481,13 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     auto kstep = [&](auto passc, auto fc, int s, int step, uint32_t bufoff, bool more) {
         constexpr int F = decltype(fc)::value;
         constexpr bool kStage = !(kPair && decltype(passc)::value == 1);  // the second tile of a pair stages nothing
-        const uint32_t cur = bufoff + tap_off(step), nxt = bufoff + tap_off(step + 1);
+        uint32_t cur, nxt;
+        if constexpr (kS2) {
+            cur = bufoff + tap_off_s2(std::integral_constant<int, F>{});
+            nxt = bufoff + tap_off_s2(std::integral_constant<int, F + 1>{});  // (F + 1 == 9: a read nobody uses, inside the buffer)
+        } else {
+            cur = bufoff + tap_off(step), nxt = bufoff + tap_off(step + 1);
+        }
         const uint32_t nbufoff = bufb - bufoff;
         // the weights of FR - 1 steps ahead (the plan pads the copy: no tail test)
         // (kPair: both tiles read the same NSTEP fragments; the ring runs on into the second tile's first ones)
@@ -547,7 +498,6 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         // requested only four steps ahead, the LDS writes of step 4 waited ~3 000 cycles for HBM in every stage
         const bool two = kTwo && a.pt_nitc > 1;
         const bool do_write0 = F == FW && more && step == FW;
-        const bool top_next = kS2 && s + 1 == 3 * (((s + 1) * 43) >> 7);  // the stage being written is a ky = 0 one
         const bool do_write1 = F == 7 && more && step == 7 && two;
         const bool do_load = !kPair && (two ? F == 8 && step == 8 : F == FL && step == FL) && s + 2 < nstg;
         static_for<NB>([&](auto jc) {
@@ -570,8 +520,8 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             }
             if constexpr (kStage && F == FW) {
                 if (do_write0) {
-                    stage_write_one(nbufoff, 0, std::integral_constant<int, P0>{}, top_next);
-                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 0, std::integral_constant<int, P1>{}, top_next);
+                    stage_write_one(nbufoff, 0, std::integral_constant<int, P0>{});
+                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 0, std::integral_constant<int, P1>{});
                 }
             }
             if constexpr (kStage && kTwo && F == 7) {
@@ -598,7 +548,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         const uint32_t bufoff = (s & 1) ? bufb : 0u;
         const bool more = kPair ? PASS == 0 : st + 1 < nstg;
         {
-            const uint32_t cur = bufoff + tap_off(0);
+            const uint32_t cur = bufoff + (kS2 ? tap_off_s2(std::integral_constant<int, 0>{}) : tap_off(0));
             static_for<D>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 rb[j] = *reinterpret_cast<const v4i *>(smem + (pbase[j] + cur));
@@ -925,7 +875,7 @@ static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipS
     if constexpr (kF16) {  // stride 1, no pair mode, eight waves (the host sets the bit: patch_choose_geom)
         patch_launch_nw<true, 0, false, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
     } else if (PT_S2(a.pt_geom)) {
-        if constexpr (KC == 64 && KP <= 2) patch_launch_nw<false, EPI, kNchw, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
+        if constexpr (KC == 128 && KP == 1 && kNchw) patch_launch_nw<false, EPI, true, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
     } else if (PT_NW8(a.pt_geom)) {
         if constexpr (KP == 1) {  // pair mode exists for eight waves, one K part
             if (a.pt_pair_in) return patch_launch_nw<false, EPI, kNchw, true, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);

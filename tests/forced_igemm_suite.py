@@ -53,7 +53,7 @@ SHAPES = [
     dict(c=128, co=160, h=3, w=5, n=37),
     dict(c=64, co=64, h=5, w=300, n=1),
     dict(c=192, co=48, h=33, w=17, n=2, act=2),
-    # its stride-2 form (stage = 64 channels x one filter row, columns de-interleaved by parity): top padding rows, tiles
+    # its stride-2 form (NCHW: a stride-1 layer on the half-resolution grid, four input planes per grid pixel): top padding rows, tiles
     # that straddle images, a ragged last tile, 16-pixel NCHW segments that end inside a row, K parts, a wide row
     dict(c=64, co=64, h=56, w=56, n=2, stride=(2, 2)),
     dict(c=128, co=96, h=28, w=28, n=5, stride=(2, 2), act=1),
