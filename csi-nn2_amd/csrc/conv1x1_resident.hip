@@ -189,12 +189,15 @@ bool conv1x1_resident_pick(const ConvArgs &a)
     static const char *env = getenv("SHL_MI355X_PWRES");  // "0" never, "1" always (A/B), default: by size
     if (env && env[0] == '0') return false;
     if (env && env[0] == '1') return true;
-    // from ~5 blocks of 32 pixels per workgroup (MobileNetV1 from batch ~96 on the 14 x 14 maps; ~3 with K = 1024, where a
-    // block is 32 MFMAs): below that the weights' prologue is not paid back.  MobileNetV1 at batch 128, us in the pass
-    // (profiles/r05_notes.md): 128 -> 256 @28 16.2 -> 15.2, 256 -> 256 @28 21.2 -> 17.8, 256 -> 512 @14 13.2 -> 10.7,
-    // 512 -> 512 @14 16.8 -> 13.5, 1024 -> 1024 @7 15.8 -> 12.7; 512 -> 1024 @7 (3 blocks per workgroup) 8.6 -> 9.1: not taken
+    // from so many blocks of 32 pixels per workgroup that the weights' prologue and the cold start of the stream are paid
+    // back -- more of them the shallower K is (a block is K / 32 MFMAs against one 110-instruction epilogue): measured over
+    // batches 16 .. 256 of MobileNetV1's pointwise layers against what the rules / the tuner pick without this kernel
+    // (profiles/r05_mobilenet_batch_sweep.txt): K = 128 from 12 (128 -> 256 @28: batch 128 17.0 vs 18.1 us, batch 96 17.5 vs
+    // 13.8), K = 256 from 6 (256 -> 256 @28 from batch 64, 256 -> 512 @14 from 128), K = 512 from 4.5 (512 -> 512 @14 from
+    // batch 96: 12.6 vs 18.6; 512 -> 1024 @7 from 192), K = 1024 from 2.25 (1024 -> 1024 @7 from batch 96: 15.3 vs 16.2)
     const int bpt = a.C >= 512 ? 1 : 512 / a.C;
-    return (int64_t)ntiles * bpt * ncb >= (a.C >= 1024 ? 3 : 5) * 256;
+    const int need4 = a.C >= 1024 ? 9 : a.C >= 512 ? 18 : a.C >= 256 ? 24 : 48;  // blocks per workgroup x 4
+    return (int64_t)ntiles * bpt * ncb * 4 >= (int64_t)need4 * 256;
 }
 
 int launch_conv1x1_resident(const ConvArgs &a, hipStream_t s)
