@@ -57,38 +57,35 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const void *in, voi
     store_requant(out, i, avg, dtype, so, zo);  // output is [N, 1, 1, C] / [N, C, 1, 1]: index n*C + c
 }
 
-// int8 NHWC with at most 64 pixels (every MobileNet / ResNet tail): a thread owns 4 consecutive
-// channels, requests ALL its H*W dwords up front (one memory round trip instead of H*W dependent
-// ones) and then adds them in the reference's (y, x) order.
-__global__ __launch_bounds__(256) void global_avgpool_nhwc_i8_kernel(const void *in, void *out, int64_t ngroups,
-                                                                     int cgroups, int HW, float si, float zi,
-                                                                     float so, float zo)
+// int8 NHWC with at most 64 pixels (every MobileNet / ResNet tail): ONE channel per thread -- the reference's sum is a
+// chain of H*W dependent fp32 additions per channel, so the channels are all the parallelism there is (1 024 threads for
+// MobileNetV1; round 4 ran four such chains per thread).  A thread requests ALL the H*W dwords that hold its channel up
+// front (one memory round trip; the four threads of a dword share the load) and then adds its byte of each in the
+// reference's (y, x) order.
+__global__ __launch_bounds__(64) void global_avgpool_nhwc_i8_kernel(const void *in, void *out, int64_t nc, int C, int HW,
+                                                                    float si, float zi, float so, float zo)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, channel group)
-    if (i >= ngroups) return;
-    const int64_t n = i / cgroups;
-    const int g = (int)(i - n * cgroups);
-    const uint32_t *src = static_cast<const uint32_t *>(in) + n * HW * cgroups + g;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, c), c fastest
+    if (i >= nc) return;
+    const int64_t n = i / C;
+    const int c = (int)(i - n * C);
+    const int cgroups = C >> 2;
+    const uint32_t *src = static_cast<const uint32_t *>(in) + n * HW * cgroups + (c >> 2);
+    const int sh = 8 * (c & 3);
     uint32_t v[64];
 #pragma unroll
     for (int p = 0; p < 64; ++p)
         if (p < HW) v[p] = src[(int64_t)p * cgroups];
-    float total[4] = {0.f, 0.f, 0.f, 0.f};
+    float total = 0.f;
 #pragma unroll
     for (int p = 0; p < 64; ++p) {
         if (p < HW) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = __fmul_rn(__fsub_rn((float)(int8_t)(v[p] >> (8 * e)), zi), si);
-                total[e] = __fadd_rn(total[e], x);
-            }
+            const float x = __fmul_rn(__fsub_rn((float)(int8_t)(v[p] >> sh), zi), si);
+            total = __fadd_rn(total, x);
         }
     }
-    int q[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        q[e] = sat8_from_float(__fadd_rn(rintf(__fdiv_rn(__fdiv_rn(total[e], (float)HW), so)), zo));
-    static_cast<uint32_t *>(out)[i] = pack4_i8(q[0], q[1], q[2], q[3]);
+    const int q = sat8_from_float(__fadd_rn(rintf(__fdiv_rn(__fdiv_rn(total, (float)HW), so)), zo));
+    static_cast<int8_t *>(out)[i] = (int8_t)q;
 }
 
 // The reference's running sum  acc = (float)((double)acc + e[j]),  j = 0 .. cnt-1  (softmax.c:21-66) is a
@@ -226,10 +223,9 @@ extern "C" int shl_mi355x_global_avgpool2d(const void *input_dev, void *output_d
     const int64_t nc = (int64_t)batch * channels;
     if (nc == 0) return SHL_MI355X_OK;
     if (dtype == SHL_MI355X_I8 && layout == SHL_MI355X_NHWC && channels % 4 == 0 && pixels <= 64) {
-        const int64_t ngroups = nc / 4;
-        // 64 threads per workgroup: MobileNetV1's 1024 channels spread over 4 CUs
-        hipLaunchKernelGGL(shl::global_avgpool_nhwc_i8_kernel, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0,
-                           (hipStream_t)stream, input_dev, output_dev, ngroups, (int)(channels / 4), (int)pixels,
+        // 64 threads per workgroup: MobileNetV1's 1024 channels spread over 16 CUs
+        hipLaunchKernelGGL(shl::global_avgpool_nhwc_i8_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0,
+                           (hipStream_t)stream, input_dev, output_dev, nc, (int)channels, (int)pixels,
                            in_scale, (float)in_zp, out_scale, (float)out_zp);
         SHL_HIP(hipGetLastError());
         return SHL_MI355X_OK;

@@ -16,7 +16,7 @@ for n in (1000,):
     # avgpool 7x7x1024
     x = rng.integers(-128,128,(1,7,7,1024),dtype=np.int8); di=dev.alloc(x.size); do=dev.alloc(1024); dev.upload(di,x)
     hip.shl_mi355x_graph_begin(s)
-    for _ in range(50): hip.shl_mi355x_global_avgpool2d(di, do, 0, 1, 1, 1024, 49, 0.0625, -5, 0.0625, -5, s)
+    for _ in range(50): hip.shl_mi355x_global_avgpool2d(di, do, 0, 0, 1, 1024, 49, 0.0625, -5, 0.0625, -5, s)
     g = hip.shl_mi355x_graph_end(s); hip.shl_mi355x_graph_launch(g, s); hip.shl_mi355x_stream_sync(s)
     hip.shl_mi355x_event_record(ev0, s); hip.shl_mi355x_graph_launch(g, s); hip.shl_mi355x_event_record(ev1, s)
     hip.shl_mi355x_event_elapsed_ms(ev0, ev1, C.byref(ms)); print("avgpool: %.2f us" % (ms.value*1e3/50))
