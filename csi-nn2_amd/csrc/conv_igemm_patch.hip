@@ -175,7 +175,8 @@ bool patch_shape_uncached(int n, int H, int W, int C, int Co, bool nchw, int geo
     const int64_t total_rows = (int64_t)n * HO;
     if ((int64_t)n * H + n >= (1 << 22) || (int64_t)n * H * W >= (1 << 24) || (int64_t)n * C >= (1 << 24)) return false;  // 24-bit multiplies
     if ((int64_t)n * H * W * C >= (1ll << 31) - 65536) return false;  // 32-bit source offsets
-    int rows = PT_PIX / WO;
+    int rows = PT_NBT(geom) * 32 / WO;  // a pixel group fits its wave role's blocks
+    if (rows < 1) return false;
     if ((int64_t)rows * pg > total_rows) rows = (int)((total_rows + pg - 1) / pg);
     int top = 0;  // the most rows that fit
     for (; rows >= 1 && !top; --rows) {
@@ -200,11 +201,17 @@ bool patch_shape_uncached(int n, int H, int W, int C, int Co, bool nchw, int geo
     return true;
 }
 
-int make_geom(int kc, int pg, int ob, int kp)
+int make_geom(int kc, int pg, int ob, int kp, int nbt = PT_NB)
 {
     static const char *env = getenv("SHL_MI355X_PATCH_WAVES");  // "4": one wave per SIMD (A/B, tests)
     const int nw8 = !(env && env[0] == '4');
-    return kc | pg << 8 | ob << 12 | kp << 16 | nw8 << 20;
+    return kc | pg << 8 | ob << 12 | kp << 16 | nw8 << 20 | (nbt == 7 ? 1 : nbt == 4 ? 2 : 0) << 24;
+}
+
+// small tiles (7 / 4 pixel blocks per wave role): the instantiations that exist (conv_igemm_patch_kernel.h:patch_launch_one)
+bool small_tiles_ok(bool nchw, bool f16, int kc, int pg, int ob, int kp, int g)
+{
+    return nchw && !f16 && kc == 128 && pg == 1 && ob == 4 && kp == 1 && PT_NW8(g);
 }
 
 }  // namespace
@@ -224,17 +231,24 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     // NHWC keeps its stride-2 layers on the block-tile kernels (28 / 22 / 23 us for ResNet-50's at batch 128); NCHW saves the
     // re-layout passes around them
     if (s2 && !nchw) return 0;
-    if (env && env[0] && env[0] != '0' && env[0] != '1') {
-        int pg = 0, ob = 0, kp = 0;
-        if (sscanf(env, "%d,%d,%d", &pg, &ob, &kp) == 3 && pg * ob * kp == 4 && u % kp == 0 && pg != 4 && !(pg == 2 && kp == 2) && !(s2 && kp != 1)) {
+    if (env && strchr(env, ',')) {  // ("0" / "1" alone are the on / off switch; round 5: "1,4,1" used to be read as "1")
+        int pg = 0, ob = 0, kp = 0, nbt = PT_NB;
+        if (sscanf(env, "%d,%d,%d,%d", &pg, &ob, &kp, &nbt) >= 3 && pg * ob * kp == 4 && u % kp == 0 && pg != 4 && !(pg == 2 && kp == 2) && !(s2 && kp != 1)) {
             PatchShape ps;
-            int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0) | (f16 ? 1 << 23 | 1 << 20 : 0);
+            if (nbt != 7 && nbt != 4) nbt = PT_NB;
+            if (nbt != PT_NB && !small_tiles_ok(nchw, f16, kc, pg, ob, kp, make_geom(kc, pg, ob, kp))) nbt = PT_NB;
+            int g = make_geom(kc, pg, ob, kp, nbt) | (s2 ? 1 << 21 : 0) | (f16 ? 1 << 23 | 1 << 20 : 0);
             if (s2 && !PT_NW8(g)) return 0;  // the stride-2 form has eight waves
             if (!s2 && !f16 && !patch_shape(batch, d.in_h, d.in_w, cbytes, d.out_c, nchw, g, &ps)) g &= ~(1 << 20);  // four waves take two NCHW rounds
             return patch_shape(batch, d.in_h, d.in_w, cbytes, d.out_c, nchw, g, &ps) ? g : 0;
         }
     }
-    static const int cand[][3] = {{1, 4, 1}, {2, 2, 1}, {1, 2, 2}, {1, 1, 4}};
+    // {pixel groups, channel blocks, K parts, pixel blocks per role}.  The 7-block form: maps of 14 x 14 pixels (one image =
+    // 6.1 blocks) as one round of 256 tiles without K parts -- ResNet-50 NCHW at batch 128: 256 -> 256 @14 24.2 -> 22.3 us (no
+    // exchange of partial sums), 256 -> 256 @28 stride 2 39.3 -> 29.1 (its 13-block tiles were half empty).  The 4-block form
+    // (7 x 7 maps) exists for SHL_MI355X_PATCH=1,4,1,4 only: 512 -> 512 @7 28.9 vs 27.5 us with four K parts, 512 -> 512 @14
+    // stride 2 41.1 vs 35.1 through the re-layout passes (16 stages of nine 4-block steps are all barrier)
+    static const int cand[][4] = {{1, 4, 1, PT_NB}, {2, 2, 1, PT_NB}, {1, 2, 2, PT_NB}, {1, 1, 4, PT_NB}, {1, 4, 1, 7}};
     const int ocblks = (d.out_c + 31) / 32;
     int best = 0;
     double best_cost = 0;
@@ -245,28 +259,25 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     if (kc_try != kc && !f16) break;
     kc = kc_try, u = kc / 32;
     for (const auto &c : cand) {
-        const int pg = c[0], ob = c[1], kp = c[2];
+        const int pg = c[0], ob = c[1], kp = c[2], nbt = c[3];
         if (u % kp != 0 || (s2 && kp != 1)) continue;  // (stride 2: one K sub-step per tap and stage)
         if (ob > 1 && ob / 2 >= ocblks) continue;  // half of the channel blocks of a tile would be empty
+        if (nbt != PT_NB && !small_tiles_ok(nchw, f16, kc, pg, ob, kp, make_geom(kc, pg, ob, kp))) continue;
         PatchShape ps;
-        int g = make_geom(kc, pg, ob, kp) | (s2 ? 1 << 21 : 0) | (f16 ? 1 << 23 | 1 << 20 : 0);  // binary16: eight waves
+        int g = make_geom(kc, pg, ob, kp, nbt) | (s2 ? 1 << 21 : 0) | (f16 ? 1 << 23 | 1 << 20 : 0);  // binary16: eight waves
         if (s2 && !PT_NW8(g)) return 0;  // the stride-2 form has eight waves
         if (!patch_shape(batch, d.in_h, d.in_w, cbytes, d.out_c, nchw, g, &ps)) {
-            if (s2 || f16) continue;
+            if (s2 || f16 || nbt != PT_NB) continue;
             g &= ~(1 << 20);  // four waves take two NCHW staging rounds
             if (!patch_shape(batch, d.in_h, d.in_w, cbytes, d.out_c, nchw, g, &ps)) continue;
         }
         const int64_t tiles = (int64_t)ps.nt_m * ps.nt_n;
         const double rounds = (double)((tiles + 255) / 256);
-        // per tile and wave: a K loop over K / kp for 13 pixel blocks + fixed costs (prologue, epilogue; the exchange
+        // per tile and wave: a K loop over K / kp for the role's pixel blocks + fixed costs (prologue, epilogue; the exchange
         // of partial sums for K parts)
-        // (stride 2 has one K part: what separates its candidates is how much of a 13-block wave they fill -- 256 -> 256 @28
-        // is 128 tiles of 28 rows with four channel blocks per tile, or 256 tiles of 2 x 14 rows with two: the second puts a
-        // tile on every CU)
-        const double fill = s2 ? (double)ps.rows * (d.in_w / 2) / PT_PIX : 1.0;
-        const double total = rounds * fill * (1.0 / kp + 0.12 + (kp > 1 ? 0.04 : 0.0));
+        const double total = rounds * ((double)nbt / PT_NB / kp + 0.12 + (kp > 1 ? 0.04 : 0.0));
         static const char *dbg = getenv("SHL_MI355X_DEBUG_GEOM");
-        if (dbg) fprintf(stderr, "patch geom %d,%d,%d nw%d%s: rows %d prows %d tiles %d x %d lds %d nitc %d pair %d cost %.3f\n", pg, ob, kp, PT_NW8(g) ? 8 : 4,
+        if (dbg) fprintf(stderr, "patch geom %d,%d,%d/%d nw%d%s: rows %d prows %d tiles %d x %d lds %d nitc %d pair %d cost %.3f\n", pg, ob, kp, nbt, PT_NW8(g) ? 8 : 4,
                          s2 ? " s2" : "", ps.rows, ps.prows, ps.nt_m, ps.nt_n, ps.lds, ps.nitc, ps.pair_dn, total);
         if (!best || total < best_cost - 1e-9) best = g, best_cost = total;
     }

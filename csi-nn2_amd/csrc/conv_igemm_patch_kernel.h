@@ -26,6 +26,7 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 #define PT_NW8(g) (((g) >> 20) & 1)  // eight waves (two per SIMD) instead of four
 #define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (a stride-1 layer on the half-resolution grid, four planes per pixel)
 #define PT_NT(g) (((g) >> 22) & 1)   // NHWC output stored non-temporally (set per launch by patch_setup)
+#define PT_NBT(g) ((((g) >> 24) & 3) == 1 ? 7 : (((g) >> 24) & 3) == 2 ? 4 : 13)  // MFMA pixel blocks per wave role (bits 24 - 25: 0 -> 13, 1 -> 7, 2 -> 4)
 #define PT_F16(g) (((g) >> 23) & 1)  // binary16 (NHWC, stride 1): the same bytes through v_mfma_f32_32x32x16_f16, fp32 epilogue
 
 // x / d for x < 2^22 (q is within one of the quotient after the float multiply)
@@ -74,7 +75,10 @@ static __device__ unsigned long long g_pt_span[2 * 1024];  // SHL_MI355X_DEBUG=3
 // same bytes (lane (row, half) = bytes 16 half .. +15 of the row's 32-byte K slab).  Different: fp32 accumulators, K
 // parts summed in fp32 (part order: deterministic), epilogue = + bias, relu / relu6, the reference's f32 -> f16
 // rounding (common.h:finish_f16), two 16-byte stores of 8 channels per lane and block.
-template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW, int NBW>
+// NBT: pixel blocks per wave role (13; 7 / 4 for maps of 14 x 14 / 7 x 7 pixels: a tile of whole images then fills its blocks, a
+// layer is one round of 256 tiles without K parts and their exchange of partial sums, and a stride-2 layer of 512 channels
+// has 256 tiles at all); the two halves of a role take (NBT + 1) / 2 and NBT / 2 of them.
+template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW, int NBW, int NBT = PT_NB>
 __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, const int h)
 {
     static_assert(!kF16 || (!kNchw && !kPair && !kS2), "binary16: NHWC, stride 1");
@@ -87,8 +91,9 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     static_assert(PG * OB * KP == 4, "four wave roles");
     static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
     constexpr int NB = NBW;                  // MFMA pixel blocks of this wave
-    constexpr int HB = NW == 8 ? 7 : 0;      // blocks of half 0 in front of half 1's
-    constexpr int D = NB >= 13 ? PT_D : 4;   // B fragments are read this many MFMAs ahead
+    constexpr int HB = NW == 8 ? (NBT + 1) / 2 : 0;  // blocks of half 0 in front of half 1's
+    constexpr int D = NB >= 13 ? PT_D : (NB > 4 ? 4 : NB - 1);  // B fragments are read this many MFMAs ahead (< NB)
+    static_assert(NB >= 2, "two blocks per wave at least");
     constexpr int NT = NW * 64;              // threads
     constexpr int NIT = PT_NIT * 4 / NW;     // NHWC staging items per lane and stage
     constexpr int CI = NW == 8 ? 8 : 16;     // NCHW staging: channels per item
@@ -509,26 +514,16 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                 rb[j + D - NB] = *reinterpret_cast<const v4i *>(smem + (pbase[j + D - NB] + nxt));
             // the NP staging pieces on the NB slots, IN ORDER (the NCHW transposition finishes a dword column with its
             // last channel quad): slot j takes pieces [j NP / NB, (j + 1) NP / NB)
-            constexpr int P0 = j * NP / NB;
-            constexpr int P1 = (j + 1) * NP / NB - P0 > 1 ? P0 + 1 : -1;
-            static_assert((j + 1) * NP / NB - P0 <= 2 && (j + 1) * NP / NB - P0 >= 1, "one or two pieces per slot");
+            // (one or two pieces with 13 / 7 / 6 blocks; up to four with the 2 .. 4 blocks of the small tiles)
+            constexpr int P0 = j * NP / NB, PN = (j + 1) * NP / NB - P0;
             if constexpr (!kPair && (F == FL || (kTwo && F == 8))) {
-                if (do_load) {
-                    stage_load_one(s + 2, 0, std::integral_constant<int, P0>{});
-                    if constexpr (P1 >= 0) stage_load_one(s + 2, 0, std::integral_constant<int, P1>{});
-                }
+                if (do_load) static_for<PN>([&](auto pc) { stage_load_one(s + 2, 0, std::integral_constant<int, P0 + decltype(pc)::value>{}); });
             }
             if constexpr (kStage && F == FW) {
-                if (do_write0) {
-                    stage_write_one(nbufoff, 0, std::integral_constant<int, P0>{});
-                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 0, std::integral_constant<int, P1>{});
-                }
+                if (do_write0) static_for<PN>([&](auto pc) { stage_write_one(nbufoff, 0, std::integral_constant<int, P0 + decltype(pc)::value>{}); });
             }
             if constexpr (kStage && kTwo && F == 7) {
-                if (do_write1) {
-                    stage_write_one(nbufoff, 1, std::integral_constant<int, P0>{});
-                    if constexpr (P1 >= 0) stage_write_one(nbufoff, 1, std::integral_constant<int, P1>{});
-                }
+                if (do_write1) static_for<PN>([&](auto pc) { stage_write_one(nbufoff, 1, std::integral_constant<int, P0 + decltype(pc)::value>{}); });
             }
             if constexpr (kNchw)
                 acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[j], fa[F % FR], acc[j], 0, 0, 0);  // rows = pixels
@@ -843,27 +838,28 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW>
+template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW, int NBT = PT_NB>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_patch_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (NW == 4) {
+        static_assert(NW == 8 || NBT == PT_NB, "small tiles: eight waves");
         patch_body<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 4, PT_NB>(a, smem, 0);
     } else {
         // the two halves are two straight-line bodies (7 and 6 pixel blocks) behind ONE wave-uniform branch; both pass
         // the same sequence of workgroup barriers
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         if (((((a.debug & 64) != 0) != (kNchw && (kPair || KP == 4))) ? w & 1 : w >> 2) == 0)
-            patch_body<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 7>(a, smem, 0);
+            patch_body<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, (NBT + 1) / 2, NBT>(a, smem, 0);
         else
-            patch_body<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, 6>(a, smem, 1);
+            patch_body<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, 8, NBT / 2, NBT>(a, smem, 1);
     }
 }
 
-template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW>
+template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW, int NBT = PT_NB>
 static void patch_launch_nw(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
-    auto kernel = conv_igemm_patch_kernel<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, NW>;
+    auto kernel = conv_igemm_patch_kernel<kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, NW, NBT>;
     static LdsOptIn opted;
     lds_opt_in(opted, reinterpret_cast<const void *>(kernel), PT_LDS_MAX);
     hipLaunchKernelGGL(kernel, dim3(tiles), dim3(NW * 64), lds, s, a);
@@ -874,6 +870,18 @@ static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipS
 {
     if constexpr (kF16) {  // stride 1, no pair mode, eight waves (the host sets the bit: patch_choose_geom)
         patch_launch_nw<true, 0, false, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+    } else if (PT_NBT(a.pt_geom) != PT_NB) {
+        // small tiles (7 / 4 blocks per role): NCHW, eight waves, one K part, four channel blocks, 128-byte stages
+        if constexpr (KC == 128 && KP == 1 && kNchw && PG == 1 && OB == 4) {
+            const bool s2 = PT_S2(a.pt_geom) != 0;
+            if (PT_NBT(a.pt_geom) == 7) {
+                if (s2) patch_launch_nw<false, EPI, true, false, true, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
+                else patch_launch_nw<false, EPI, true, false, false, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
+            } else {
+                if (s2) patch_launch_nw<false, EPI, true, false, true, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
+                else patch_launch_nw<false, EPI, true, false, false, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
+            }
+        }
     } else if (PT_S2(a.pt_geom)) {
         if constexpr (KC == 128 && KP == 1 && kNchw) patch_launch_nw<false, EPI, true, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
     } else if (PT_NW8(a.pt_geom)) {

@@ -63,6 +63,9 @@ VARIANTS = [
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="2,2,1"), "patch"),
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="1,2,2"), "patch"),
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="1,1,4"), "patch"),
+    # ... with 7 / 4 pixel blocks per wave role (NCHW, eight waves: maps of 14 x 14 / 7 x 7 pixels; NHWC shapes keep 13)
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="1,4,1,7"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH="1,4,1,4"), "patch"),
     # ... and with one wave per SIMD (13 pixel blocks per wave) instead of two (7 + 6)
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_WAVES="4"), "patch"),
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_WAVES="4", SHL_MI355X_PATCH="1,2,2"), "patch"),

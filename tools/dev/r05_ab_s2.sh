@@ -6,7 +6,7 @@ cp csi-nn2_amd/lib/libshl_mi355x.so /tmp/var.so
 for rep in 1 2; do for which in base var; do
   if [ $which = base ]; then cp csi-nn2_amd/lib_base/libshl_mi355x.so csi-nn2_amd/lib/libshl_mi355x.so; else cp /tmp/var.so csi-nn2_amd/lib/libshl_mi355x.so; fi
   echo "== $which"
-  timeout 300 python tools/kbench.py --set resnet --batch 128 --layout NCHW 2>&1 | tail -9 | grep "s2\|TOTAL"
+  timeout 300 python tools/kbench.py --set resnet --batch 128 --layout NCHW 2>&1 | tail -9 | grep "s2\|256@14\|TOTAL"
   timeout 300 python bench.py --workload resnet50_3x3 --layout NCHW --no-configs --no-cpu-baseline --steps 20 --windows 3 2>/dev/null \
       | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('PASS ms', d['ms_per_step'])"
 done; done
