@@ -12,6 +12,7 @@ hipcc cross-compiles for gfx950 without a GPU.
 """
 import argparse
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -60,7 +61,7 @@ def spilled_kernels(usage_file):
 # the row-patch kernels: every eight-wave instantiation (the ones that run ResNet-50; the four-wave ones are a fallback
 # and a test switch) must stay free of scratch -- they sit at 256 registers, and a kernel with scratch pays for it at
 # every launch (profiles/r04_notes.md: +15 us on a 6-us kernel)
-PATCH_SOURCES = ("conv_igemm_patch.hip", "conv_igemm_patch_nchw.hip", "conv_igemm_patch_f16.hip")
+PATCH_SOURCES = ("conv_igemm_patch.hip", "conv_igemm_patch_nchw.hip", "conv_igemm_patch_f16.hip", "conv_igemm_patch_nchw_f16.hip")
 
 
 def patch_kernels_with_scratch(usage_file):
@@ -80,7 +81,8 @@ def patch_kernels_with_scratch(usage_file):
                 # them: 128 -> 128 @56 stride 2 at batch 128 34.1 - 35.2 -> 30.7 - 31.0 us (profiles/r05_notes.md)
                 if "ELb1ELb0ELb1ELi128E" in name and n <= 64:
                     continue
-                if n > (12 if known else 0) and "conv_igemm_patch_kernel" in name and ("Li8EEEv" in name or "Li8ELb1EEEv" in name or "Li8ELb0EEEv" in name):
+                # (... ELi<NW>ELi<NBT>EEEv: eight waves, 13 / 7 / 4 pixel blocks per role)
+                if n > (12 if known else 0) and "conv_igemm_patch_kernel" in name and re.search(r"ELi8ELi\d+EEEvNS_8ConvArgsE", name):
                     bad.append("%s (%d bytes)" % (name, n))
     return bad
 

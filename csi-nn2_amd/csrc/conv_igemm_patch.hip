@@ -48,8 +48,8 @@ bool patch_supports(const shl_mi355x_conv_desc &d)
 {
     if (d.group != 1) return false;
     if (d.dtype == SHL_MI355X_F16) {
-        // binary16: stride 1, NHWC tensors (the NCHW staging -- which the stride-2 form builds on -- transposes BYTES); an NCHW layer meets
-        // the kernel on the NHWC view of conv_forward's re-layout path
+        // binary16: stride 1; NCHW layers natively (8 x 8 transposition of two-byte elements in the staging), or -- when the
+        // NCHW item budget does not cover a stage -- on the NHWC view of conv_forward's re-layout path
         static const char *f16_env = getenv("SHL_MI355X_PATCH_F16");  // "0": off (A/B)
         if (f16_env && f16_env[0] == '0') return false;
         if (d.stride_h != 1 || d.stride_w != 1) return false;
@@ -65,7 +65,7 @@ bool patch_supports(const shl_mi355x_conv_desc &d)
         return false;
     }
     if ((d.in_c * pt_esize(d)) % 64 != 0 || d.in_w > PT_PIX) return false;
-    if ((d.layout == SHL_MI355X_NHWC || d.dtype == SHL_MI355X_F16) && d.out_c % 16 != 0) return false;  // 16-byte stores of 16 (binary16: 2 x 8) channels
+    if (d.layout == SHL_MI355X_NHWC && d.out_c % 16 != 0) return false;  // 16-byte stores of 16 (binary16: 2 x 8) channels (NCHW: lane = channel)
     if (d.dtype == SHL_MI355X_I8 && (d.in_zp < -128 || d.in_zp > 127)) return false;
     return true;
 }
@@ -113,9 +113,10 @@ int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, in
     int nitc = 1, spr = 1;
     if (nchw) {
         const int maxrun = (rows * pg + 2 < H ? rows * pg + 2 : H) * (s2 ? 2 * TW : W);
-        spr = (maxrun + 15) / 16;
+        const int es = PT_F16(geom) ? 2 : 1;  // a 16-byte segment of a plane run is 16 / es pixels, an item 8 (16) channels of it
+        spr = (maxrun * es + 15) / 16;
         const int nw8 = PT_NW8(geom);
-        const int items = runs * spr * (kcp / (nw8 ? 8 : 16));
+        const int items = runs * spr * (kcp / ((nw8 ? 8 : 16) * es));
         nitc = (items + (nw8 ? 511 : 255)) / (nw8 ? 512 : 256);
         if (nitc > (nw8 ? 1 : 2)) return -1;
     }
@@ -227,7 +228,7 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     const int cbytes = d.in_c * pt_esize(d);  // the kernel's "channels" are the bytes of a pixel
     int kc = (cbytes % 128 == 0 || s2) ? 128 : 64;  // stride 2: a patch pixel is four planes of 32 channels
     int u = kc / 32;
-    const bool nchw = d.layout == SHL_MI355X_NCHW && !f16;  // binary16 NCHW layers: the NHWC view
+    bool nchw = d.layout == SHL_MI355X_NCHW;  // (binary16 NCHW layers whose stages no NCHW geometry covers: the NHWC view, below)
     // NHWC keeps its stride-2 layers on the block-tile kernels (28 / 22 / 23 us for ResNet-50's at batch 128); NCHW saves the
     // re-layout passes around them
     if (s2 && !nchw) return 0;
@@ -255,8 +256,14 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     // binary16: a pixel is twice the bytes, and a stage's patch is bounded by what one round of staging items moves
     // (64 KB): with 128-byte stages 64 channels @56 get 3 rows per pixel group (168 of 416 pixels, 1 195 tiles); with
     // 64-byte stages 7 rows (512 tiles, two stages).  Both stage sizes are costed; ties keep the larger.
-    for (int kc_try = kc; kc_try >= 64; kc_try -= 64) {
-    if (kc_try != kc && !f16) break;
+    const int kc_top = kc;
+    for (int view = 0; view < 2 && !best; ++view) {
+    if (view == 1) {
+        if (!(f16 && nchw)) break;
+        nchw = false;
+    }
+    for (int kc_try = kc_top; kc_try >= 64; kc_try -= 64) {
+    if (kc_try != kc_top && !f16) break;
     kc = kc_try, u = kc / 32;
     for (const auto &c : cand) {
         const int pg = c[0], ob = c[1], kp = c[2], nbt = c[3];
@@ -280,6 +287,7 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
         if (dbg) fprintf(stderr, "patch geom %d,%d,%d/%d nw%d%s: rows %d prows %d tiles %d x %d lds %d nitc %d pair %d cost %.3f\n", pg, ob, kp, nbt, PT_NW8(g) ? 8 : 4,
                          s2 ? " s2" : "", ps.rows, ps.prows, ps.nt_m, ps.nt_n, ps.lds, ps.nitc, ps.pair_dn, total);
         if (!best || total < best_cost - 1e-9) best = g, best_cost = total;
+    }
     }
     }
     return best;
@@ -333,7 +341,7 @@ bool patch_setup(ConvArgs &a)
     if (!a.in_nchw && a.Co % 16 != 0) return false;
     PatchShape ps;
     const int cbytes = a.C * (PT_F16(a.pt_geom) ? 2 : 1);
-    if (PT_F16(a.pt_geom) && (a.in_nchw || a.sh != 1 || a.sw != 1)) return false;
+    if (PT_F16(a.pt_geom) && (a.sh != 1 || a.sw != 1)) return false;
     if (!patch_shape(a.N, a.H, a.W, cbytes, a.Co, a.in_nchw != 0, a.pt_geom, &ps)) return false;
     a.pt_rows = ps.rows;
     a.pt_prows = ps.prows;
@@ -409,7 +417,7 @@ int launch_conv_igemm_patch(const ConvArgs &a0, hipStream_t s)
     patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
     const unsigned tiles = (unsigned)((ps.pair_dn ? ps.nt_m / 2 : ps.nt_m) * ps.nt_n);
     g_last_nchw = a.in_nchw != 0;
-    const int rc = f16 ? patch_launch_nhwc_f16(a, tiles, ps.lds, s)
+    const int rc = f16 ? (a.in_nchw ? patch_launch_nchw_f16(a, tiles, ps.lds, s) : patch_launch_nhwc_f16(a, tiles, ps.lds, s))
                        : (a.in_nchw ? patch_launch_nchw(a, tiles, ps.lds, s) : patch_launch_nhwc(a, tiles, ps.lds, s));
     if (rc != SHL_MI355X_OK) return rc;
     SHL_HIP(hipGetLastError());

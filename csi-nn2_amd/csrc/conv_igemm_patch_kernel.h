@@ -27,7 +27,7 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 #define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (a stride-1 layer on the half-resolution grid, four planes per pixel)
 #define PT_NT(g) (((g) >> 22) & 1)   // NHWC output stored non-temporally (set per launch by patch_setup)
 #define PT_NBT(g) ((((g) >> 24) & 3) == 1 ? 7 : (((g) >> 24) & 3) == 2 ? 4 : 13)  // MFMA pixel blocks per wave role (bits 24 - 25: 0 -> 13, 1 -> 7, 2 -> 4)
-#define PT_F16(g) (((g) >> 23) & 1)  // binary16 (NHWC, stride 1): the same bytes through v_mfma_f32_32x32x16_f16, fp32 epilogue
+#define PT_F16(g) (((g) >> 23) & 1)  // binary16: the same bytes through v_mfma_f32_32x32x16_f16, fp32 epilogue
 
 // x / d for x < 2^22 (q is within one of the quotient after the float multiply)
 __device__ __forceinline__ uint32_t pt_div(uint32_t x, uint32_t d, float rcp)
@@ -69,19 +69,22 @@ static __device__ unsigned long long g_pt_span[2 * 1024];  // SHL_MI355X_DEBUG=3
 // of grid row / column -1): the shared padding column and the padding rows between images of the stride-1 geometry serve
 // them.  Everything else -- geometry, tables, padding, K loop (nine K steps per 32-channel stage), epilogue -- IS the
 // stride-1 code on the (H / 2) x (W / 2) grid; the weight stream is the stride-1 one with 32-channel stages.
-// kF16: binary16 tensors (NHWC, stride 1, no pair mode).  Everything up to the matrix instruction is byte arithmetic --
+// kF16: binary16 tensors (eight waves, no pair mode).  Everything up to the matrix instruction is byte arithmetic --
 // a.C is the pixel size in BYTES (the host doubles it), KC bytes of a pixel per stage are KC / 2 channels, a 16-byte
 // fragment piece is 8 channels -- and the fragment layouts of v_mfma_f32_32x32x16_f16 and v_mfma_i32_32x32x32_i8 are the
 // same bytes (lane (row, half) = bytes 16 half .. +15 of the row's 32-byte K slab).  Different: fp32 accumulators, K
 // parts summed in fp32 (part order: deterministic), epilogue = + bias, relu / relu6, the reference's f32 -> f16
-// rounding (common.h:finish_f16), two 16-byte stores of 8 channels per lane and block.
+// rounding (common.h:finish_f16), two 16-byte stores of 8 channels per lane and block.  NCHW (round 5): a staging item is
+// 8 pixels x 8 channels -- eight 16-byte loads of plane runs, an 8 x 8 transposition of two-byte elements (32 v_perm_b32),
+// eight 16-byte LDS writes; the MFMA operands swap (rows = pixels) and a lane finishes 16 consecutive pixels of its
+// channel's plane: two 16-byte stores at a two-byte-aligned address.
 // NBT: pixel blocks per wave role (13; 7 / 4 for maps of 14 x 14 / 7 x 7 pixels: a tile of whole images then fills its blocks, a
 // layer is one round of 256 tiles without K parts and their exchange of partial sums, and a stride-2 layer of 512 channels
 // has 256 tiles at all); the two halves of a role take (NBT + 1) / 2 and NBT / 2 of them.
 template <bool kF16, int EPI, bool kNchw, bool kPair, bool kS2, int KC, int PG, int OB, int KP, int NW, int NBW, int NBT = PT_NB>
 __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, const int h)
 {
-    static_assert(!kF16 || (!kNchw && !kPair && !kS2), "binary16: NHWC, stride 1");
+    static_assert(!kF16 || (!kPair && NW == 8), "binary16: eight waves, no pair mode");
     int trace_k = 0;
     auto mark = [&]() {
         if ((a.debug & 32) && blockIdx.x == 0 && threadIdx.x == 0 && trace_k < 64) g_pt_trace[trace_k++] = __builtin_amdgcn_s_memtime();
@@ -96,7 +99,10 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     static_assert(NB >= 2, "two blocks per wave at least");
     constexpr int NT = NW * 64;              // threads
     constexpr int NIT = PT_NIT * 4 / NW;     // NHWC staging items per lane and stage
+    constexpr int ES = kF16 ? 2 : 1;         // bytes per tensor element
     constexpr int CI = NW == 8 ? 8 : 16;     // NCHW staging: channels per item
+    constexpr int CIB = CI * ES;             // ... = bytes of an item per patch pixel
+    constexpr int SEGP = 16 / ES;            // NCHW staging: pixels per 16-byte segment of a plane run
     constexpr int NP = kNchw ? CI : NIT;     // staging pieces per round (loads, and again writes)
     constexpr bool kTwo = kNchw && NW == 4;  // NCHW staging may take a second round of items (eight waves: the host
                                              // falls back to four when one round does not cover a stage)
@@ -111,7 +117,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     constexpr int NF = NSTEP * NB;      // MFMAs per stage and wave
     constexpr int PITCH = KC + 16;
     constexpr int SLOTS = KC / 16;
-    constexpr int CG = KCP / CI;        // channel groups per stage (NCHW staging)
+    constexpr int CG = KCP / CIB;       // channel groups per stage (NCHW staging)
     static_assert(U % KP == 0, "K parts split the sub-steps of a tap");
     static_assert(NSTEP % SPI == 0 && SPI % FR == 0, "weight fragment ring");
     // (NCHW only: NHWC stride-2 layers run faster on the ping-pong / producer-consumer kernels -- 22 - 28 us against 32 for
@@ -226,7 +232,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // ---- staging items of this lane (the same for every stage) -------------------------------------------
     // NHWC: item = (patch pixel, 16-byte slot); NCHW: item = (image run, 16-channel group, 16-pixel segment)
     constexpr int NSRC = kNchw ? (kTwo ? 2 : 1) : NIT;
-    constexpr int NDST = kNchw ? (kTwo ? 32 : 16) : NIT;
+    constexpr int NDST = kNchw ? (kTwo ? 2 : 1) * SEGP : NIT;
     uint32_t s_src[NSRC], s_dst[NDST];
     const uint32_t trash = 2 * bufb + lane * 16 + (wave & 3) * 1024;
     if constexpr (!kNchw) {
@@ -258,7 +264,8 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         const uint32_t nf = pt_div((uint32_t)(v0 + 1), H1, rH1);
         const uint32_t spr = (uint32_t)a.pt_spr;
         const float rspr = a.pt_rspr;
-        const int total = a.N * a.C * THW;  // < 2^31 (checked on the host)
+        const int total = a.N * a.C * THW;  // bytes, < 2^31 (checked on the host; binary16: a.C = bytes of a pixel)
+        const uint32_t cch = (uint32_t)a.C / ES;  // channels
         if constexpr (kTwo) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) s_dst[16 + q] = trash;
@@ -279,15 +286,15 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             const bool run_ok = it < a.pt_nitc && n < (uint32_t)a.N && vb >= va;
             // (kS2: a grid row is two input rows -- the run is twice as many rows of the plane, each TW pixels)
             const int ya = va - lo, runlen = run_ok ? (int)m24(vb - va + 1, kS2 ? 2 * TW : W) : 0;
-            int k0 = (int)seg * 16;
-            // byte offset of (image n, channel cg * 16, row ya, pixel k0) in the NCHW tensor; the window of the LAST
+            int k0 = (int)seg * SEGP;
+            // byte offset of (image n, channel cg * CI, row ya, pixel k0) in the NCHW tensor; the window of the LAST
             // channel of the LAST stage must end inside the tensor: slide the window back (its first bytes then
             // belong to pixels in front of the segment and are dropped)
-            int off = (int)m24(m24(n, a.C) + cg * CI, THW) + (int)m24(kS2 ? 2 * ya : ya, TW) + k0;
-            const int over = run_ok ? off + (kPair ? a.pt_pair_in : 0) + (a.C - KCP + CI - 1) * THW + 16 - total : 0;
+            int off = ((int)m24(m24(n, cch) + cg * CI, THW) + (int)m24(kS2 ? 2 * ya : ya, TW) + k0) * ES;
+            const int over = run_ok ? off + (kPair ? a.pt_pair_in : 0) + (a.C - KCP + (CI - 1) * ES) * THW + 16 - total : 0;
             if (over > 0) {
                 off -= over;
-                k0 -= over;
+                k0 -= over / ES;
             }
             if (!run_ok || off < 0) off = 0;
             s_src[it] = (uint32_t)off;
@@ -299,13 +306,13 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             if constexpr (kS2) {
                 // LDS offset = row term (grid row yy / 2, plane row yy & 1) + column term (grid column x / 2 + 1, plane column
                 // x & 1), both advanced by additions: the sixteen products of the direct form tipped the instantiation into scratch
-                auto rowterm = [&](uint32_t y2) { return m24(m24(pr0 + (y2 >> 1), W1), PITCH) + (y2 & 1) * (2 * KCP) + cg * CI; };
+                auto rowterm = [&](uint32_t y2) { return m24(m24(pr0 + (y2 >> 1), W1), PITCH) + (y2 & 1) * (2 * KCP) + cg * CIB; };
                 uint32_t rt = rowterm(yy), ct = m24((x >> 1) + 1, PITCH) + (x & 1) * KCP;
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
+                for (int b = 0; b < SEGP; ++b) {
                     const int k = k0 + b;
-                    const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
-                    s_dst[it * 16 + b] = ok ? rt + ct : trash;
+                    const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * SEGP <= k);
+                    s_dst[it * SEGP + b] = ok ? rt + ct : trash;
                     if (k >= 0) {
                         ct += (x & 1) ? (uint32_t)(PITCH - KCP) : (uint32_t)KCP;
                         if (++x == (uint32_t)TW) x = 0, ++yy, rt = rowterm(yy), ct = PITCH;
@@ -313,10 +320,10 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                 }
             } else {
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
+                for (int b = 0; b < SEGP; ++b) {
                     const int k = k0 + b;
-                    const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * 16 <= k);
-                    s_dst[it * 16 + b] = ok ? m24(m24(pr0 + yy, W1) + x + 1, PITCH) + cg * CI : trash;
+                    const bool ok = run_ok && k >= 0 && k < runlen && ((int)seg * SEGP <= k);
+                    s_dst[it * SEGP + b] = ok ? m24(m24(pr0 + yy, W1) + x + 1, PITCH) + cg * CIB : trash;
                     if (k >= 0) {
                         if (++x == (uint32_t)W) x = 0, ++yy;
                     }
@@ -341,7 +348,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         } else {
             const char *base = static_cast<const char *>(a.in) + (kPair ? (size_t)stage * (uint32_t)a.pt_pair_in : (size_t)stage * KCP * THW);
             const uint32_t o = (!kTwo || it == 0) ? s_src[0] : s_src[NSRC - 1];
-            sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * THW))));
+            sd[q] = __builtin_bit_cast(v4i, *reinterpret_cast<const pt_u4 *>(base + (o + (uint32_t)(q * THW * ES))));
         }
     };
     auto stage_write_one = [&](uint32_t bufoff, int it, auto qc) {
@@ -349,6 +356,15 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         if constexpr (!kNchw) {
             const uint32_t d = s_dst[q];
             *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = sd[q];
+        } else if constexpr (kF16) {
+            // piece q = pixel q of the lane's eight: dword k of its 16 bytes = channels (2 k, 2 k + 1), i.e. the low (even
+            // pixel) or high (odd pixel) halves of dword q / 2 of the two channels' loads
+            constexpr uint32_t sel = (q & 1) ? 0x07060302u : 0x05040100u;
+            v4i v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (int)__builtin_amdgcn_perm((uint32_t)sd[2 * k + 1][q >> 1], (uint32_t)sd[2 * k][q >> 1], sel);
+            const uint32_t d = s_dst[q];
+            *reinterpret_cast<v4i *>(smem + (d >= 2 * bufb ? d : d + bufoff)) = v;
         } else {
             // piece q = (dword column jd, channel quad ca): one 4 x 4 byte block of the CI channels x 16 pixels ->
             // 16 pixels x CI channels transposition; after the last quad the column's four pixels go out
@@ -526,7 +542,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                 if (do_write1) static_for<PN>([&](auto pc) { stage_write_one(nbufoff, 1, std::integral_constant<int, P0 + decltype(pc)::value>{}); });
             }
             if constexpr (kNchw)
-                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[j], fa[F % FR], acc[j], 0, 0, 0);  // rows = pixels
+                acc[j] = mfma<!kF16>(rb[j], fa[F % FR], acc[j]);  // rows = pixels
             else
                 acc[j] = mfma<!kF16>(fa[F % FR], rb[j], acc[j]);  // rows = channels
             __builtin_amdgcn_sched_barrier(0);
@@ -588,12 +604,12 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         const uint32_t m00 = (uint32_t)(pixbase + hb * 32 + fhalf * 16);
         const uint32_t e_n = pt_div(m00, OHW, a.pt_rHW);
         e_rem = m00 - m24(e_n, OHW);
-        e_ptr = out + ((int64_t)(m24(e_n, a.Co) + (uint32_t)(ocb * 32 + frow)) * OHW + e_rem);
+        e_ptr = out + ((int64_t)(m24(e_n, a.Co) + (uint32_t)(ocb * 32 + frow)) * OHW + e_rem) * ES;
     } else {
         e_ptr = out + ((int64_t)(pixbase + hb * 32 + frow) * a.Co + (ocb * 32 + fhalf * 16)) * (kF16 ? 2 : 1);
     }
-    const int64_t e_step = kNchw ? 32 : (int64_t)32 * a.Co * (kF16 ? 2 : 1);
-    const int64_t e_wrap = (int64_t)(a.Co - 1) * OHW;
+    const int64_t e_step = kNchw ? 32 * ES : (int64_t)32 * a.Co * ES;
+    const int64_t e_wrap = (int64_t)(a.Co - 1) * OHW * ES;
     auto advance_on = [&](char *&p, uint32_t &rem) {
         p += e_step;
         if constexpr (kNchw) {
@@ -613,20 +629,22 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // 56 x 56 and 28 x 28 maps
     uint32_t slow_mask = 0;
     uint4 sv[NB];
+    uint4 sv1[kF16 && kNchw ? NB : 1];  // (binary16: 16 pixels are 32 bytes)
     char *const e_ptr0 = e_ptr;
     const uint32_t e_rem0 = e_rem;
-    auto finalize = [&](int j, const acc_t &c) {
+    auto finalize = [&](int j, const acc_t &c) __attribute__((always_inline)) {  // (left to the inliner the binary16 NCHW body stays a call: accumulators in scratch)
         if constexpr (kF16) {
             // rows 8 g + 4 fhalf + e of the lane's pixel -> binary16 pairs; after the half swaps a lane holds channels
             // 16 fhalf .. +15 of its pixel: 32 contiguous bytes of the NHWC output
             uint2 pk2[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float x[4] = {__fadd_rn(c[4 * g + 0], bi[g].x), __fadd_rn(c[4 * g + 1], bi[g].y), __fadd_rn(c[4 * g + 2], bi[g].z),
-                              __fadd_rn(c[4 * g + 3], bi[g].w)};
+                const float4 bg = kNchw ? bi[0] : bi[g];
+                float x[4] = {__fadd_rn(c[4 * g + 0], bg.x), __fadd_rn(c[4 * g + 1], bg.y), __fadd_rn(c[4 * g + 2], bg.z),
+                              __fadd_rn(c[4 * g + 3], bg.w)};
                 if (a.scale_out) {
-                    pk2[g].x = (uint32_t)finish_f16(c[4 * g + 0], bi[g].x, a) | (uint32_t)finish_f16(c[4 * g + 1], bi[g].y, a) << 16;
-                    pk2[g].y = (uint32_t)finish_f16(c[4 * g + 2], bi[g].z, a) | (uint32_t)finish_f16(c[4 * g + 3], bi[g].w, a) << 16;
+                    pk2[g].x = (uint32_t)finish_f16(c[4 * g + 0], bg.x, a) | (uint32_t)finish_f16(c[4 * g + 1], bg.y, a) << 16;
+                    pk2[g].y = (uint32_t)finish_f16(c[4 * g + 2], bg.z, a) | (uint32_t)finish_f16(c[4 * g + 3], bg.w, a) << 16;
                 } else {
                     if (a.act != SHL_MI355X_ACT_NONE) {
 #pragma unroll
@@ -649,12 +667,30 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             const auto a13 = __builtin_amdgcn_permlane32_swap(pk2[1].x, pk2[3].x, false, false);
             const auto b13 = __builtin_amdgcn_permlane32_swap(pk2[1].y, pk2[3].y, false, false);
             if (a.debug & 2) return;
-            const int pl = (hb + j) * 32 + frow;
-            const int m = pixbase + pl;
-            const int oc = ocb * 32 + fhalf * 16;
-            if (ocb_ok && pl < RW && m < a.M && oc < a.Co) {
-                reinterpret_cast<uint4 *>(e_ptr)[0] = make_uint4(a02[0], b02[0], a02[1], b02[1]);  // channels +0 .. +7
-                reinterpret_cast<uint4 *>(e_ptr)[1] = make_uint4(a13[0], b13[0], a13[1], b13[1]);  // channels +8 .. +15
+            const uint4 v0 = make_uint4(a02[0], b02[0], a02[1], b02[1]);  // rows +0 .. +7 of the lane's sixteen
+            const uint4 v1 = make_uint4(a13[0], b13[0], a13[1], b13[1]);  // rows +8 .. +15
+            if constexpr (!kNchw) {
+                const int pl = (hb + j) * 32 + frow;
+                const int m = pixbase + pl;
+                const int oc = ocb * 32 + fhalf * 16;
+                if (ocb_ok && pl < RW && m < a.M && oc < a.Co) {
+                    reinterpret_cast<uint4 *>(e_ptr)[0] = v0;  // channels +0 .. +7
+                    reinterpret_cast<uint4 *>(e_ptr)[1] = v1;  // channels +8 .. +15
+                }
+            } else {  // 16 pixels of the lane's channel plane, as in the int8 NCHW case below
+                const int oc = ocb * 32 + frow;
+                const int pl0 = (hb + j) * 32 + fhalf * 16;
+                const int m0 = pixbase + pl0;
+                const bool live = ocb_ok && oc < a.Co && pl0 < RW && m0 < a.M;
+                const bool full = pl0 + 16 <= RW && m0 + 16 <= a.M;
+                const bool fast = live && full && e_rem + 16 <= (uint32_t)OHW;
+                if (fast) {
+                    const pt_u4 t0 = {v0.x, v0.y, v0.z, v0.w}, t1 = {v1.x, v1.y, v1.z, v1.w};
+                    reinterpret_cast<pt_u4 *>(e_ptr)[0] = t0;
+                    reinterpret_cast<pt_u4 *>(e_ptr)[1] = t1;
+                }
+                sv[j] = v0, sv1[j] = v1;
+                slow_mask |= __builtin_amdgcn_ballot_w64(!fast) != 0 ? 1u << j : 0u;
             }
             return;
         } else {
@@ -702,7 +738,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     // last, so it is kept short: valid bytes [0, L) of the lane's 16, of which [0, len1) lie in image n and the rest in
     // image n + 1 (the same channel plane, Co planes further); whole dwords go out whole at whatever byte address, the at
     // most two dwords that straddle len1 or L byte by byte.  (A byte loop over all 16 cost 1.6 - 2.8 us per launch.)
-    auto store_general = [&](int j, const uint4 &v, char *dst, uint32_t rem) {
+    auto store_general = [&](int j, const uint4 &v, const uint4 &vhi, char *dst, uint32_t rem) __attribute__((always_inline)) {
         const int oc = ocb * 32 + frow;
         const int pl0 = (hb + j) * 32 + fhalf * 16;
         const int m0 = pixbase + pl0;
@@ -710,6 +746,39 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
         int L = RW - pl0 < a.M - m0 ? RW - pl0 : a.M - m0;  // >= 1
         L = L < 16 ? L : 16;
         if (L == 16 && rem + 16 <= (uint32_t)OHW) return;  // stored in the first pass
+        if constexpr (kF16) {
+            // binary16: dword d = pixels (2 d, 2 d + 1).  Pixels [0, l1) lie in image n, [len1, L) in image n + 1 (the same
+            // channel plane, Co planes further: dst2 + 2 p); whole dwords where both pixels go to one place, halves otherwise
+            const uint32_t w8[8] = {v.x, v.y, v.z, v.w, vhi.x, vhi.y, vhi.z, vhi.w};
+            typedef uint32_t u1_a2 __attribute__((aligned(2)));
+            if (OHW >= 16) {
+                const int len1 = OHW - (int)rem;  // > 0
+                const int l1 = len1 < L ? len1 : L;
+                char *dst2 = dst + (int64_t)(a.Co - 1) * OHW * 2;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const int p0 = 2 * d, p1 = 2 * d + 1;
+                    if (p1 < l1) *reinterpret_cast<u1_a2 *>(dst + 4 * d) = w8[d];
+                    else if (p0 >= len1 && p1 < L) *reinterpret_cast<u1_a2 *>(dst2 + 4 * d) = w8[d];
+                    else {
+                        if (p0 < L) *reinterpret_cast<uint16_t *>((p0 < len1 ? dst : dst2) + 4 * d) = (uint16_t)w8[d];
+                        if (p1 < L) *reinterpret_cast<uint16_t *>((p1 < len1 ? dst : dst2) + 4 * d + 2) = (uint16_t)(w8[d] >> 16);
+                    }
+                }
+            } else {  // planes of fewer than 16 pixels: several image boundaries inside one run
+                uint32_t r2 = rem;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (e < L) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(w8[e >> 1] >> (16 * (e & 1)));
+                    dst += 2;
+                    if (++r2 == (uint32_t)OHW) {
+                        r2 = 0;
+                        dst += (int64_t)(a.Co - 1) * OHW * 2;
+                    }
+                }
+            }
+            return;
+        }
         const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
         if (OHW >= 16) {
             const int len1 = OHW - (int)rem;                  // bytes that still belong to image n (> 0)
@@ -756,7 +825,7 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             uint32_t rem = e_rem0;
             static_for<NB>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                if (slow_mask & (1u << j)) store_general(j, sv[j], p, rem);
+                if (slow_mask & (1u << j)) store_general(j, sv[j], sv1[kF16 ? j : 0], p, rem);
                 advance_on(p, rem);
             });
         }
@@ -765,11 +834,22 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     if constexpr (KP == 1) {
         // two blocks at a time: their requantisation chains are independent (a wave alone on its SIMD runs one chain
         // latency-bound), the pairs are kept apart so that the accumulators' copies do not pile up in registers
+        if constexpr (kF16 && kNchw) {
+            // (the binary16 NCHW body is past the size up to which "#pragma unroll" unrolls -- accumulators in scratch; the
+            // other forms keep the loop: as a static_for two binary16 NHWC instantiations spill three registers)
+            static_for<NB>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                finalize(j, acc[j]);
+                advance();
+                if constexpr (j & 1) __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            finalize(j, acc[j]);
-            advance();
-            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NB; ++j) {
+                finalize(j, acc[j]);
+                advance();
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         second_pass();
     } else {
@@ -869,7 +949,7 @@ template <bool kF16, int EPI, bool kNchw, int KC, int PG, int OB, int KP>
 static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
     if constexpr (kF16) {  // stride 1, no pair mode, eight waves (the host sets the bit: patch_choose_geom)
-        patch_launch_nw<true, 0, false, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+        patch_launch_nw<true, 0, kNchw, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
     } else if (PT_NBT(a.pt_geom) != PT_NB) {
         // small tiles (7 / 4 blocks per role): NCHW, eight waves, one K part, four channel blocks, 128-byte stages
         if constexpr (KC == 128 && KP == 1 && kNchw && PG == 1 && OB == 4) {
@@ -898,7 +978,7 @@ template <bool kF16, bool kNchw, int KC, int PG, int OB, int KP>
 static void patch_launch_geom(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
     if constexpr ((KC / 32) % KP == 0) {
-        if constexpr (kF16) patch_launch_one<true, 0, false, KC, PG, OB, KP>(a, tiles, lds, s);
+        if constexpr (kF16) patch_launch_one<true, 0, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
         else if (a.div_exact != 0) patch_launch_one<false, 3, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
         else patch_launch_one<false, 0, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
     }
@@ -939,6 +1019,7 @@ static int patch_read_trace_layout(unsigned long long *host, int count)
 int patch_launch_nhwc(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s);
 int patch_launch_nchw(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s);
 int patch_launch_nhwc_f16(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s);  // conv_igemm_patch_f16.hip
+int patch_launch_nchw_f16(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s);  // conv_igemm_patch_nchw_f16.hip
 int patch_read_trace_nhwc(unsigned long long *host, int count);
 int patch_read_trace_nchw(unsigned long long *host, int count);
 

@@ -427,10 +427,11 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         // as shl_mi355x_conv_forward decides: an NCHW layer first asks the NCHW-native row-patch kernel (input AND output
         // NCHW), everything else sees the NHWC view of the re-layout path
         const char *v = nullptr;
+        bool patch_native_nchw = false;
         if (probe.in_nchw) {
             ConvArgs t = probe;
             t.out_nchw = 1;
-            if (!strcmp(igemm_pick_name(t, es), "patch")) v = "patch";
+            if (!strcmp(igemm_pick_name(t, es), "patch")) v = "patch", patch_native_nchw = true;
             probe.in_nchw = 0;
         }
         if (!v && es == 2 && d.layout == SHL_MI355X_NCHW && probe.w_patch) {  // binary16 NCHW: the row-patch kernel on the NHWC view (conv_forward)
@@ -446,7 +447,8 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
         else if (!strcmp(v, "gemv"))
             p->kernel_name = i8 ? "conv_gemv_i8_dot4" : "conv_gemv_f16_fma";
         else if (!strcmp(v, "patch"))
-            p->kernel_name = i8 ? "conv_igemm_patch_i8_mfma32x32x32" : "conv_igemm_patch_f16_mfma32x32x16";
+            p->kernel_name = i8 ? "conv_igemm_patch_i8_mfma32x32x32"
+                                : (patch_native_nchw ? "conv_igemm_patch_nchw_f16_mfma32x32x16" : "conv_igemm_patch_f16_mfma32x32x16");
         else if (!strcmp(v, "pp"))
             p->kernel_name = i8 ? "conv_igemm_pp_i8_mfma32x32x32" : "conv_igemm_pp_f16_mfma32x32x16";
         else if (!strcmp(v, "res")) {
@@ -887,11 +889,11 @@ static int conv_forward_impl(const shl_mi355x_conv_plan *plan, const void *input
                 igemm_note_family("nchw1x1");
                 return launch_conv1x1_nchw(a, d.dtype, s);
             }
-            // 3x3 stride-1 "same" int8: the row-patch kernel reads and writes NCHW itself (conv_igemm_patch.hip)
+            // 3x3 "same": the row-patch kernel reads and writes NCHW itself (conv_igemm_patch.hip; int8, and binary16 at stride 1)
             if (a.w_patch) {
                 ConvArgs t = a;
                 t.in_nchw = t.out_nchw = 1;
-                if (!strcmp(igemm_pick_name(t, 1), "patch")) {
+                if (!strcmp(igemm_pick_name(t, d.dtype == SHL_MI355X_I8 ? 1 : 2), "patch")) {
                     igemm_note_family("patch");
                     return launch_conv_igemm_patch(t, s);
                 }

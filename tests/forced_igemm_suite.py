@@ -67,12 +67,12 @@ SHAPES = [
     dict(c=128, co=96, h=14, w=14, n=8, act=1),
     dict(c=64, co=32, h=7, w=7, n=32),
 ]
-F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19, 23, 24, 25, 26, 27, 28, 29]  # from 23: the row-patch shapes (binary16: NHWC native)
+F16_IDX = [0, 3, 4, 7, 10, 14, 16, 17, 19, 23, 24, 25, 26, 27, 28, 29, 36, 37, 38]  # from 23: the row-patch shapes (binary16: stride 1, both layouts native)
 
 EXPECT = os.environ.get("SHL_EXPECT_KERNEL", "")          # the forced kernel family ...
 FALLBACK = os.environ.get("SHL_EXPECT_FALLBACK", "")      # ... or, for shapes it does not take, this one
 EXPECT_MIN = int(os.environ.get("SHL_EXPECT_MIN", "1"))   # cases that must have run on the forced family
-SEEN = {"expected": 0, "fallback": 0}
+SEEN = {"expected": 0, "fallback": 0, "f16_nchw_native": 0}
 
 
 def _note(kname):
@@ -126,18 +126,21 @@ def test_forced_variant_fp16_within_tolerance(gpu, idx, layout):
     case = cases.make_case(8500 + idx, dtype="f16", layout=layout, **kw)
     got, kname = _run(gpu, case)
     _note(kname)
+    if "patch_nchw_f16" in kname:  # read and written NCHW by the row-patch kernel itself (no re-layout pass)
+        SEEN["f16_nchw_native"] += 1
     golden_util.compare_f16_tol(got, cases.oracle_run(case, "f16"), "fp16 shape %d %s via %s" % (idx, layout, kname))
 
 
+@pytest.mark.parametrize("layout", [NHWC, NCHW])
 @pytest.mark.parametrize("scale,act", [(0.5, 2), (0.37, 1), (1.0, 2)])
 @pytest.mark.parametrize("idx", [0, 16, 24])
-def test_forced_variant_fp16_output_scale_and_relu6(gpu, idx, scale, act):
+def test_forced_variant_fp16_output_scale_and_relu6(gpu, idx, scale, act, layout):
     """binary16 with an output scale != 1 and a fused relu / relu6 (the literal epilogue of common.h:finish_f16: the clamp
     acts on the dequantised stored value) through the forced family -- the row-patch kernel's own epilogue included"""
     kw = dict(SHAPES[idx])
     kw.pop("per_channel", None)
     kw["act"] = act
-    case = cases.make_case(8700 + idx, dtype="f16", layout=NHWC, **kw)
+    case = cases.make_case(8700 + idx, dtype="f16", layout=layout, **kw)
     case["out_scale"] = scale
     case["input"] = (case["input"].astype(np.float32) * 3).astype(np.float16)   # reach beyond 6
     got, kname = _run(gpu, case)
@@ -149,3 +152,7 @@ def test_zz_the_forced_family_was_exercised():
     """runs last (file order): the forced kernel family must have taken its share of the cases"""
     if EXPECT:
         assert SEEN["expected"] >= EXPECT_MIN, SEEN
+    # the row-patch kernel forced: its binary16 NCHW cases must have run NCHW-native (a silent fall to the re-layout path
+    # around the NHWC kernel would pass the comparisons all the same)
+    if EXPECT == "patch" and os.environ.get("SHL_MI355X_PATCH_WAVES") != "4" and os.environ.get("SHL_MI355X_PATCH", "1,4,1").startswith(("1,4,1", "2,2,1")):
+        assert SEEN["f16_nchw_native"] >= 6, SEEN
