@@ -48,11 +48,11 @@ bool patch_supports(const shl_mi355x_conv_desc &d)
 {
     if (d.group != 1) return false;
     if (d.dtype == SHL_MI355X_F16) {
-        // binary16: stride 1; NCHW layers natively (8 x 8 transposition of two-byte elements in the staging), or -- when the
-        // NCHW item budget does not cover a stage -- on the NHWC view of conv_forward's re-layout path
+        // binary16: NCHW layers natively (8 x 8 transposition of two-byte elements in the staging; stride 1 and the stride-2 form), or
+        // -- stride 1, when the NCHW item budget does not cover a stage -- on the NHWC view of conv_forward's re-layout path
         static const char *f16_env = getenv("SHL_MI355X_PATCH_F16");  // "0": off (A/B)
         if (f16_env && f16_env[0] == '0') return false;
-        if (d.stride_h != 1 || d.stride_w != 1) return false;
+        if ((d.stride_h != 1 || d.stride_w != 1) && d.layout != SHL_MI355X_NCHW) return false;
     } else if (d.dtype != SHL_MI355X_I8) {
         return false;
     }
@@ -212,7 +212,7 @@ int make_geom(int kc, int pg, int ob, int kp, int nbt = PT_NB)
 // small tiles (7 / 4 pixel blocks per wave role): the instantiations that exist (conv_igemm_patch_kernel.h:patch_launch_one)
 bool small_tiles_ok(bool nchw, bool f16, int kc, int pg, int ob, int kp, int g)
 {
-    return nchw && !f16 && kc == 128 && pg == 1 && ob == 4 && kp == 1 && PT_NW8(g);
+    return nchw && kc == 128 && pg == 1 && ob == 4 && kp == 1 && PT_NW8(g);
 }
 
 }  // namespace
@@ -259,11 +259,11 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     const int kc_top = kc;
     for (int view = 0; view < 2 && !best; ++view) {
     if (view == 1) {
-        if (!(f16 && nchw)) break;
+        if (!(f16 && nchw) || s2) break;
         nchw = false;
     }
     for (int kc_try = kc_top; kc_try >= 64; kc_try -= 64) {
-    if (kc_try != kc_top && !f16) break;
+    if (kc_try != kc_top && (!f16 || s2)) break;
     kc = kc_try, u = kc / 32;
     for (const auto &c : cand) {
         const int pg = c[0], ob = c[1], kp = c[2], nbt = c[3];
@@ -341,7 +341,8 @@ bool patch_setup(ConvArgs &a)
     if (!a.in_nchw && a.Co % 16 != 0) return false;
     PatchShape ps;
     const int cbytes = a.C * (PT_F16(a.pt_geom) ? 2 : 1);
-    if (PT_F16(a.pt_geom) && (a.sh != 1 || a.sw != 1)) return false;
+    if (PT_F16(a.pt_geom) && !PT_S2(a.pt_geom) && (a.sh != 1 || a.sw != 1)) return false;
+    if (PT_S2(a.pt_geom) && (!a.in_nchw || a.sh != 2 || a.sw != 2)) return false;
     if (!patch_shape(a.N, a.H, a.W, cbytes, a.Co, a.in_nchw != 0, a.pt_geom, &ps)) return false;
     a.pt_rows = ps.rows;
     a.pt_prows = ps.prows;
@@ -385,7 +386,8 @@ bool patch_auto(const ConvArgs &a, bool vs_wave)
     // (binary16: the block-tile kernels are further behind -- 256 -> 256 @14 at batch 8 26 us against 33, profiles/r04_f16_patch_kbench.txt)
     // (stride 2: from 192 -- ResNet-50's 512 -> 512 @14 is 128 tiles of 16 stages, slower than the re-layout passes around the
     // producer / consumer kernel)
-    if ((int64_t)ps.nt_m * ps.nt_n < ((s2 || (!a.in_nchw && !vs_wave && !f16)) ? 192 : 96)) return false;
+    // (binary16 stride 2: from 96 -- the alternative is two re-layout passes around the tile kernel, 97 us for 512 -> 512 @14 at batch 128)
+    if ((int64_t)ps.nt_m * ps.nt_n < (((s2 && !f16) || (!a.in_nchw && !vs_wave && !f16)) ? 192 : 96)) return false;
     // NHWC with four K parts (512 channels @7 at batch 128): nine K steps per stage and the exchange of partial sums
     // leave it behind the producer / consumer kernel (25.4 vs 22.4 us); NCHW takes it anyway -- the alternative there
     // is two re-layout passes around that kernel (39 vs 47 us)

@@ -24,7 +24,7 @@ constexpr int PT_LDS_MAX = 160 * 1024;
 #define PT_OB(g) (((g) >> 12) & 0xf)
 #define PT_KP(g) (((g) >> 16) & 0xf)
 #define PT_NW8(g) (((g) >> 20) & 1)  // eight waves (two per SIMD) instead of four
-#define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (a stride-1 layer on the half-resolution grid, four planes per pixel)
+#define PT_S2(g) (((g) >> 21) & 1)   // the stride-2 form (a stride-1 layer on the half-resolution grid, four planes per pixel; NCHW)
 #define PT_NT(g) (((g) >> 22) & 1)   // NHWC output stored non-temporally (set per launch by patch_setup)
 #define PT_NBT(g) ((((g) >> 24) & 3) == 1 ? 7 : (((g) >> 24) & 3) == 2 ? 4 : 13)  // MFMA pixel blocks per wave role (bits 24 - 25: 0 -> 13, 1 -> 7, 2 -> 4)
 #define PT_F16(g) (((g) >> 23) & 1)  // binary16: the same bytes through v_mfma_f32_32x32x16_f16, fp32 epilogue
@@ -949,6 +949,20 @@ template <bool kF16, int EPI, bool kNchw, int KC, int PG, int OB, int KP>
 static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
     if constexpr (kF16) {  // stride 1, no pair mode, eight waves (the host sets the bit: patch_choose_geom)
+        if constexpr (kNchw && KC == 128 && KP == 1) {
+            const bool s2 = PT_S2(a.pt_geom) != 0;
+            if constexpr (PG == 1 && OB == 4) {  // small tiles, as for int8 below
+                if (PT_NBT(a.pt_geom) == 7) {
+                    if (s2) return patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
+                    return patch_launch_nw<true, 0, true, false, false, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
+                }
+                if (PT_NBT(a.pt_geom) == 4) {
+                    if (s2) return patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
+                    return patch_launch_nw<true, 0, true, false, false, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
+                }
+            }
+            if (s2) return patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
+        }
         patch_launch_nw<true, 0, kNchw, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
     } else if (PT_NBT(a.pt_geom) != PT_NB) {
         // small tiles (7 / 4 blocks per role): NCHW, eight waves, one K part, four channel blocks, 128-byte stages
