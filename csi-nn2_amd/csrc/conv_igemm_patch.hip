@@ -249,7 +249,10 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     // exchange of partial sums), 256 -> 256 @28 stride 2 39.3 -> 29.1 (its 13-block tiles were half empty).  The 4-block form
     // (7 x 7 maps) exists for SHL_MI355X_PATCH=1,4,1,4 only: 512 -> 512 @7 28.9 vs 27.5 us with four K parts, 512 -> 512 @14
     // stride 2 41.1 vs 35.1 through the re-layout passes (16 stages of nine 4-block steps are all barrier)
-    static const int cand[][4] = {{1, 4, 1, PT_NB}, {2, 2, 1, PT_NB}, {1, 2, 2, PT_NB}, {1, 1, 4, PT_NB}, {1, 4, 1, 7}};
+    // binary16 takes the 4-block form too: 512 -> 512 @14 stride 2 at batch 128 69 us against 78 (the alternative is the tile kernel
+    // between two re-layout passes, 97), and at batches 8 .. 32 it fills more CUs (128 -> 128 @28 at batch 16: 15.2 us against 17.8;
+    // profiles/r05_f16_nchw_small_batches.txt)
+    static const int cand[][4] = {{1, 4, 1, PT_NB}, {2, 2, 1, PT_NB}, {1, 2, 2, PT_NB}, {1, 1, 4, PT_NB}, {1, 4, 1, 7}, {1, 4, 1, 4}};
     const int ocblks = (d.out_c + 31) / 32;
     int best = 0;
     double best_cost = 0;
@@ -268,6 +271,7 @@ int patch_choose_geom(const shl_mi355x_conv_desc &d, int32_t batch)
     for (const auto &c : cand) {
         const int pg = c[0], ob = c[1], kp = c[2], nbt = c[3];
         if (u % kp != 0 || (s2 && kp != 1)) continue;  // (stride 2: one K sub-step per tap and stage)
+        if (nbt == 4 && !f16) continue;
         if (ob > 1 && ob / 2 >= ocblks) continue;  // half of the channel blocks of a tile would be empty
         if (nbt != PT_NB && !small_tiles_ok(nchw, f16, kc, pg, ob, kp, make_geom(kc, pg, ob, kp))) continue;
         PatchShape ps;
@@ -386,13 +390,21 @@ bool patch_auto(const ConvArgs &a, bool vs_wave)
     // (binary16: the block-tile kernels are further behind -- 256 -> 256 @14 at batch 8 26 us against 33, profiles/r04_f16_patch_kbench.txt)
     // (stride 2: from 192 -- ResNet-50's 512 -> 512 @14 is 128 tiles of 16 stages, slower than the re-layout passes around the
     // producer / consumer kernel)
-    // (binary16 stride 2: from 96 -- the alternative is two re-layout passes around the tile kernel, 97 us for 512 -> 512 @14 at batch 128)
-    if ((int64_t)ps.nt_m * ps.nt_n < (((s2 && !f16) || (!a.in_nchw && !vs_wave && !f16)) ? 192 : 96)) return false;
+    if (f16) {
+        // binary16: the block-tile kernels are far behind (and an NCHW layer pays two re-layout passes around them) -- from 24 tiles, or
+        // from 12 when the layer is at most four stages (a launch is ~10 us + 3 us per stage whatever the batch: 256 -> 256 @14
+        // NCHW at batch 8, 16 tiles: 21.9 us against 33.1; 512 -> 512 @14 stride 2 at batch 8, 32 stages: 66 against the wave kernel's 33;
+        // profiles/r05_f16_nchw_small_batches.txt)
+        const int kcp = s2 ? PT_KC(a.pt_geom) / 4 : PT_KC(a.pt_geom);
+        const int64_t tiles = (int64_t)ps.nt_m * ps.nt_n;
+        return tiles >= 24 || (tiles >= 12 && a.C * 2 / kcp <= 4);  // (below 12 tiles: not measured, the latency kernels keep them)
+    }
+    if ((int64_t)ps.nt_m * ps.nt_n < ((s2 || (!a.in_nchw && !vs_wave)) ? 192 : 96)) return false;
     // NHWC with four K parts (512 channels @7 at batch 128): nine K steps per stage and the exchange of partial sums
     // leave it behind the producer / consumer kernel (25.4 vs 22.4 us); NCHW takes it anyway -- the alternative there
     // is two re-layout passes around that kernel (39 vs 47 us)
     // (binary16: 39 us against 68 through the tile kernel)
-    if (!a.in_nchw && PT_KP(a.pt_geom) == 4 && !vs_wave && !f16) return false;
+    if (!a.in_nchw && PT_KP(a.pt_geom) == 4 && !vs_wave) return false;
     return true;
 }
 
