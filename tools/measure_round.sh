@@ -21,7 +21,10 @@ for L in NHWC NCHW; do
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_resnet_$L" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout $L --steps-only --steps 3 --warmup 1 --windows 1 > /dev/null 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_resnet_$L" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout $L --steps-only --steps 3 --warmup 1 --windows 1 > /dev/null 2>&1
 done
+# ---- the same set in binary16 NCHW (round 5: read and written NCHW by the row-patch kernel -- no transpose_* launch may show up)
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/prof_resnet_f16_NCHW" -o t -- python "$REPO/bench.py" --workload resnet50_3x3 --layout NCHW --dtype f16 --steps 5 --warmup 2 --windows 1 --no-cpu-baseline --no-configs > "$OUT/prof_resnet_f16_NCHW.log" 2>&1
 cd "$REPO"
+python tools/rocprof_summary.py $(find "$OUT/prof_resnet_f16_NCHW" -name '*.db' | head -1) > "$OUT/rocprof_summary_resnet_f16_NCHW.txt" 2>&1
 python tools/rocprof_summary.py $(find "$OUT/prof" -name '*.db' | head -1) > "$OUT/rocprof_summary.txt" 2>&1
 python tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/traffic.json" 2> "$OUT/traffic.err"
 for L in NHWC NCHW; do
