@@ -176,3 +176,24 @@ def test_resnet50_3x3_batch128_full_size(gpu, idx, layout, exact):
     # (3) every image was written: a batch output is never constant over an image (random inputs)
     flat = got.reshape(batch, -1)
     assert np.all(flat.max(axis=1) != flat.min(axis=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [NHWC, NCHW], ids=["NHWC", "NCHW"])
+@pytest.mark.parametrize("idx", range(len(RESNET_3X3)), ids=["%d_%d_at%d" % (s["c"], s["co"], s["h"]) for s in RESNET_3X3])
+def test_resnet50_3x3_batch128_full_size_binary16(gpu, idx, layout):
+    """the same set in binary16 at its own size (1e-3 relative: fp32 sums in the MFMA's order).  NCHW must run on the
+    row-patch kernel's NCHW-native form -- stride 1 and 2, no re-layout pass around an NHWC kernel (round 5)."""
+    fe, hip, opt, dev = gpu
+    batch = 128
+    case = cases.make_case(9300 + idx, n=batch, layout=layout, act=1, dtype="f16", **RESNET_3X3[idx])
+    kept = []
+    got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+    kname = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
+    assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
+    if layout == NCHW:
+        assert "patch_nchw_f16" in kname, "binary16 NCHW 3x3 at batch 128 must run NCHW-native, the plan chose " + kname
+    for i in (0, 41, 86, batch - 1):
+        golden_util.compare_f16_tol(got[i:i + 1], cases.oracle_run(_one_image(case, i), "f16"), "binary16 %s image %d via %s" % (layout, i, kname))
+    flat = got.reshape(batch, -1).astype(np.float32)
+    assert np.all(flat.max(axis=1) != flat.min(axis=1))
