@@ -81,6 +81,10 @@ def patch_kernels_with_scratch(usage_file):
                 # them: 128 -> 128 @56 stride 2 at batch 128 34.1 - 35.2 -> 30.7 - 31.0 us (profiles/r05_notes.md)
                 if "ELb1ELb0ELb1ELi128E" in name and n <= 64:
                     continue
+                # binary16 NHWC, 64-byte stages, one K part (round 5: the sixteen-value epilogue needs the two activation bounds in
+                # registers -- v_med3_f32 takes one scalar operand): two spilled registers in the epilogue, measured with them
+                if ("ILb1ELi0ELb0ELb0ELb0ELi64ELi1ELi4ELi1ELi8ELi13E" in name or "ILb1ELi0ELb0ELb0ELb0ELi64ELi2ELi2ELi1ELi8ELi13E" in name) and n <= 8:
+                    continue
                 # (... ELi<NW>ELi<NBT>EEEv: eight waves, 13 / 7 / 4 pixel blocks per role)
                 if n > (12 if known else 0) and "conv_igemm_patch_kernel" in name and re.search(r"ELi8ELi\d+EEEvNS_8ConvArgsE", name):
                     bad.append("%s (%d bytes)" % (name, n))

@@ -401,6 +401,61 @@ __device__ __forceinline__ uint32_t pack2_f16_ref(float x0, float x1, uint32_t &
 // true when every magnitude seen was zero or a normal binary16 result, and none a NaN
 __device__ __forceinline__ bool pack_f16_ref_ok(uint32_t lo, uint32_t hi) { return lo >= 0x387FFFFFu && hi <= 0x7F800000u; }
 
+// Sixteen values per lane at once (the row-patch kernel's block; output scale 1): x = acc + bias is tested (one running
+// min / max over the sixteen magnitudes, ONE lane-mask branch per block instead of one per four values), the activation and
+// the conversion's saturation are one v_med3_f32 with bounds from the activation (none: +-65520, relu: 0 .. 65520, relu6:
+// 0 .. 6), then bits + 0x1000 and the packed round-toward-zero conversion.  6.5 VALU instructions per value against ~16 for
+// four finish4 calls (25 000 of a 54 000-cycle tile of 64 -> 64 @56 were this epilogue).  Blocks that hold a NaN or a
+// non-zero value below 2^-14 before the activation take the literal recipe on the reference's own order (activation as a
+// comparison, then the rounding).  bias(i): the bias of value i.
+// (N = 8: half a block per test, for instantiations that have no sixteen registers to spare)
+template <int N, int I0, typename V16, typename BiasFn>
+__device__ __forceinline__ void finish16_f16_unit_scale(const V16 &c, BiasFn bias, int act, uint32_t (&pk)[8])
+{
+    static_assert(N == 16 || N == 8 || N == 4, "a block, half or a quarter of it");
+    const float flo = act == SHL_MI355X_ACT_NONE ? -65520.0f : 0.0f, fhi = act == SHL_MI355X_ACT_RELU6 ? 6.0f : 65520.0f;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+    for (int i = I0; i < I0 + N; i += 2) {
+        const float x0 = __fadd_rn(c[i], bias(i)), x1 = __fadd_rn(c[i + 1], bias(i + 1));
+        const uint32_t a0 = __float_as_uint(x0) & 0x7FFFFFFFu, a1 = __float_as_uint(x1) & 0x7FFFFFFFu;
+        lo = min(lo, min(a0 - 1u, a1 - 1u));
+        hi = max(hi, max(a0, a1));
+        const float y0 = __builtin_amdgcn_fmed3f(x0, flo, fhi), y1 = __builtin_amdgcn_fmed3f(x1, flo, fhi);
+        const auto h2 = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(__float_as_uint(y0) + 0x1000u), __uint_as_float(__float_as_uint(y1) + 0x1000u));
+        __builtin_memcpy(&pk[i / 2], &h2, 4);
+    }
+    if (!pack_f16_ref_ok(lo, hi)) {
+#pragma unroll
+        for (int i = I0; i < I0 + N; i += 2) {
+            float y[2] = {__fadd_rn(c[i], bias(i)), __fadd_rn(c[i + 1], bias(i + 1))};  // (again: sixteen sums kept for this branch cost registers)
+            if (act != SHL_MI355X_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    y[e] = y[e] > 0.0f ? y[e] : 0.0f;  // (NaN -> 0, as the reference's comparison)
+                    if (act == SHL_MI355X_ACT_RELU6) y[e] = fminf(y[e], 6.0f);
+                }
+            }
+            pk[i / 2] = float_to_f16_bits_literal_nb(y[0]) | float_to_f16_bits_literal_nb(y[1]) << 16;
+        }
+    }
+}
+
+// Four consecutive channels of a pixel (the block-tile kernels' register groups), each with its own bias: the packed
+// form above when the output scale is 1, finish_f16 per value otherwise.  (Round 5: the block-tile epilogues called
+// finish_f16 four times -- four lane-mask branches and ~16 instructions per value.)
+__device__ __forceinline__ uint2 finish4_f16(float v0, float v1, float v2, float v3, const float4 &b, const ConvArgs &a)
+{
+    if (a.scale_out) {
+        const uint32_t h0 = finish_f16(v0, b.x, a), h1 = finish_f16(v1, b.y, a), h2 = finish_f16(v2, b.z, a), h3 = finish_f16(v3, b.w, a);
+        return make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+    }
+    const float c[4] = {v0, v1, v2, v3};
+    uint32_t pk[8];
+    finish16_f16_unit_scale<4, 0>(c, [&](int i) { return i == 0 ? b.x : i == 1 ? b.y : i == 2 ? b.z : b.w; }, a.act, pk);
+    return make_uint2(pk[0], pk[1]);
+}
+
 // bias, relu / relu6, rounding of four values; output scale 1 only (callers check ConvArgs::scale_out)
 __device__ __forceinline__ uint2 finish4_f16_unit_scale(float v0, float v1, float v2, float v3, float bias_f, int act)
 {

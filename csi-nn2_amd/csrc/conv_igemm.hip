@@ -150,15 +150,12 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const Acc &acc, in
                 for (int e = 0; e < 4 && oc + e < a.Co; ++e) out[o + e] = (int8_t)(packed >> (8 * e));
             }
         } else {
-            const uint32_t h0 = finish_f16(acc[4 * g + 0], bi.x, a);
-            const uint32_t h1 = finish_f16(acc[4 * g + 1], bi.y, a);
-            const uint32_t h2 = finish_f16(acc[4 * g + 2], bi.z, a);
-            const uint32_t h3 = finish_f16(acc[4 * g + 3], bi.w, a);
+            const uint2 h2 = finish4_f16(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], bi, a);
             uint16_t *out = static_cast<uint16_t *>(a.out);
             if (vec_ok) {
-                *reinterpret_cast<uint2 *>(out + o) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                *reinterpret_cast<uint2 *>(out + o) = h2;
             } else {
-                const uint32_t h[4] = {h0, h1, h2, h3};
+                const uint32_t h[4] = {h2.x & 0xFFFFu, h2.x >> 16, h2.y & 0xFFFFu, h2.y >> 16};
                 for (int e = 0; e < 4 && oc + e < a.Co; ++e) out[o + e] = (uint16_t)h[e];
             }
         }
@@ -544,10 +541,8 @@ __global__ __launch_bounds__(64 * WR * WC * (PIPE ? 2 : 1)) void conv_igemm_tile
                                 *reinterpret_cast<uint32_t *>(dst) = pk;
                             }
                         } else {
-                            const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
-                            const uint32_t h1 = finish_f16(acc[i][j][4 * g + 1], bi.y, a);
-                            const uint32_t h2 = finish_f16(acc[i][j][4 * g + 2], bi.z, a);
-                            const uint32_t h3 = finish_f16(acc[i][j][4 * g + 3], bi.w, a);
+                            const uint2 hp = finish4_f16(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], bi, a);
+                            const uint32_t h0 = hp.x & 0xFFFFu, h1 = hp.x >> 16, h2 = hp.y & 0xFFFFu, h3 = hp.y >> 16;
                             if (a.out_nchw) {
                                 *reinterpret_cast<uint16_t *>(dst_t) = (uint16_t)h0;
                                 *reinterpret_cast<uint16_t *>(dst_t + PITCH) = (uint16_t)h1;
@@ -843,15 +838,12 @@ __global__ __launch_bounds__(256) void conv_igemm_wave_kernel(ConvArgs a)
                 for (int e = 0; e < 4 && occ + e < a.Co; ++e) out[o + e] = (int8_t)(packed >> (8 * e));
             }
         } else {
-            const uint32_t h0 = finish_f16(v_f[0], bi[g_tab].x, a);
-            const uint32_t h1 = finish_f16(v_f[1], bi[g_tab].y, a);
-            const uint32_t h2 = finish_f16(v_f[2], bi[g_tab].z, a);
-            const uint32_t h3 = finish_f16(v_f[3], bi[g_tab].w, a);
+            const uint2 hp = finish4_f16(v_f[0], v_f[1], v_f[2], v_f[3], bi[g_tab], a);
             uint16_t *out = static_cast<uint16_t *>(a.out);
             if (vec_ok) {
-                *reinterpret_cast<uint2 *>(out + o) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                *reinterpret_cast<uint2 *>(out + o) = hp;
             } else {
-                const uint32_t h[4] = {h0, h1, h2, h3};
+                const uint32_t h[4] = {hp.x & 0xFFFFu, hp.x >> 16, hp.y & 0xFFFFu, hp.y >> 16};
                 for (int e = 0; e < 4 && occ + e < a.Co; ++e) out[o + e] = (uint16_t)h[e];
             }
         }

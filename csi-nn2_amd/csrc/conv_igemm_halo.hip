@@ -413,11 +413,7 @@ __global__ __launch_bounds__(2 * 64 * WR * WC) void conv_igemm_halo_kernel(ConvA
                         *reinterpret_cast<uint32_t *>(dst) = requant4_i8_t<EPI>(
                             acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], mu, bi, a);
                     } else {
-                        const uint32_t h0 = finish_f16(acc[i][j][4 * g + 0], bi.x, a);
-                        const uint32_t h1 = finish_f16(acc[i][j][4 * g + 1], bi.y, a);
-                        const uint32_t h2 = finish_f16(acc[i][j][4 * g + 2], bi.z, a);
-                        const uint32_t h3 = finish_f16(acc[i][j][4 * g + 3], bi.w, a);
-                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                        *reinterpret_cast<uint2 *>(dst) = finish4_f16(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], bi, a);
                     }
                 }
         // wave-local hand-over: the same wave wrote and reads; LDS operations complete in order

@@ -408,14 +408,19 @@ bool patch_auto(const ConvArgs &a, bool vs_wave)
     return true;
 }
 
-static bool g_last_nchw = false;  // layout of the last launch: its translation unit holds the trace
+static int g_last_tu = 0;  // translation unit of the last launch (layout | binary16 << 1): it holds the trace
 
 int patch_launch_nhwc(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s) { return patch_launch_layout<false>(a, tiles, lds, s); }
 int patch_read_trace_nhwc(unsigned long long *host, int count) { return patch_read_trace_layout<false>(host, count); }
 
 int patch_read_trace(unsigned long long *host, int count)
 {
-    return g_last_nchw ? patch_read_trace_nchw(host, count) : patch_read_trace_nhwc(host, count);
+    switch (g_last_tu) {
+        case 1: return patch_read_trace_nchw(host, count);
+        case 2: return patch_read_trace_nhwc_f16(host, count);
+        case 3: return patch_read_trace_nchw_f16(host, count);
+        default: return patch_read_trace_nhwc(host, count);
+    }
 }
 
 int launch_conv_igemm_patch(const ConvArgs &a0, hipStream_t s)
@@ -430,7 +435,7 @@ int launch_conv_igemm_patch(const ConvArgs &a0, hipStream_t s)
     PatchShape ps;
     patch_shape(a.N, a.H, a.W, a.C, a.Co, a.in_nchw != 0, a.pt_geom, &ps);
     const unsigned tiles = (unsigned)((ps.pair_dn ? ps.nt_m / 2 : ps.nt_m) * ps.nt_n);
-    g_last_nchw = a.in_nchw != 0;
+    g_last_tu = (a.in_nchw != 0 ? 1 : 0) | (f16 ? 2 : 0);
     const int rc = f16 ? (a.in_nchw ? patch_launch_nchw_f16(a, tiles, ps.lds, s) : patch_launch_nhwc_f16(a, tiles, ps.lds, s))
                        : (a.in_nchw ? patch_launch_nchw(a, tiles, ps.lds, s) : patch_launch_nhwc(a, tiles, ps.lds, s));
     if (rc != SHL_MI355X_OK) return rc;

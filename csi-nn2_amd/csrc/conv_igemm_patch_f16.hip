@@ -8,5 +8,6 @@
 namespace shl {
 
 int patch_launch_nhwc_f16(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s) { return patch_launch_layout<false, true>(a, tiles, lds, s); }
+int patch_read_trace_nhwc_f16(unsigned long long *host, int count) { return patch_read_trace_layout<false>(host, count); }
 
 }  // namespace shl

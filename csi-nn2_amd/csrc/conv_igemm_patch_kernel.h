@@ -637,30 +637,22 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
             // rows 8 g + 4 fhalf + e of the lane's pixel -> binary16 pairs; after the half swaps a lane holds channels
             // 16 fhalf .. +15 of its pixel: 32 contiguous bytes of the NHWC output
             uint2 pk2[4];
+            if (a.scale_out) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bg = kNchw ? bi[0] : bi[g];
-                float x[4] = {__fadd_rn(c[4 * g + 0], bg.x), __fadd_rn(c[4 * g + 1], bg.y), __fadd_rn(c[4 * g + 2], bg.z),
-                              __fadd_rn(c[4 * g + 3], bg.w)};
-                if (a.scale_out) {
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bg = kNchw ? bi[0] : bi[g];
                     pk2[g].x = (uint32_t)finish_f16(c[4 * g + 0], bg.x, a) | (uint32_t)finish_f16(c[4 * g + 1], bg.y, a) << 16;
                     pk2[g].y = (uint32_t)finish_f16(c[4 * g + 2], bg.z, a) | (uint32_t)finish_f16(c[4 * g + 3], bg.w, a) << 16;
-                } else {
-                    if (a.act != SHL_MI355X_ACT_NONE) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            x[e] = x[e] > 0.0f ? x[e] : 0.0f;
-                            if (a.act == SHL_MI355X_ACT_RELU6) x[e] = fminf(x[e], 6.0f);
-                        }
-                    }
-                    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-                    uint32_t p0 = pack2_f16_ref(x[0], x[1], lo, hi), p1 = pack2_f16_ref(x[2], x[3], lo, hi);
-                    if (!pack_f16_ref_ok(lo, hi)) {
-                        p0 = float_to_f16_bits_literal_nb(x[0]) | float_to_f16_bits_literal_nb(x[1]) << 16;
-                        p1 = float_to_f16_bits_literal_nb(x[2]) | float_to_f16_bits_literal_nb(x[3]) << 16;
-                    }
-                    pk2[g] = make_uint2(p0, p1);
                 }
+            } else {
+                uint32_t pk[8];
+                auto bias_of = [&](int i) {
+                    const float4 bg = kNchw ? bi[0] : bi[i >> 2];
+                    return (i & 3) == 0 ? bg.x : (i & 3) == 1 ? bg.y : (i & 3) == 2 ? bg.z : bg.w;
+                };
+                finish16_f16_unit_scale<16, 0>(c, bias_of, a.act, pk);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pk2[g] = make_uint2(pk[2 * g], pk[2 * g + 1]);
             }
             const auto a02 = __builtin_amdgcn_permlane32_swap(pk2[0].x, pk2[2].x, false, false);
             const auto b02 = __builtin_amdgcn_permlane32_swap(pk2[0].y, pk2[2].y, false, false);
@@ -1036,6 +1028,8 @@ int patch_launch_nhwc_f16(const ConvArgs &a, unsigned tiles, size_t lds, hipStre
 int patch_launch_nchw_f16(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s);  // conv_igemm_patch_nchw_f16.hip
 int patch_read_trace_nhwc(unsigned long long *host, int count);
 int patch_read_trace_nchw(unsigned long long *host, int count);
+int patch_read_trace_nhwc_f16(unsigned long long *host, int count);
+int patch_read_trace_nchw_f16(unsigned long long *host, int count);
 
 }  // namespace shl
 

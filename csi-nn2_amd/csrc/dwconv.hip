@@ -112,10 +112,7 @@ __global__ __launch_bounds__(256) void dwconv_nhwc_kernel(ConvArgs a)
             const int q3 = requant_i8_fast(acc_i[3], mu.w, bi.w, a);
             *reinterpret_cast<uint32_t *>(static_cast<int8_t *>(a.out) + o) = pack4_i8(q0, q1, q2, q3);
         } else {
-            const uint32_t h0 = finish_f16(acc_f[0], bi.x, a), h1 = finish_f16(acc_f[1], bi.y, a);
-            const uint32_t h2 = finish_f16(acc_f[2], bi.z, a), h3 = finish_f16(acc_f[3], bi.w, a);
-            *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(a.out) + o) =
-                make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+            *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(a.out) + o) = finish4_f16(acc_f[0], acc_f[1], acc_f[2], acc_f[3], bi, a);
         }
     }
 }

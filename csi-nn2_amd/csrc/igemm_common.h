@@ -167,10 +167,8 @@ __device__ __forceinline__ void igemm_store_block64_impl(const ConvArgs &a, cons
                 *reinterpret_cast<uint32_t *>(dst) = pk;
             }
         } else {
-            const uint32_t h0 = finish_f16(acc[4 * g + 0], bi.x, a);
-            const uint32_t h1 = finish_f16(acc[4 * g + 1], bi.y, a);
-            const uint32_t h2 = finish_f16(acc[4 * g + 2], bi.z, a);
-            const uint32_t h3 = finish_f16(acc[4 * g + 3], bi.w, a);
+            const uint2 hp = finish4_f16(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], bi, a);
+            const uint32_t h0 = hp.x & 0xFFFFu, h1 = hp.x >> 16, h2 = hp.y & 0xFFFFu, h3 = hp.y >> 16;
             if constexpr (kNchw) {
                 *reinterpret_cast<uint16_t *>(dst_t) = (uint16_t)h0;
                 *reinterpret_cast<uint16_t *>(dst_t + PITCH) = (uint16_t)h1;

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--pc", action="store_true", help="producer / consumer kernel (SHL_MI355X_IGEMM=pc SHL_MI355X_DEBUG=32)")
     ap.add_argument("--patch", action="store_true", help="row-patch kernel (SHL_MI355X_IGEMM=patch SHL_MI355X_DEBUG=32)")
     ap.add_argument("--layout", default="NHWC")
+    ap.add_argument("--dtype", default="int8")
     a = ap.parse_args()
     import cases
     pkg = cases.pkg
@@ -35,7 +36,7 @@ def main():
     fe = pkg.load_frontend("standalone")
     hip, opt = pkg.load_backend(fe)
     dev = cases.HipDevice(hip)
-    chain = wl.LayerChain(fe, hip, opt, [wl.RESNET50_3X3[a.layer]], a.batch, dev.alloc, dev.upload, chained=False, layout=a.layout)
+    chain = wl.LayerChain(fe, hip, opt, [wl.RESNET50_3X3[a.layer]], a.batch, dev.alloc, dev.upload, chained=False, layout=a.layout, dtype=a.dtype)
     for _ in range(3):
         chain.run_layer(0)
     hip.shl_mi355x_stream_sync(None)
