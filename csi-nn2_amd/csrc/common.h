@@ -459,21 +459,10 @@ __device__ __forceinline__ uint2 finish4_f16(float v0, float v1, float v2, float
 // bias, relu / relu6, rounding of four values; output scale 1 only (callers check ConvArgs::scale_out)
 __device__ __forceinline__ uint2 finish4_f16_unit_scale(float v0, float v1, float v2, float v3, float bias_f, int act)
 {
-    float x[4] = {__fadd_rn(v0, bias_f), __fadd_rn(v1, bias_f), __fadd_rn(v2, bias_f), __fadd_rn(v3, bias_f)};
-    if (act != SHL_MI355X_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            x[e] = x[e] > 0.0f ? x[e] : 0.0f;  // (NaN -> 0, as the reference's comparison)
-            if (act == SHL_MI355X_ACT_RELU6) x[e] = fminf(x[e], 6.0f);
-        }
-    }
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    uint32_t p0 = pack2_f16_ref(x[0], x[1], lo, hi), p1 = pack2_f16_ref(x[2], x[3], lo, hi);
-    if (!pack_f16_ref_ok(lo, hi)) {
-        p0 = float_to_f16_bits_literal_nb(x[0]) | float_to_f16_bits_literal_nb(x[1]) << 16;
-        p1 = float_to_f16_bits_literal_nb(x[2]) | float_to_f16_bits_literal_nb(x[3]) << 16;
-    }
-    return make_uint2(p0, p1);
+    const float c[4] = {v0, v1, v2, v3};
+    uint32_t pk[8];
+    finish16_f16_unit_scale<4, 0>(c, [&](int) { return bias_f; }, act, pk);  // (round 5: activation + saturation in one v_med3_f32)
+    return make_uint2(pk[0], pk[1]);
 }
 
 // ---- host-side error plumbing (shim_runtime.hip) --------------------------------------------
