@@ -470,6 +470,9 @@ def main():
     hip, opt = pkg.load_backend(fe)
     if hip.shl_mi355x_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: " + hip.shl_mi355x_last_error().decode())
+    # (a launcher that narrows every rank to its own GPU -- HIP_VISIBLE_DEVICES per rank -- leaves one visible device: index 0;
+    # the distinct-devices check below compares PCI bus ids, so two ranks on one GPU are still caught)
+    local_rank %= hip.shl_mi355x_device_count()
     pkg.check(hip.shl_mi355x_set_device(local_rank), hip, "set_device")
     if torch is not None and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)  # the fallback transport of the weight broadcast stages through torch buffers
