@@ -130,7 +130,9 @@ int patch_shape_rows(int n, int H, int W, int C, int Co, bool nchw, int geom, in
     static const char *pair_env = getenv("SHL_MI355X_PATCH_PAIR");  // "0": off (A/B), "1": whenever the tiles pair up (tests)
     const int64_t tiles = (int64_t)nt_m * ps->nt_n;
     const bool pays = (pair_env && pair_env[0] == '1') || (double)((tiles + 511) / 512) * 1.7 < (double)((tiles + 255) / 256);
-    if (!(pair_env && pair_env[0] == '0') && !PT_F16(geom) && !s2 && PT_NW8(geom) && C == kc && kp == 1 && nt_m % 2 == 0 && total_rows % tr == 0 &&
+    // (13-block tiles only: the small-tile instantiations have no pair form -- launched on half the tiles they would leave the
+    // other half of the output unwritten; round 5: reachable through SHL_MI355X_PATCH=1,4,1,7 on single-stage layers)
+    if (!(pair_env && pair_env[0] == '0') && !PT_F16(geom) && !s2 && PT_NW8(geom) && PT_NBT(geom) == PT_NB && C == kc && kp == 1 && nt_m % 2 == 0 && total_rows % tr == 0 &&
         ((int64_t)(nt_m / 2) * tr) % H == 0 && pays)
         ps->pair_dn = (int)((int64_t)(nt_m / 2) * tr / H);
     return 1;

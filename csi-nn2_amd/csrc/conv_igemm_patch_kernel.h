@@ -106,7 +106,13 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     constexpr int NP = kNchw ? CI : NIT;     // staging pieces per round (loads, and again writes)
     constexpr bool kTwo = kNchw && NW == 4;  // NCHW staging may take a second round of items (eight waves: the host
                                              // falls back to four when one round does not cover a stage)
-    constexpr int FR = (NW == 8 && kNchw) ? 3 : 9;  // weight fragment ring (256 registers per wave: NCHW staging needs the rest)
+    // weight fragment ring (NCHW with eight waves: 3 -- the staging registers need the rest).  Vector loads return in order: a weight
+    // load issued behind the next stage's staging loads waits for THEIR data, so the ring's FR - 1 steps of look-ahead are what
+    // a stage transition has to cover an HBM round trip with.  The stride-2 form on small tiles -- many short stages, registers to
+    // spare -- takes the deep ring (round 5, same-box A/B: 256 -> 256 @28 s2 int8 28.4 -> 27.1 us, binary16 48.7 -> 45.8, 512 -> 512
+    // @14 s2 binary16 71.5 -> 64.2); on the stride-1 instantiations it changed nothing or cost 2 us (eight fragments of cold weights in
+    // front of the first stage's data), and the 13-block stride-2 ones have no 24 registers for it.
+    constexpr int FR = (NW == 8 && kNchw && !(kS2 && NBT < PT_NB)) ? 3 : 9;
     constexpr int KCP = kS2 ? KC / 4 : KC;  // bytes of a TENSOR pixel per stage (kS2: a patch pixel is four planes of them)
     constexpr int U = KCP / 32;         // 32-byte K sub-steps per tap and stage
     constexpr int UI = U / KP;          // ... of which this wave takes every KP-th

@@ -75,6 +75,9 @@ VARIANTS = [
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_PAIR="1"), "patch"),
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_PAIR="1", SHL_MI355X_PATCH="2,2,1"), "patch"),
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_PAIR="1", SHL_MI355X_PATCH="1,4,1"), "patch"),
+    # small tiles have no pair form: with pairing forced they must still write every tile (round 5: they were launched on half)
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_PAIR="1", SHL_MI355X_PATCH="1,4,1,7"), "patch"),
+    (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_PATCH_PAIR="1", SHL_MI355X_PATCH="1,4,1,4"), "patch"),
     (dict(SHL_MI355X_IGEMM="patch", SHL_MI355X_DEBUG="64"), "patch"),
 ]
 
