@@ -944,12 +944,18 @@ int shl_mi355x_debug_trace(uint64_t *host, int32_t count)
     return pp_read_trace(reinterpret_cast<unsigned long long *>(host), count);
 }
 
-/* which fused kernel runs the pair: 0 none, 1 latency form (pwdw_fused.hip: small grids), 3 stem + depthwise
+/* which fused kernel runs the pair (first layer `pw`, second `dw`; 6 is the pair in the other order): 0 none, 1 latency form (pwdw_fused.hip: small grids), 3 stem + depthwise
  * (stemdw_fused.hip), 4 binary16 NCHW (pwdw_f16_nchw.hip), 5 binary16 NCHW stem + depthwise (stemdw_f16_nchw.hip).  (2 was the int8 bandwidth form for large batches: it only
- * broke even with the two stand-alone kernels, attic/README.md; large batches keep one launch per layer.) */
+ * broke even with the two stand-alone kernels, attic/README.md.)  6 = depthwise -> pointwise in bandwidth form (dwpw_stream.hip): the
+ * 32 / 64 / 128-channel blocks at large batches. */
 static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, const ConvArgs &a,
                            const ConvArgs &b)
 {
+    // the other order (6): `pw` is the depthwise layer and `dw` the pointwise one consuming it (dwpw_stream.hip, large batches)
+    if (pw->algo == SHL_MI355X_ALGO_DW)
+        return pw->desc.dtype == SHL_MI355X_I8 &&
+                       dwpw_stream_fusable(a, b, pw->kstride == 12, dw->algo == SHL_MI355X_ALGO_IGEMM)
+                   ? 6 : 0;
     const int pw_igemm = pw->algo == SHL_MI355X_ALGO_IGEMM, dw_dot4 = dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12;
     if (pw->desc.dtype == SHL_MI355X_F16) {  // binary16 NCHW (pwdw_f16_nchw.hip, stemdw_f16_nchw.hip)
         if (dw->algo != SHL_MI355X_ALGO_DW) return 0;
@@ -996,6 +1002,7 @@ int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     if (rc != SHL_MI355X_OK) return rc;
     if (b.M == 0) return SHL_MI355X_OK;
     switch (pwdw_kernel_for(pw, dw, a, b)) {
+        case 6: return launch_dwpw_stream(a, b, (hipStream_t)stream);
         case 5: return launch_stemdw_f16_nchw(a, b, (hipStream_t)stream);
         case 4: return launch_pwdw_f16_nchw(a, b, (hipStream_t)stream);
         case 3: return launch_stemdw_fused(a, b, (hipStream_t)stream);

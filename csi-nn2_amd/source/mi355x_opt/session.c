@@ -181,8 +181,9 @@ static struct shl_node *final_out(struct dev_session *ds, struct shl_ref_graph *
  *        converter emits for a RISC-V target -- example/c906_mobilenetv1_f16.c is 28 csinn_conv2d + 27 csinn_relu --
  *        runs as 28 launches, not 55
  *   1x1 convolution -> depthwise 3x3   one launch of csrc/pwdw_fused.hip (int8 NHWC) / pwdw_f16_nchw.hip (fused[i] = 2)
- * (The other pairing, depthwise -> pointwise, recomputes the depthwise tile in every channel slice and measured
- * slower beyond 64 channels: attic/README.md.) */
+ *   depthwise 3x3 -> 1x1 convolution   one launch of csrc/dwpw_stream.hip at throughput batches (32 / 64 / 128 channels:
+ *        the requantised depthwise tile is the pointwise MFMA operand); the latency form of this pairing recomputed the
+ *        depthwise tile in every channel slice and is parked (attic/README.md) */
 static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
 {
     ds->fused = calloc((size_t)g->layer_index + 1, 1);
@@ -210,7 +211,9 @@ static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
             i = j - 1;
             continue;
         }
-        const int pw_dw = is_conv_op(a->type) && is_dw_op(b->type);
+        /* pointwise -> depthwise (latency form, small batches) or depthwise -> pointwise (bandwidth form, large
+         * batches: csrc/dwpw_stream.hip); shl_mi355x_pwdw_fusable tells the orders apart by the plans */
+        const int pw_dw = (is_conv_op(a->type) && is_dw_op(b->type)) || (is_dw_op(a->type) && is_conv_op(b->type));
         if (!pw_dw || consumers_of(g, mid) != 1) {
             i = j - 1;
             continue;

@@ -187,7 +187,7 @@ class LayerChain:
         while i < len(self.entries):
             a = self.entries[i]
             b = self.entries[i + 1] if i + 1 < len(self.entries) else None
-            if (fuse and b is not None and not a["layer"]["depthwise"] and b["layer"]["depthwise"]
+            if (fuse and b is not None and a["layer"]["depthwise"] != b["layer"]["depthwise"]
                     and b["d_in"] == a["d_out"]
                     and hip.shl_mi355x_pwdw_fusable(opt.shl_mi355x_registry_get(a["params"]),
                                                     opt.shl_mi355x_registry_get(b["params"]), batch) == 1):
@@ -217,6 +217,8 @@ class LayerChain:
         idx = self.units[u]
         if len(idx) == 1:
             return self.entries[idx[0]]["kernel_name"]
+        if self.entries[idx[0]]["layer"]["depthwise"]:
+            return "dwpw_stream_i8"
         if self.dtype != "int8":
             return "pwdw_f16_nchw" if "igemm" in self.entries[idx[0]]["kernel_name"] or "1x1" in self.entries[idx[0]]["kernel_name"] else "stemdw_f16_nchw"
         return "stemdw_fused_i8" if self.entries[idx[0]]["kernel_name"].startswith("conv_stem") else "pwdw_fused_i8"

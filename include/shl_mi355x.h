@@ -260,6 +260,11 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
  * result in LDS and runs shl_ref_depthwise_conv2d_quant on those channels from there -- same bits as
  * the two plans back to back; the pointwise output (the largest tensors of a MobileNet) is never
  * written.  `input_dev` is the pointwise layer's input, `output_dev` the depthwise layer's output.
+ *
+ * The same two entry points take the pair in the OTHER order -- first plan = a depthwise 3x3 layer, second plan =
+ * the pointwise layer consuming it (32 / 64 / 128 channels, int8 NHWC, throughput batches; csrc/dwpw_stream.hip):
+ * the requantised depthwise tile is the pointwise layer's MFMA operand and never leaves the chip.  `input_dev` is
+ * always the first layer's input and `output_dev` the second layer's output; the plans say which order it is.
  */
 int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch);
 int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw,
