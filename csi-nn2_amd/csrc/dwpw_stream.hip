@@ -10,7 +10,7 @@
 // requantised depthwise tile IS the pointwise fragment; it only crosses LDS because the wave that owns a channel
 // group (its nine diagonal fragments live in registers) is not the wave that owns a pixel tile's outputs.
 //
-//   workgroup  a rectangle of output pixels (MFMA pixel tiles of 8 x 4) x ALL C = 32 / 64 / 128 channels; the
+//   workgroup  a rectangle of output pixels (MFMA pixel tiles of 8 x 4) x ALL C = 32 / 64 / 128 / 256 channels; the
 //              input patch (+ halo) goes HBM -> LDS once by global_load_lds_dwordx4, padding from the pad page
 //              (exactly dwconv_mfma.hip's staging)
 //   phase 1    wave = one 32-channel group x the rectangle's tiles (fewer groups: tiles dealt out): nine MFMAs
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
 {
     constexpr int CB = NCG * 32;        // bytes of a pixel
     constexpr int NCH = CB >> 4;        // 16-byte slots per pixel
-    constexpr int NCH_SHIFT = NCH == 8 ? 3 : (NCH == 4 ? 2 : 1);
+    constexpr int NCH_SHIFT = NCH == 16 ? 4 : (NCH == 8 ? 3 : (NCH == 4 ? 2 : 1));
+    constexpr int CGW = NCG > 4 ? NCG / 4 : 1;  // channel groups per wave in phase 1 (256 channels: two)
     constexpr int MPITCH = CB + 16;     // pitch of a parked pixel (conflict-free ds_read_b128 / ds_write_b128)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -105,10 +106,11 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
     // ---- phase-1 role: channel group, its diagonal weight fragments and its epilogue tables.  The tables do not
     // depend on the tile: 48 registers for the whole phase instead of 12 ds_read_b128 per tile (a first version read
     // them from LDS per tile -- in both phases -- and ran at the LDS pipe's rate: profiles/r05_dwpw_stream.txt)
-    const int cgl = wave & (NCG - 1);
-    const int stream = NCG == 4 ? 0 : (NCG == 2 ? wave >> 1 : wave);
-    constexpr int NSTREAM = 4 / NCG;
-    {
+    const int stream = NCG >= 4 ? 0 : (NCG == 2 ? wave >> 1 : wave);
+    constexpr int NSTREAM = NCG >= 4 ? 1 : 4 / NCG;
+    static_for<CGW>([&](auto ci_c) {
+        constexpr int ci = decltype(ci_c)::value;
+        const int cgl = NCG > 4 ? wave + 4 * ci : (wave & (NCG - 1));
         const int dc = cgl * 32 + 4 * half;  // rows 8 e + 4 half + i of the tile
         int4 dai[4];
         float4 dmu[4], dbi[4];
@@ -122,9 +124,11 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
         const uint32_t wd[3] = {wq[0], wq[1], wq[2]};  // taps 0-3 | 4-7 | 8
         v4i fa[9];
         dw_diag_fragments(wd, row, half, fa);  // one non-zero byte per lane (dw_mfma.h)
-        // the patch pieces and the tables must have landed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (ci == 0) {
+            // the patch pieces and the tables must have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
 
         const int lchunk = cgl * 2 + half;  // this lane's logical 16-byte slot inside a pixel
 #pragma unroll 1
@@ -155,12 +159,14 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
             // 16 consecutive channels of the lane's pixel = its piece of the pointwise B fragment of sub-step cgl
             *reinterpret_cast<uint4 *>(mid + (t * 32 + row) * MPITCH + lchunk * 16) = tile_channels_16(pk);
         }
-    }
+    });
     // ---- the wave's pointwise weights (A fragments, plan order [32-channel group][K / 32][lane][16 B]; L2-resident: every
-    // workgroup reads them).  Requested here and not at the top: 64 registers held across phase 1 spill.
-    v4i fw[NOGB][NCG];
-    {
-        const char *wp = static_cast<const char *>(q.w_frag) + lane * 16;
+    // workgroup reads them).  Up to 64 registers of them are requested here, ahead of the barrier (not at the top: held
+    // across phase 1 they spill); deeper sets (256 -> 512: 128 registers) are fetched per output group in phase 2.
+    constexpr bool PF = NOGB * NCG <= 16;
+    const char *const wp = static_cast<const char *>(q.w_frag) + lane * 16;
+    v4i fw[PF ? NOGB : 1][NCG];
+    if constexpr (PF) {
 #pragma unroll
         for (int j = 0; j < NOGB; ++j)
 #pragma unroll
@@ -175,6 +181,14 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
     static_for<NOGB>([&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
         const int og = ogb * NOGB + j;
+        v4i fj[NCG];
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) {
+            if constexpr (PF)
+                fj[c] = fw[j][c];
+            else
+                fj[c] = *reinterpret_cast<const v4i *>(wp + ((int64_t)(og * NCG + c)) * 1024);
+        }
         int4 qai[4];
         float4 qmu[4], qbi[4];
         {
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
 #pragma unroll
             for (int c = 0; c < NCG; ++c) {
                 const v4i fb = *reinterpret_cast<const v4i *>(mp + c * 32);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[j][c], fb, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fj[c], fb, acc, 0, 0, 0);
             }
             uint32_t pk[4];
 #pragma unroll
@@ -221,8 +235,9 @@ static bool clamp_epilogue(const ConvArgs &a)
 static int dwpw_nogb(int C, int Co, int *npass)
 {
     const int nog = Co >> 5;
-    const int nogb = C == 32 ? 2 : 4;
+    const int nogb = C == 32 || (C == 256 && nog == 8) ? 2 : 4;
     if ((Co & 31) != 0 || nog % nogb != 0) return 0;
+    if (C == 256 && nog != 8 && nog != 16) return 0;  // instantiated: 256 -> 256, 256 -> 512
     const int np = nog / nogb;
     if (np != 1 && np != 2 && np != 4) return 0;
     *npass = np;
@@ -240,6 +255,10 @@ static bool dwpw_geometry(const ConvArgs &d, const ConvArgs &q, DwPwGeom &g, siz
     g.bty = d.C <= 32 && s1 ? 4 : 2;
     if (!s1 && d.C == 128 && np >= 2) g.bty = 1;  // two tiles x two passes keep the four waves busy; the stride-2 patch is 4x the pixels
     if (g.btx == 1) g.bty *= 2;                   // narrow maps: the same tile count in one column
+    if (d.C == 256) {  // 256-byte pixels: a 16 x 4 rectangle (stride 2: 8 x 4) keeps patch + parked tiles near 50 KB
+        g.btx = s1 && d.Wo > 8 ? 2 : 1;
+        g.bty = 1;
+    }
     while (g.bty > 1 && (g.bty - 1) * 4 >= d.Ho) --g.bty;
     g.tiles_x = (d.Wo + g.btx * 8 - 1) / (g.btx * 8);
     g.tiles_y = (d.Ho + g.bty * 4 - 1) / (g.bty * 4);
@@ -257,7 +276,7 @@ bool dwpw_stream_fusable(const ConvArgs &d, const ConvArgs &q, int dw_dot4_packe
 {
     if (!dw_dot4_packed || !pw_is_igemm) return false;
     if (d.Kh != 3 || d.Kw != 3 || d.dh != 1 || d.dw != 1 || d.sh != d.sw || d.sh < 1 || d.sh > 2) return false;
-    if (d.C != 32 && d.C != 64 && d.C != 128) return false;
+    if (d.C != 32 && d.C != 64 && d.C != 128 && d.C != 256) return false;
     if (d.Co != d.C) return false;
     if (q.Kh != 1 || q.Kw != 1 || q.sh != 1 || q.sw != 1 || q.pt != 0 || q.pl != 0) return false;
     if (q.C != d.C || q.H != d.Ho || q.W != d.Wo || q.Ho != d.Ho || q.Wo != d.Wo || q.N != d.N) return false;
@@ -270,8 +289,13 @@ bool dwpw_stream_fusable(const ConvArgs &d, const ConvArgs &q, int dw_dot4_packe
     const char *env = getenv("SHL_MI355X_DWPW");  // "0" never, "1" always (tests, A/B), default: by size; read per call: tests switch it
     if (env && env[0] == '0') return false;
     if (env && env[0] == '1') return true;
-    // bandwidth regime only: the intermediate tensor is what the fusion saves (profiles/r05_dwpw_stream.txt)
-    return (int64_t)d.M * d.C >= (int64_t)8 << 20;
+    // from a megabyte of intermediate tensor (MobileNetV1's first blocks from batch 4): measured against the pointwise ->
+    // depthwise latency form + single launches over batches 4 .. 128 (profiles/r05_dwpw_sweep.txt: ahead at every batch;
+    // callers pair greedily from the front, so the latency form keeps the pairs it accepts)
+    // 256 channels at stride 2 (8 x 4 rectangles, one tile per workgroup, weights fetched per output group): 21.7 us
+    // against 8.7 + 10.8 for MobileNetV1's 256 @28 s2 -> 512 @14 at batch 128 -- correct (tests force it), not chosen
+    if (d.C == 256 && d.sh != 1) return false;
+    return (int64_t)d.M * d.C >= (int64_t)1 << 20;
 }
 
 int launch_dwpw_stream(const ConvArgs &d, const ConvArgs &q, hipStream_t s)
@@ -292,7 +316,10 @@ int launch_dwpw_stream(const ConvArgs &d, const ConvArgs &q, hipStream_t s)
     switch (d.C) {
         case 32: SHL_DWPW(1, 2); break;
         case 64: SHL_DWPW(2, 4); break;
-        default: SHL_DWPW(4, 4); break;
+        case 128: SHL_DWPW(4, 4); break;
+        default:
+            if (q.Co == 256) SHL_DWPW(8, 2); else SHL_DWPW(8, 4);
+            break;
     }
 #undef SHL_DWPW
     SHL_HIP(hipGetLastError());

@@ -293,7 +293,7 @@ class ModelSession:
     csinn_get_output with HOST tensors, i.e. it includes the H2D / D2H copies and the final
     synchronisation -- the PCIe-inclusive rate of DESIGN.md."""
 
-    def __init__(self, fe, api, dtype="int8", layout="NHWC", seed=99, layers=None, dev_in=None, dev_out=None):
+    def __init__(self, fe, api, dtype="int8", layout="NHWC", seed=99, layers=None, dev_in=None, dev_out=None, batch=1):
         """dev_in / dev_out: HBM pointers for the graph input / output (DMABUF tensors): the session then
         runs in place on them and csinn_session_run only enqueues (run_async)."""
         from . import (QUANT_FLOAT16, QUANT_INT8_ASYM_W_SYM, RM_CPU_GRAPH, siso_params)
@@ -313,7 +313,8 @@ class ModelSession:
         fe.csinn_set_input_number(1, sess)
         fe.csinn_set_output_number(1, sess)
         L0 = layers[0]
-        self.in_dims = (1, L0["h"], L0["w"], L0["cin"]) if nhwc else (1, L0["cin"], L0["h"], L0["w"])
+        self.batch = batch
+        self.in_dims = (batch, L0["h"], L0["w"], L0["cin"]) if nhwc else (batch, L0["cin"], L0["h"], L0["w"])
         q = (2.0 ** -4, -5) if int8 else (1.0, 0)
         self.in_q = q
 
@@ -324,14 +325,14 @@ class ModelSession:
         cur, ops = t_in, []
         for i, L in enumerate(layers):
             if i == len(layers) - 1:  # pooled map feeds the classifier
-                pooled = (1, 1, 1, L["cin"]) if nhwc else (1, L["cin"], 1, 1)
+                pooled = (batch, 1, 1, L["cin"]) if nhwc else (batch, L["cin"], 1, 1)
                 qp = (2.0 ** -4, -5) if int8 else (1.0, 0)
                 t_p = T(pooled, qp, b"gap_out")
                 pp = siso_params(fe, keep, api, "pool", act_l, 1, sess, b"gap")
                 ops.append((fe.csinn_global_avgpool2d_init, fe.csinn_global_avgpool2d, (cur, t_p, pp)))
                 cur, q = t_p, qp
             ho = out_hw(L)
-            out_dims = (1, ho, ho, L["cout"]) if nhwc else (1, L["cout"], ho, ho)
+            out_dims = (batch, ho, ho, L["cout"]) if nhwc else (batch, L["cout"], ho, ho)
             o = synth_layer_operands(L, seed + i, dtype, layout, q[0] if int8 else None)
             qo = (o["out_scale"], o["out_zp"])
             t_out = T(out_dims, qo, b"out%d" % i)

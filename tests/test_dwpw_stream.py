@@ -37,6 +37,9 @@ DWPW_PAIRS = [
     dict(c=64, co=128, hw=8, stride=2, pad=(0, 0, 1, 1)),    # TF-style "same" padding for stride 2
     dict(c=32, co=64, hw=5, pad=(2, 2, 2, 2)),               # padding 2: windows that are mostly padding
     dict(c=128, co=128, hw=7, exact=False, relu=(0, 0)),     # no activation, general scales
+    dict(c=256, co=256, hw=12),                              # 256 channels: two channel groups per wave, 16 x 4 rectangles
+    dict(c=256, co=512, hw=9, stride=2, n=2, exact=False),   # weights fetched per output group
+    dict(c=256, co=256, hw=28, stride=2, relu=(1, 0)),       # stride 2 on 256-byte pixels: 8 x 4 rectangles
 ]
 
 
@@ -102,11 +105,12 @@ def test_depthwise_pointwise_pair_equals_the_two_kernels_and_the_oracle(gpu, i, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c,co,hw,stride,n", [(32, 64, 112, 1, 24), (64, 128, 112, 2, 48), (128, 128, 56, 1, 24),
-                                              (128, 256, 56, 2, 96)])
+@pytest.mark.parametrize("c,co,hw,stride,n", [(32, 64, 112, 1, 4), (64, 128, 112, 2, 8), (128, 128, 56, 1, 4),
+                                              (128, 256, 56, 2, 16), (256, 256, 28, 1, 8),
+                                              (128, 128, 56, 1, 128)])
 def test_mobilenet_blocks_at_a_throughput_batch_fuse_by_the_size_rule(gpu, c, co, hw, stride, n):
     """MobileNetV1's first separable blocks (example/c906_mobilenetv1_f16.c:1888-1947 shapes, int8 NHWC) at the smallest
-    batch the size rule takes: fused by default, bit-identical to the two launches"""
+    batch the size rule takes (and one block at batch 128): fused by default, bit-identical to the two launches"""
     fe, hip, opt = gpu
     dw, pw = make_dwpw(40 + c // 32 + stride, c=c, co=co, hw=hw, stride=stride, n=n, exact=False)
     dev, keep, plan_dw, plan_pw, want = run_pair(gpu, dw, pw, oracle=False)
@@ -120,7 +124,7 @@ def test_mobilenet_blocks_at_a_throughput_batch_fuse_by_the_size_rule(gpu, c, co
 def test_pairs_outside_the_form_are_refused(gpu, monkeypatch):
     fe, hip, opt = gpu
     monkeypatch.setenv("SHL_MI355X_DWPW", "1")
-    for kw in (dict(c=96, co=64, hw=8), dict(c=256, co=256, hw=8), dict(c=64, co=96, hw=8), dict(c=32, co=32, hw=8)):
+    for kw in (dict(c=96, co=64, hw=8), dict(c=512, co=512, hw=8), dict(c=256, co=128, hw=8), dict(c=64, co=96, hw=8), dict(c=32, co=32, hw=8)):
         dw, pw = make_dwpw(90, **kw)
         dev, keep, plan_dw, plan_pw, want = run_pair(gpu, dw, pw, oracle=False)
         assert hip.shl_mi355x_pwdw_fusable(plan_dw, plan_pw, 1) == 0, kw

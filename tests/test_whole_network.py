@@ -219,3 +219,20 @@ def test_mobilenetv1_session_equals_the_oracle_model(gpu, dtype, layout):
             g, w = got.astype(np.float64), want.astype(np.float64)
             assert np.abs(g - w).max() <= 2e-2 * max(w.max(), 1e-6), "probabilities drift %.3e" % np.abs(g - w).max()
     ms.close()
+
+
+@pytest.mark.gpu
+def test_mobilenetv1_int8_session_at_batch_8_fuses_depthwise_pointwise_blocks(gpu):
+    """A throughput-sized session: plan_fusion pairs the 32 / 64 / 128 / 256-channel separable blocks the other way round
+    (depthwise -> pointwise, csrc/dwpw_stream.hip); the 1000 x 8 probabilities still equal the oracle's replay bit for bit."""
+    fe, hip, opt, dev = gpu
+    ms = wl.ModelSession(fe, pkg.API_MI355X, "int8", "NHWC", batch=8)
+    assert opt.shl_mi355x_session_is_device_resident(ms.sess) == 2
+    fused = opt.shl_mi355x_session_fused_pairs(ms.sess)
+    assert fused >= 4, "only %d fused pairs in a batch-8 session" % fused
+    x = ms.synthetic_input(3)
+    got = ms.run(x).reshape(-1)
+    want = oracle_whole_model(ms, x, "int8", "NHWC").reshape(-1)
+    n, worst = cases.mismatch_report(got, want)
+    assert n == 0, "softmax output: %d mismatches (max %d)" % (n, worst)
+    ms.close()
