@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t requant4_clamp(int s0, int s1, int s2, int s
 
 // NCG = C / 32 depthwise channel groups (= pointwise K sub-steps); NOGB = 32-channel output groups per wave
 template <int NCG, int NOGB>
-__global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(ConvArgs d, ConvArgs q, DwPwGeom g)
+__global__ __launch_bounds__(256, NCG <= 2 ? 4 : 3) void dwpw_stream_kernel(ConvArgs d, ConvArgs q, DwPwGeom g)
 {
     constexpr int CB = NCG * 32;        // bytes of a pixel
     constexpr int NCH = CB >> 4;        // 16-byte slots per pixel
@@ -60,8 +60,16 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = lane & 31, half = lane >> 5;
-    const int tx = blockIdx.x;
-    int ty = blockIdx.y, n = 0;
+    // workgroup -> rectangle: consecutive workgroup ids go round the eight XCDs, so XCD x takes the x-th eighth of the
+    // rectangles (row-major over an image, then images): neighbours -- which share their halo rows and columns --
+    // share an L2
+    int rect = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        if ((nwg & 7) == 0 && !(d.debug & 8)) rect = (rect & 7) * (nwg >> 3) + (rect >> 3);
+    }
+    const int tx = rect % g.tiles_x;
+    int ty = rect / g.tiles_x, n = 0;
     if (d.N > 1) {
         n = ty / g.tiles_y;
         ty -= n * g.tiles_y;
@@ -131,24 +139,35 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
         }
 
         const int lchunk = cgl * 2 + half;  // this lane's logical 16-byte slot inside a pixel
+        // byte offsets of the nine taps relative to the patch pixel of tap (0, 0): the slot swizzle looks at the low
+        // bits of the patch row / column only (dw_mfma.h), and a tile moves a lane's pixel by multiples of 4 rows and
+        // 8 columns (stride 2: 8 and 16) -- the swizzle of a tap is the same for every tile, nine registers for the phase
+        int toff[9];
+        {
+            const int px = row & 7, py = row >> 3;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int sz = swz(py * d.sh + ky, px * d.sw + kx) & (NCH - 1);
+                    toff[ky * 3 + kx] = (ky * g.pw + kx) * CB + ((lchunk ^ sz) << 4);
+                }
+        }
+        v16i dinit;  // acc_init (the folded input zero point) as the first MFMA's C operand
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            dinit[4 * e] = dai[e].x, dinit[4 * e + 1] = dai[e].y, dinit[4 * e + 2] = dai[e].z, dinit[4 * e + 3] = dai[e].w;
 #pragma unroll 1
         for (int t = stream; t < ntile; t += NSTREAM) {
             const int tby = g.btx == 2 ? t >> 1 : t, tbx = g.btx == 2 ? t & 1 : 0;
             const int px = tbx * 8 + (row & 7), py = tby * 4 + (row >> 3);  // output pixel inside the workgroup
-            const int pi0 = (py * d.sh) * g.pw + px * d.sw;                 // patch pixel of tap (0, 0)
-            v16i acc;  // starts at acc_init (the folded input zero point)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[4 * e] = dai[e].x, acc[4 * e + 1] = dai[e].y, acc[4 * e + 2] = dai[e].z, acc[4 * e + 3] = dai[e].w;
+            const char *p0 = smem + ((py * d.sh) * g.pw + px * d.sw) * CB;  // patch pixel of tap (0, 0)
+            v16i acc = dinit;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 v4i fb[3];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int pi = pi0 + ky * g.pw + kx;
-                    const int sz = swz(py * d.sh + ky, px * d.sw + kx) & (NCH - 1);
-                    fb[kx] = *reinterpret_cast<const v4i *>(smem + pi * CB + ((lchunk ^ sz) << 4));
-                }
+                for (int kx = 0; kx < 3; ++kx) fb[kx] = *reinterpret_cast<const v4i *>(p0 + toff[ky * 3 + kx]);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ky * 3 + kx], fb[kx], acc, 0, 0, 0);
             }
@@ -200,15 +219,16 @@ __global__ __launch_bounds__(256, NCG == 1 ? 4 : 2) void dwpw_stream_kernel(Conv
                 qbi[e] = *reinterpret_cast<const float4 *>(tq + q.Co * 8 + e * 32);
             }
         }
+        v16i qinit;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            qinit[4 * e] = qai[e].x, qinit[4 * e + 1] = qai[e].y, qinit[4 * e + 2] = qai[e].z, qinit[4 * e + 3] = qai[e].w;
 #pragma unroll 1
         for (int t = t2_0; t < ntile; t += t2_step) {
             const int tby = g.btx == 2 ? t >> 1 : t, tbx = g.btx == 2 ? t & 1 : 0;
             const int px = tbx * 8 + (row & 7), py = tby * 4 + (row >> 3);
             const int oy = oy0 + py, ox = ox0 + px;
-            v16i acc;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[4 * e] = qai[e].x, acc[4 * e + 1] = qai[e].y, acc[4 * e + 2] = qai[e].z, acc[4 * e + 3] = qai[e].w;
+            v16i acc = qinit;
             const char *mp = mid + (t * 32 + row) * MPITCH + half * 16;
 #pragma unroll
             for (int c = 0; c < NCG; ++c) {
@@ -268,7 +288,7 @@ static bool dwpw_geometry(const ConvArgs &d, const ConvArgs &q, DwPwGeom &g, siz
     g.npieces = (slots + 63) / 64;
     g.pw_magic = (uint32_t)((((uint64_t)1 << 32) / (uint32_t)g.pw) + 1);  // exact for j < 2^16 (pw < 2^7)
     *lds = (size_t)g.npieces * 1024 + (size_t)q.Co * 12 + (size_t)g.btx * g.bty * 32 * (d.C + 16);
-    return g.tiles_x <= 65535 && (int64_t)g.tiles_y * d.N <= 65535 && *lds <= 80 * 1024;
+    return (int64_t)g.tiles_x * g.tiles_y * d.N < ((int64_t)1 << 31) && *lds <= 80 * 1024;
 }
 
 // depthwise 3x3 (stride 1 / 2, dot4-packed plan weights) feeding a pointwise layer, both int8 NHWC with clamp epilogues
@@ -306,7 +326,7 @@ int launch_dwpw_stream(const ConvArgs &d, const ConvArgs &q, hipStream_t s)
         set_error("dwpw_stream: the pair does not qualify");
         return SHL_MI355X_ENOTSUP;
     }
-    const dim3 grid((unsigned)g.tiles_x, (unsigned)(g.tiles_y * d.N));
+    const dim3 grid((unsigned)((int64_t)g.tiles_x * g.tiles_y * d.N));
 #define SHL_DWPW(NCGV, NOGBV)                                                                                        \
     do {                                                                                                             \
         static LdsOptIn opted;                                                                                       \
