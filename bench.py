@@ -614,7 +614,7 @@ def main():
                     ("configs[2] (binary16 NHWC view)", "resnet50 3x3 set binary16 NHWC batch 128", wl.RESNET50_3X3, 128, "f16", "NHWC", "mfma", False, 10),
                     ("configs[2] (binary16 NCHW view)", "resnet50 3x3 set binary16 NCHW batch 128", wl.RESNET50_3X3, 128, "f16", "NCHW", "mfma", False, 10),
                     ("configs[3]", "mobilenetv1 fp16 NCHW batch 1 (c906_mobilenetv1_f16 shapes)", wl.MOBILENETV1, 1, "f16", "NCHW", "hbm", True, 50),
-                    ("configs[1] (throughput view)", "mobilenetv1 int8 NHWC batch 128, launches as csinn_session_setup fuses them (depthwise+pointwise pairs of the 32 / 64 / 128-channel blocks in one launch each)", wl.MOBILENETV1, 128,
+                    ("configs[1] (throughput view)", "mobilenetv1 int8 NHWC batch 128, launches as csinn_session_setup fuses them (depthwise+pointwise pairs of the 32 / 64 / 128 / 256-channel blocks in one launch each)", wl.MOBILENETV1, 128,
                      "int8", "NHWC", "hbm", True, 20)):
                 try:
                     result["configs"].append(measure_config(tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, chained_x, env, steps=steps_x,
