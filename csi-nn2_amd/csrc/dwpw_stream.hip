@@ -157,26 +157,29 @@ __global__ __launch_bounds__(256, NCG <= 2 ? 4 : 3) void dwpw_stream_kernel(Conv
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             dinit[4 * e] = dai[e].x, dinit[4 * e + 1] = dai[e].y, dinit[4 * e + 2] = dai[e].z, dinit[4 * e + 3] = dai[e].w;
+        // a lane's share of the addresses is the same for every tile; the tile's share is wave-uniform (scalar unit)
+        const char *const lane_p0 = smem + (((row >> 3) * d.sh) * g.pw + (row & 7) * d.sw) * CB;  // tap (0, 0) of tile 0
+        char *const lane_mid = mid + row * MPITCH + lchunk * 16;
 #pragma unroll 1
         for (int t = stream; t < ntile; t += NSTREAM) {
             const int tby = g.btx == 2 ? t >> 1 : t, tbx = g.btx == 2 ? t & 1 : 0;
-            const int px = tbx * 8 + (row & 7), py = tby * 4 + (row >> 3);  // output pixel inside the workgroup
-            const char *p0 = smem + ((py * d.sh) * g.pw + px * d.sw) * CB;  // patch pixel of tap (0, 0)
-            v16i acc = dinit;
+            const char *p0 = lane_p0 + ((tby * 4 * d.sh) * g.pw + tbx * 8 * d.sw) * CB;
+            v16i acc;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 v4i fb[3];
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) fb[kx] = *reinterpret_cast<const v4i *>(p0 + toff[ky * 3 + kx]);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ky * 3 + kx], fb[kx], acc, 0, 0, 0);
+                for (int kx = 0; kx < 3; ++kx)  // the first MFMA takes acc_init as its C operand: no copy per tile
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ky * 3 + kx], fb[kx], ky + kx == 0 ? dinit : acc, 0, 0, 0);
             }
             uint32_t pk[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 pk[e] = requant4_clamp(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3], dmu[e], dbi[e], d);
             // 16 consecutive channels of the lane's pixel = its piece of the pointwise B fragment of sub-step cgl
-            *reinterpret_cast<uint4 *>(mid + (t * 32 + row) * MPITCH + lchunk * 16) = tile_channels_16(pk);
+            *reinterpret_cast<uint4 *>(lane_mid + t * (32 * MPITCH)) = tile_channels_16(pk);
         }
     });
     // ---- the wave's pointwise weights (A fragments, plan order [32-channel group][K / 32][lane][16 B]; L2-resident: every
@@ -197,6 +200,9 @@ __global__ __launch_bounds__(256, NCG <= 2 ? 4 : 3) void dwpw_stream_kernel(Conv
 
     // ---- phase 2: pointwise layer on the parked tiles, output group by output group: a group's tables sit in registers
     // for all the wave's tiles (the B fragments are read again per group: C / 32 ds_read_b128 instead of 12 table reads)
+    const int lane_oy = oy0 + (row >> 3), lane_ox = ox0 + (row & 7);  // tile 0's pixel of this lane
+    char *const lane_out = static_cast<char *>(q.out) + (((int64_t)n * d.Ho + lane_oy) * d.Wo + lane_ox) * q.Co + half * 16;
+    const char *const lane_mid2 = mid + row * MPITCH + half * 16;
     static_for<NOGB>([&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
         const int og = ogb * NOGB + j;
@@ -226,22 +232,20 @@ __global__ __launch_bounds__(256, NCG <= 2 ? 4 : 3) void dwpw_stream_kernel(Conv
 #pragma unroll 1
         for (int t = t2_0; t < ntile; t += t2_step) {
             const int tby = g.btx == 2 ? t >> 1 : t, tbx = g.btx == 2 ? t & 1 : 0;
-            const int px = tbx * 8 + (row & 7), py = tby * 4 + (row >> 3);
-            const int oy = oy0 + py, ox = ox0 + px;
-            v16i acc = qinit;
-            const char *mp = mid + (t * 32 + row) * MPITCH + half * 16;
+            v16i acc;
+            const char *mp = lane_mid2 + t * (32 * MPITCH);
 #pragma unroll
             for (int c = 0; c < NCG; ++c) {
                 const v4i fb = *reinterpret_cast<const v4i *>(mp + c * 32);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fj[c], fb, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fj[c], fb, c == 0 ? qinit : acc, 0, 0, 0);
             }
             uint32_t pk[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 pk[e] = requant4_clamp(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3], qmu[e], qbi[e], q);
             const uint4 v = tile_channels_16(pk);
-            if (oy < d.Ho && ox < d.Wo)
-                *reinterpret_cast<uint4 *>(static_cast<char *>(q.out) + (((int64_t)n * d.Ho + oy) * d.Wo + ox) * q.Co + og * 32 + half * 16) = v;
+            if (lane_oy + tby * 4 < d.Ho && lane_ox + tbx * 8 < d.Wo)
+                *reinterpret_cast<uint4 *>(lane_out + ((int64_t)(tby * 4) * d.Wo + tbx * 8) * q.Co + og * 32) = v;
         }
     });
 }
