@@ -538,6 +538,7 @@ bool stem_mfma_pick(const ConvArgs &a);  // conv_stem.hip: the matrix-core form 
 // stem 3x3 (3 -> 32) + the depthwise 3x3 consuming it in one launch (stemdw_fused.hip)
 // depthwise 3x3 + the pointwise layer consuming it, bandwidth form for large batches (dwpw_stream.hip)
 bool dwpw_stream_fusable(const ConvArgs &dw, const ConvArgs &pw, int dw_dot4_packed, int pw_is_igemm);
+bool dwpw_stream_takes(const ConvArgs &dw);  // the depthwise layer belongs to a depthwise -> pointwise launch (throughput sizes)
 int launch_dwpw_stream(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);
 bool pwdw_f16_nchw_fusable(const ConvArgs &pw, const ConvArgs &dw);  // binary16 NCHW form (pwdw_f16_nchw.hip)
 int launch_pwdw_f16_nchw(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);

@@ -962,6 +962,12 @@ static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv
         if (pw_igemm) return pwdw_f16_nchw_fusable(a, b) ? 4 : 0;
         return pw->algo == SHL_MI355X_ALGO_DIRECT && stemdw_f16_nchw_fusable(a, b) ? 5 : 0;
     }
+    // int8 NHWC latency forms: at throughput sizes the depthwise layer belongs to the pair with the pointwise layer BEHIND it
+    // (dwpw_stream.hip); a chain pairs up one way round
+    {
+        static const char *sel = getenv("SHL_MI355X_PWDW");  // "2": latency forms without size rules (A/B)
+        if (!(sel && sel[0] == '2') && dw_dot4 && dwpw_stream_takes(b)) return 0;
+    }
     if (pw->algo == SHL_MI355X_ALGO_STEM) return dw_dot4 && stemdw_fusable(a, b) ? 3 : 0;  // stem + depthwise
     return pwdw_fusable(a, b, pw_igemm, dw_dot4) ? 1 : 0;
 }

@@ -295,31 +295,42 @@ static bool dwpw_geometry(const ConvArgs &d, const ConvArgs &q, DwPwGeom &g, siz
     return (int64_t)g.tiles_x * g.tiles_y * d.N < ((int64_t)1 << 31) && *lds <= 80 * 1024;
 }
 
+// the depthwise layer's side of the rule: would this layer be the first of a depthwise -> pointwise launch (given a
+// pointwise consumer the form takes)?  The latency forms of the OTHER order (pwdw_fused.hip, stemdw_fused.hip) ask this
+// about the depthwise layer they would take, and leave it to this form when the answer is yes.
+//   by size   from 4 MB of intermediate tensor whatever the batch (large images)
+//   by batch  from batch 8 every eligible block: a chain pairs up ONE way round (a block left to the latency form shifts
+//             its neighbours into single launches), and from batch 8 the whole model is faster this way round
+//             (profiles/r05_dwpw_sweep_whole_model.txt: MobileNetV1 at batch 8 / 16 / 32 / 64 / 128 143 / 176 / 233 / 341 /
+//             526 us without this form, 130 / 157 / 206 / 300 / 466 with it; at batch 4 a by-size rule of 1 MB took two
+//             blocks, left four single launches behind and lost 3 %; layers 1 .. 12 alone: r05_dwpw_sweep.txt)
+//   not       256 channels at stride 2 (8 x 4 rectangles, one tile per workgroup, weights fetched per output group):
+//             21.7 us against 8.7 + 10.8 for MobileNetV1's 256 @28 s2 -> 512 @14 at batch 128 -- correct (tests force it)
+bool dwpw_stream_takes(const ConvArgs &d)
+{
+    if (d.Kh != 3 || d.Kw != 3 || d.dh != 1 || d.dw != 1 || d.sh != d.sw || d.sh < 1 || d.sh > 2) return false;
+    if (d.C != 32 && d.C != 64 && d.C != 128 && d.C != 256) return false;
+    if (d.Co != d.C || d.in_nchw || d.out_nchw || !clamp_epilogue(d)) return false;
+    const char *env = getenv("SHL_MI355X_DWPW");  // "0" never, "1" always (tests, A/B); read per call: tests switch it
+    if (env && env[0] == '0') return false;
+    if (env && env[0] == '1') return true;
+    if (d.C == 256 && d.sh != 1) return false;
+    return d.N >= 8 || (int64_t)d.M * d.C >= (int64_t)4 << 20;
+}
+
 // depthwise 3x3 (stride 1 / 2, dot4-packed plan weights) feeding a pointwise layer, both int8 NHWC with clamp epilogues
 bool dwpw_stream_fusable(const ConvArgs &d, const ConvArgs &q, int dw_dot4_packed, int pw_is_igemm)
 {
     if (!dw_dot4_packed || !pw_is_igemm) return false;
-    if (d.Kh != 3 || d.Kw != 3 || d.dh != 1 || d.dw != 1 || d.sh != d.sw || d.sh < 1 || d.sh > 2) return false;
-    if (d.C != 32 && d.C != 64 && d.C != 128 && d.C != 256) return false;
-    if (d.Co != d.C) return false;
     if (q.Kh != 1 || q.Kw != 1 || q.sh != 1 || q.sw != 1 || q.pt != 0 || q.pl != 0) return false;
     if (q.C != d.C || q.H != d.Ho || q.W != d.Wo || q.Ho != d.Ho || q.Wo != d.Wo || q.N != d.N) return false;
-    if (!q.w_frag || q.out_nchw || q.in_nchw || d.in_nchw) return false;
-    if (!clamp_epilogue(d) || !clamp_epilogue(q)) return false;
+    if (!q.w_frag || q.out_nchw || q.in_nchw) return false;
+    if (!clamp_epilogue(q)) return false;
     if ((int64_t)d.H * d.W * d.C >= ((int64_t)1 << 31)) return false;
+    if (!dwpw_stream_takes(d)) return false;
     DwPwGeom g;
     size_t lds;
-    if (!dwpw_geometry(d, q, g, &lds)) return false;
-    const char *env = getenv("SHL_MI355X_DWPW");  // "0" never, "1" always (tests, A/B), default: by size; read per call: tests switch it
-    if (env && env[0] == '0') return false;
-    if (env && env[0] == '1') return true;
-    // from a megabyte of intermediate tensor (MobileNetV1's first blocks from batch 4): measured against the pointwise ->
-    // depthwise latency form + single launches over batches 4 .. 128 (profiles/r05_dwpw_sweep.txt: ahead at every batch;
-    // callers pair greedily from the front, so the latency form keeps the pairs it accepts)
-    // 256 channels at stride 2 (8 x 4 rectangles, one tile per workgroup, weights fetched per output group): 21.7 us
-    // against 8.7 + 10.8 for MobileNetV1's 256 @28 s2 -> 512 @14 at batch 128 -- correct (tests force it), not chosen
-    if (d.C == 256 && d.sh != 1) return false;
-    return (int64_t)d.M * d.C >= (int64_t)1 << 20;
+    return dwpw_geometry(d, q, g, &lds);
 }
 
 int launch_dwpw_stream(const ConvArgs &d, const ConvArgs &q, hipStream_t s)

@@ -327,10 +327,14 @@ bool pwdw_fusable(const ConvArgs &q, const ConvArgs &d, int pw_is_igemm, int dw_
     // MobileNetV1 pair drops from 6.7-7.9 us to 4.2-5.3 us, at batch 128 the stand-alone kernels
     // (bandwidth-tuned, 1.3-3.4 TB/s) are 1.5-2x faster; the whole chain breaks even at batch 16
     // (profiles/r01_notes.md).  Fuse while the workgroups fit a few rounds on the 256 CUs (MobileNetV1
-    // up to batch 8); SHL_MI355X_PWDW=2 lifts the limit (measurements).
+    // up to batch 8 for the 512-channel blocks; the blocks of at most 256 channels leave for dwpw_stream.hip from batch 8:
+    // conv_plan.hip:pwdw_kernel_for); SHL_MI355X_PWDW=2 lifts the limit (measurements).
     static const char *sel = getenv("SHL_MI355X_PWDW");
     const int64_t blocks = (int64_t)(q.Co >> 5) * f.tiles_x * f.tiles_y * d.N;
-    if (blocks > 2048 && !(sel && sel[0] == '2')) return false;
+    // (round 5: 512, was 2048 -- the stand-alone kernels got faster: with 2048 MobileNetV1's 512-channel blocks stayed latency
+    // pairs up to batch 32 and the whole model ran 180 / 267 us at batch 16 / 32 against 158 / 210 with 512; batches 1 .. 8
+    // keep every pair either way: profiles/r05_dwpw_sweep_whole_model.txt)
+    if (blocks > 512 && !(sel && sel[0] == '2')) return false;
     return true;
 }
 

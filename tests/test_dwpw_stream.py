@@ -105,12 +105,13 @@ def test_depthwise_pointwise_pair_equals_the_two_kernels_and_the_oracle(gpu, i, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c,co,hw,stride,n", [(32, 64, 112, 1, 4), (64, 128, 112, 2, 8), (128, 128, 56, 1, 4),
-                                              (128, 256, 56, 2, 16), (256, 256, 28, 1, 8),
+@pytest.mark.parametrize("c,co,hw,stride,n", [(32, 64, 112, 1, 8), (64, 128, 112, 2, 8), (128, 128, 56, 1, 8),
+                                              (128, 256, 56, 2, 8), (256, 256, 28, 1, 8), (32, 64, 224, 1, 3),
                                               (128, 128, 56, 1, 128)])
 def test_mobilenet_blocks_at_a_throughput_batch_fuse_by_the_size_rule(gpu, c, co, hw, stride, n):
     """MobileNetV1's first separable blocks (example/c906_mobilenetv1_f16.c:1888-1947 shapes, int8 NHWC) at the smallest
-    batch the size rule takes (and one block at batch 128): fused by default, bit-identical to the two launches"""
+    batch the rule takes (8; a 224 x 224 map by its size at batch 3; one block at batch 128): fused by default, bit-identical
+    to the two launches"""
     fe, hip, opt = gpu
     dw, pw = make_dwpw(40 + c // 32 + stride, c=c, co=co, hw=hw, stride=stride, n=n, exact=False)
     dev, keep, plan_dw, plan_pw, want = run_pair(gpu, dw, pw, oracle=False)

@@ -16,14 +16,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def one(batch, last):
+def one(batch, last, first=1):
     import cases
     pkg = cases.pkg
     wl = importlib.import_module("csi-nn2_amd.workloads")
     fe = pkg.load_frontend("standalone")
     hip, opt = pkg.load_backend(fe)
     dev = cases.HipDevice(hip)
-    layers = wl.MOBILENETV1[1:last + 1]
+    layers = wl.MOBILENETV1[first:last + 1]
     chain = wl.LayerChain(fe, hip, opt, layers, batch, dev.alloc, dev.upload, dtype="int8", layout="NHWC", chained=True, fuse=True)
     stream = hip.shl_mi355x_stream_create()
     ev0, ev1 = hip.shl_mi355x_event_create(), hip.shl_mi355x_event_create()
@@ -50,17 +50,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="8,16,32,64,128")
     ap.add_argument("--last", type=int, default=12, help="last MobileNetV1 layer index of the run (12: 256 -> 512 @14)")
+    ap.add_argument("--first", type=int, default=1, help="first layer index (0: the stem, i.e. the pairing of a whole model)")
     ap.add_argument("--one", type=int, default=0)
     a = ap.parse_args()
     if a.one:
-        return one(a.one, a.last)
+        return one(a.one, a.last, a.first)
     for b in (int(x) for x in a.batches.split(",")):
         for sel in ("0", None, "1"):
             env = dict(os.environ)
             env.pop("SHL_MI355X_DWPW", None)
             if sel is not None:
                 env["SHL_MI355X_DWPW"] = sel
-            subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(b), "--last", str(a.last)], env=env, timeout=300)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(b), "--last", str(a.last), "--first", str(a.first)], env=env, timeout=300)
 
 
 if __name__ == "__main__":
