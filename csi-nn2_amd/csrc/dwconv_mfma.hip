@@ -45,7 +45,7 @@ struct DwmGeom {
 };
 
 template <int EPI>
-__global__ __launch_bounds__(256) void dwconv3x3_i8_mfma_kernel(ConvArgs a, DwmGeom g)
+__global__ __launch_bounds__(256, 4) void dwconv3x3_i8_mfma_kernel(ConvArgs a, DwmGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -111,30 +111,41 @@ __global__ __launch_bounds__(256) void dwconv3x3_i8_mfma_kernel(ConvArgs a, DwmG
     const char *tab_l = tab + (cgl * 32 + 4 * half) * 4;  // this lane's first channel in each table
     const int tab_stride = g.cb * 4;
     char *outp = static_cast<char *>(a.out) + ch0 + half * 16;
+    // byte offsets of the nine taps relative to the patch pixel of tap (0, 0): the slot swizzle looks at the low bits of the
+    // patch row / column only (dw_mfma.h) and a tile moves a lane's pixel by multiples of 4 rows and 8 columns (stride 2: 8 and
+    // 16), so a tap's swizzle is the same for every tile -- nine registers instead of ~45 VALU instructions per tile (round 5,
+    // found in dwpw_stream.hip: these kernels are bound by VALU + MFMA issue on 14 x 14 and 7 x 7 maps)
+    int toff[9];
+    {
+        const int px = row & 7, py = row >> 3;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sz = swz(py * a.sh + ky, px * a.sw + kx) & nch_mask;
+                toff[ky * 3 + kx] = (ky * g.pw + kx) * g.cb + ((lchunk ^ sz) << 4);
+            }
+    }
+    v16i ainit;  // acc_init (the folded input zero point): the first MFMA's C operand, no copy per tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int4 ai = *reinterpret_cast<const int4 *>(tab_l + q * 32);
+        ainit[4 * q] = ai.x, ainit[4 * q + 1] = ai.y, ainit[4 * q + 2] = ai.z, ainit[4 * q + 3] = ai.w;
+    }
+    const char *const lane_p0 = smem + (((row >> 3) * a.sh) * g.pw + (row & 7) * a.sw) * g.cb;  // tap (0, 0) of tile 0
     for (int t = stream; t < ntile; t += nstream) {
         const int tby = g.btx == 2 ? t >> 1 : t, tbx = g.btx == 2 ? t & 1 : 0;
         const int px = tbx * 8 + (row & 7), py = tby * 4 + (row >> 3);  // output pixel inside the workgroup
-        const int pi0 = (py * a.sh) * g.pw + px * a.sw;                 // patch pixel of tap (0, 0)
-        v16i acc;  // starts at acc_init (the folded input zero point)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int4 ai = *reinterpret_cast<const int4 *>(tab_l + q * 32);
-            acc[4 * q] = ai.x;
-            acc[4 * q + 1] = ai.y;
-            acc[4 * q + 2] = ai.z;
-            acc[4 * q + 3] = ai.w;
-        }
+        const char *p0 = lane_p0 + ((tby * 4 * a.sh) * g.pw + tbx * 8 * a.sw) * g.cb;
+        v16i acc;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             v4i fb[3];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int pi = pi0 + ky * g.pw + kx;
-                const int sz = swz(py * a.sh + ky, px * a.sw + kx) & nch_mask;
-                fb[kx] = *reinterpret_cast<const v4i *>(smem + pi * g.cb + ((lchunk ^ sz) << 4));
-            }
+            for (int kx = 0; kx < 3; ++kx) fb[kx] = *reinterpret_cast<const v4i *>(p0 + toff[ky * 3 + kx]);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ky * 3 + kx], fb[kx], acc, 0, 0, 0);
+            for (int kx = 0; kx < 3; ++kx)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ky * 3 + kx], fb[kx], ky + kx == 0 ? ainit : acc, 0, 0, 0);
         }
         uint32_t pk[4];
 #pragma unroll
