@@ -96,6 +96,10 @@ __global__ __launch_bounds__(512) void conv1x1_resident_kernel(ConvArgs a, int n
         mu[g] = *reinterpret_cast<const float4 *>(a.mult + ch0 + 8 * g + 4 * half);
         bi[g] = *reinterpret_cast<const float4 *>(a.bias + ch0 + 8 * g + 4 * half);
     }
+    v16i ainit;  // the plan's acc_init in accumulator order (rows 8 g + 4 half + e)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ainit[4 * g] = ai[g].x, ainit[4 * g + 1] = ai[g].y, ainit[4 * g + 2] = ai[g].z, ainit[4 * g + 3] = ai[g].w;
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // ---- this wave's weights: 32 channels x K, fragment order (conv_plan.hip: [32-channel group][K / 32][lane][16 B])
     const char *wp = static_cast<const char *>(a.w_frag) + ((int64_t)(ch0 >> 5) * NSUB) * 1024 + lane * 16;
     v4i fw[NSUB];
@@ -110,15 +114,12 @@ __global__ __launch_bounds__(512) void conv1x1_resident_kernel(ConvArgs a, int n
         // NBLK >= 2: one accumulator per pixel block (independent chains).  NBLK == 1 (K >= 512): two chains over the even
         // and the odd K sub-steps of the one block (a chain of dependent MFMAs issues at half rate), summed exactly at the
         // end.  Chain 0 of a block starts at the plan's acc_init.
+        // (the chains' start values are the first MFMA's C operand -- ainit / the inline constant 0 --, not 16 - 32 v_mov per tile)
         v16i acc[NACC];
+        if (a.debug & 1) {  // (ablation without the K loop: defined values)
 #pragma unroll
-        for (int q = 0; q < NACC; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const bool init = NBLK > 1 || q == 0;
-                acc[q][4 * g] = init ? ai[g].x : 0, acc[q][4 * g + 1] = init ? ai[g].y : 0;
-                acc[q][4 * g + 2] = init ? ai[g].z : 0, acc[q][4 * g + 3] = init ? ai[g].w : 0;
-            }
+            for (int q = 0; q < NACC; ++q) acc[q] = ainit;
+        }
         static_for<NKC>([&](auto kc_c) {
             constexpr int kc = decltype(kc_c)::value;
             const int s = t * NKC + kc;
@@ -139,7 +140,9 @@ __global__ __launch_bounds__(512) void conv1x1_resident_kernel(ConvArgs a, int n
                 for (int b = 0; b < NBLK; ++b) {
                     const v4i fb = *reinterpret_cast<const v4i *>(st + b * 32 * ROWB + sl);
                     const int q = NBLK == 1 ? (u & 1) : b;
-                    acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[kc * KSUB + u], fb, acc[q], 0, 0, 0);
+                    const bool first = kc == 0 && (NBLK == 1 ? u < 2 : u == 0);  // compile time: kc, u and b are unrolled
+                    const bool from_init = NBLK > 1 || q == 0;
+                    acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[kc * KSUB + u], fb, first ? (from_init ? ainit : zero16) : acc[q], 0, 0, 0);
                 }
             }
         });
