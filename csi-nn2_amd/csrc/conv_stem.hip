@@ -149,6 +149,12 @@ __global__ __launch_bounds__(256) void conv_stem_i8_mfma_kernel(ConvArgs a, int 
             bi[cb][g] = *reinterpret_cast<const float4 *>(a.bias + c);
             ai[cb][g] = *reinterpret_cast<const int4 *>(a.acc_init + c);
         }
+    v16i ainit[NCB];  // acc_init in accumulator order
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            ainit[cb][4 * g] = ai[cb][g].x, ainit[cb][4 * g + 1] = ai[cb][g].y, ainit[cb][4 * g + 2] = ai[cb][g].z, ainit[cb][4 * g + 3] = ai[cb][g].w;
     const int total = a.N * a.H * a.W * 3;  // < 2^31 (host)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.in), 0, total, 0x00020000);
     const uint32_t zp4 = (uint32_t)(a.in_zp & 0xff) * 0x01010101u;
@@ -221,16 +227,15 @@ __global__ __launch_bounds__(256) void conv_stem_i8_mfma_kernel(ConvArgs a, int 
         v4i fb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = (int)(khalf ? kd[4 + j] : kd[j]);
-        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         int8_t *outp = static_cast<int8_t *>(a.out) + (int64_t)t.p * a.Co + khalf * 16;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            const v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[cb], fb, zero16, 0, 0, 0);
+            // acc_init rides in as the C operand (16 v_add per block less)
+            const v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[cb], fb, ainit[cb], 0, 0, 0);
             uint32_t pk[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                pk[g] = requant4_i8_t<EPI>(acc[4 * g] + ai[cb][g].x, acc[4 * g + 1] + ai[cb][g].y, acc[4 * g + 2] + ai[cb][g].z,
-                                           acc[4 * g + 3] + ai[cb][g].w, mu[cb][g], bi[cb][g], a);
+                pk[g] = requant4_i8_t<EPI>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], mu[cb][g], bi[cb][g], a);
             const uint4 v = tile_channels_16(pk);
             if (t.p < (uint32_t)a.M && cb * 32 + khalf * 16 + 16 <= a.Co) *reinterpret_cast<uint4 *>(outp + cb * 32) = v;
         }
