@@ -42,6 +42,8 @@ FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kern
     ("dwconv_nhwc_kernel<true", "dwconv_nhwc_i8"),
     ("dwconv3x3_i8_dot4_kernel", "dwconv_nhwc_i8"),
     ("dwpw_fused_kernel", "dwpw_fused_i8"),
+    ("dwpw_stream_kernel", "dwpw_stream_i8"),
+    ("conv1x1_resident_kernel", "conv1x1_resident_i8_mfma32x32x32"),
     ("pwdw_f16_nchw_kernel", "pwdw_f16_nchw"),
     ("stemdw_f16_nchw_kernel", "stemdw_f16_nchw"),
     ("conv_group_direct_kernel", "conv_group_direct"),
