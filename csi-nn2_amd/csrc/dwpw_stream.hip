@@ -12,13 +12,21 @@
 //
 //   workgroup  a rectangle of output pixels (MFMA pixel tiles of 8 x 4) x ALL C = 32 / 64 / 128 / 256 channels; the
 //              input patch (+ halo) goes HBM -> LDS once by global_load_lds_dwordx4, padding from the pad page
-//              (exactly dwconv_mfma.hip's staging)
-//   phase 1    wave = one 32-channel group x the rectangle's tiles (fewer groups: tiles dealt out): nine MFMAs
-//              with the diagonal tap matrices, the depthwise layer's own requantisation (+ relu) to int8, the
-//              16-byte B fragment parked in LDS [tile][pixel][C + 16] (the pitch is conflict-free)
-//   phase 2    wave = one pixel tile x NOGB groups of 32 output channels (pointwise weights of the wave's
-//              channel groups in registers as A fragments, requested at the top of the kernel): C / 32 MFMAs per
-//              group, the pointwise layer's requantisation, one 16-byte store per lane and group
+//              (exactly dwconv_mfma.hip's staging); workgroup id -> rectangle is XCD-contiguous (neighbours share
+//              their halo lines in one L2: HBM traffic 1.005 x the algorithmic bytes by the PMC counters)
+//   phase 1    wave = one 32-channel group (256 channels: two) x the rectangle's tiles (fewer groups: tiles dealt
+//              out): the group's nine diagonal fragments, its epilogue tables and the nine tap offsets (the slot
+//              swizzle is tile invariant) in registers for the phase; nine MFMAs per tile starting from acc_init as
+//              the C operand, the depthwise layer's own requantisation (+ relu as a clamp) to int8, the 16-byte B
+//              fragment parked in LDS [tile][pixel][C + 16] (the pitch is conflict-free)
+//   phase 2    wave = pixel tiles x NOGB groups of 32 output channels, output group by output group: a group's
+//              tables (48 registers) and A fragments (pointwise weights from the plan's fragment-ordered copy; up to
+//              64 registers requested ahead of the barrier, deeper sets per group) serve all the wave's tiles, whose
+//              C / 32 B fragments are read again per group; the pointwise layer's requantisation, one 16-byte store
+//              per lane, tile and group
+// Bound by VALU + MFMA issue (75 - 85 % of a launch, profiles/r05_e_pmc_dwpw.txt): two requantisations of ~124 VALU per
+// 32 x 32 unit.  Tables read from LDS per tile -- the first version -- ran at the LDS pipe's rate, and hipcc hoists such
+// reads out of the tile loops into 48 registers per group and spills: they are in registers on purpose.
 // The intermediate is bit-identical to what the stand-alone depthwise kernel writes to HBM, so the pair is
 // bit-identical to the two launches (tests/test_dwpw_stream.py).  Both layers keep their own plans.
 // Restates shl_ref_depthwise_conv2d_quant followed by shl_ref_conv2d_quant
