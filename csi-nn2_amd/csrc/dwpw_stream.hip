@@ -292,15 +292,26 @@ static bool dwpw_geometry(const ConvArgs &d, const ConvArgs &q, DwPwGeom &g, siz
         g.bty = 1;
     }
     while (g.bty > 1 && (g.bty - 1) * 4 >= d.Ho) --g.bty;
-    g.tiles_x = (d.Wo + g.btx * 8 - 1) / (g.btx * 8);
-    g.tiles_y = (d.Ho + g.bty * 4 - 1) / (g.bty * 4);
-    g.pw = (g.btx * 8 - 1) * d.sw + 3;
-    g.ph = (g.bty * 4 - 1) * d.sh + 3;
-    const int slots = g.pw * g.ph * (d.C >> 4);
-    g.npieces = (slots + 63) / 64;
+    // a rectangle whose patch + parked tiles pass 80 KB (two workgroups per CU) gives up rows, then a column of tiles
+    // (128 channels at stride 2 with one pass: fewer tiles than waves in phase 2 -- correct, and still one launch)
+    for (;;) {
+        g.tiles_x = (d.Wo + g.btx * 8 - 1) / (g.btx * 8);
+        g.tiles_y = (d.Ho + g.bty * 4 - 1) / (g.bty * 4);
+        g.pw = (g.btx * 8 - 1) * d.sw + 3;
+        g.ph = (g.bty * 4 - 1) * d.sh + 3;
+        const int slots = g.pw * g.ph * (d.C >> 4);
+        g.npieces = (slots + 63) / 64;
+        *lds = (size_t)g.npieces * 1024 + (size_t)q.Co * 12 + (size_t)g.btx * g.bty * 32 * (d.C + 16);
+        if (*lds <= 80 * 1024) break;
+        if (g.bty > 1)
+            g.bty = (g.bty + 1) / 2;
+        else if (g.btx > 1)
+            g.btx = 1;
+        else
+            return false;
+    }
     g.pw_magic = (uint32_t)((((uint64_t)1 << 32) / (uint32_t)g.pw) + 1);  // exact for j < 2^16 (pw < 2^7)
-    *lds = (size_t)g.npieces * 1024 + (size_t)q.Co * 12 + (size_t)g.btx * g.bty * 32 * (d.C + 16);
-    return (int64_t)g.tiles_x * g.tiles_y * d.N < ((int64_t)1 << 31) && *lds <= 80 * 1024;
+    return (int64_t)g.tiles_x * g.tiles_y * d.N < ((int64_t)1 << 31);
 }
 
 // the depthwise layer's side of the rule: would this layer be the first of a depthwise -> pointwise launch (given a

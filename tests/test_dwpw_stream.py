@@ -132,3 +132,39 @@ def test_pairs_outside_the_form_are_refused(gpu, monkeypatch):
         assert hip.shl_mi355x_pwdw_forward(plan_dw, plan_pw, 16, 16, 1, None) == -3  # ENOTSUP, nothing launched
         for p, _ in keep:
             opt.shl_mi355x_release_params(p)
+
+
+def _fuzz_case(rng):
+    c = int(rng.choice([32, 64, 128, 256]))
+    # output-channel counts the form instantiates: C = 32: 64 k (k = 1, 2, 4); 64 / 128: 128 k; 256: 256 or 512
+    co = int(rng.choice({32: [64, 128, 256], 64: [128, 256, 512], 128: [128, 256, 512], 256: [256, 512]}[c]))
+    stride = int(rng.choice([1, 2]))
+    hw = int(rng.integers(3, 40 if c <= 64 else 24))
+    n = int(rng.integers(1, 4))
+    relu = (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+    pad = (1, 1, 1, 1) if rng.random() < 0.7 else tuple(int(x) for x in rng.integers(0, 3, 4))
+    if (hw + pad[0] + pad[2] - 3) // stride + 1 < 1 or (hw + pad[1] + pad[3] - 3) // stride + 1 < 1:
+        pad = (1, 1, 1, 1)
+    return dict(c=c, co=co, hw=hw, stride=stride, n=n, relu=relu, exact=bool(rng.random() < 0.5), pad=pad)
+
+
+@pytest.mark.gpu
+def test_seeded_random_pairs_equal_the_two_kernels(gpu, monkeypatch):
+    """48 seeded random blocks (channel counts the form instantiates, odd map sizes, both strides, asymmetric padding, batches
+    1 .. 3, exact and converter scales, every activation combination) forced through the fused launch: bit-identical to
+    the two stand-alone kernels; every fourth case also against the oracle chain."""
+    fe, hip, opt = gpu
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SHL_TEST_FUZZ_SEED", "20260930")))  # (a longer one-off run: both variables)
+    monkeypatch.setenv("SHL_MI355X_DWPW", "1")
+    for k in range(int(os.environ.get("SHL_TEST_FUZZ_N", "48"))):
+        kw = _fuzz_case(rng)
+        dw, pw = make_dwpw(200 + k, **kw)
+        dev, keep, plan_dw, plan_pw, want = run_pair(gpu, dw, pw, oracle=(k % 4 == 0))
+        assert hip.shl_mi355x_pwdw_fusable(plan_dw, plan_pw, dw["n"]) == 1, kw
+        try:
+            fused_equals(gpu, dev, plan_dw, plan_pw, dw, want)
+        except AssertionError as e:
+            raise AssertionError("case %d %r: %s" % (k, kw, e))
+        for p, _ in keep:
+            opt.shl_mi355x_release_params(p)
