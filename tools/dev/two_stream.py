@@ -17,6 +17,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--parts", type=int, default=2)
+    ap.add_argument("--set", default="mobilenet", choices=["mobilenet", "resnet"])
+    ap.add_argument("--layout", default="NHWC")
     a = ap.parse_args()
     import cases
     pkg = cases.pkg
@@ -28,8 +30,12 @@ def main():
     def build(batch, n):
         out = []
         for k in range(n):
-            c = wl.LayerChain(fe, hip, opt, wl.MOBILENETV1, batch, dev.alloc, dev.upload, dtype="int8", layout="NHWC", chained=True,
-                              fuse=True, seed=1234 + k)
+            if a.set == "resnet":
+                c = wl.LayerChain(fe, hip, opt, wl.RESNET50_3X3, batch, dev.alloc, dev.upload, dtype="int8", layout=a.layout,
+                                  chained=False, fuse=False, seed=1234 + k)
+            else:
+                c = wl.LayerChain(fe, hip, opt, wl.MOBILENETV1, batch, dev.alloc, dev.upload, dtype="int8", layout="NHWC", chained=True,
+                                  fuse=True, seed=1234 + k)
             s = hip.shl_mi355x_stream_create()
             c.capture(s)
             out.append((c, s))
