@@ -187,10 +187,12 @@ def load_hip():
         "shl_mi355x_graph_launch": (C.c_int, [vp, vp]),
         "shl_mi355x_graph_destroy": (C.c_int, [vp]),
         "shl_mi355x_conv_plan_create": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(vp)]),
+        "shl_mi355x_conv_plan_create_wzp": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, C.POINTER(vp)]),
         "shl_mi355x_conv_plan_create_dw_channel": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, f32, f32, vp, C.POINTER(vp)]),
         "shl_mi355x_debug_trace": (C.c_int, [vp, i32]),
         "shl_mi355x_debug_div_check": (C.c_int, [vp, i32, vp, vp]),
         "shl_mi355x_debug_f16_round_check": (C.c_int, [vp]),
+        "shl_mi355x_debug_mfma_rate": (C.c_int, [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "shl_mi355x_comm_available": (C.c_int, []),
         "shl_mi355x_comm_unique_id": (C.c_int, [vp]),
         "shl_mi355x_comm_create": (C.c_int, [vp, i32, i32, C.POINTER(vp)]),

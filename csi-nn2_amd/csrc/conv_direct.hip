@@ -58,6 +58,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a)
 
         int32_t acc_i = 0;
         float acc_f = 0.0f;
+        // int8: the kernel's zero point of this output channel (int8_to_float_base, source/nn2/utils.c:499-502, applies
+        // qinfo[oc].zero_point to weights as to activations); zero for symmetric weights
+        int32_t wz = 0;
+        if constexpr (sizeof(T) == 1) wz = a.acc_init[oc];
         for (int ky = 0; ky < a.Kh; ++ky) {
             const int y = y0 + ky * a.dh;
             if (y < 0 || y >= a.H) continue;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a)
                     const int64_t wi =
                         weight_index<kNHWC, kDwWeightsLast>(a, oc, ky, kx, ic, cpg);
                     if constexpr (sizeof(T) == 1) {
-                        acc_i += ((int32_t)in[ii] - a.in_zp) * (int32_t)w[wi];
+                        acc_i += ((int32_t)in[ii] - a.in_zp) * ((int32_t)w[wi] - wz);
                     } else {
                         const float p = __fmul_rn((float)in[ii], (float)w[wi]);
                         acc_f = __fadd_rn(acc_f, p);
@@ -194,6 +198,8 @@ __global__ __launch_bounds__(256) void conv_group_direct_kernel(ConvArgs a)
         const T *w = static_cast<const T *>(a.w);
         int32_t acc_i = 0;
         float acc_f = 0.0f;
+        int32_t wz = 0;  // the kernel's zero point of this output channel (see conv_direct_kernel)
+        if constexpr (sizeof(T) == 1) wz = a.acc_init[ocg];
         for (int ky = 0; ky < a.Kh; ++ky) {
             const int y = y0 + ky * a.dh;
             if (y < 0 || y >= a.H) continue;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_group_direct_kernel(ConvArgs a)
                     const int64_t wi = kNHWC ? (((int64_t)ocg * a.Kh + ky) * a.Kw + kx) * cpg + ic
                                              : (((int64_t)ocg * cpg + ic) * a.Kh + ky) * a.Kw + kx;
                     if constexpr (sizeof(T) == 1) {
-                        acc_i += ((int32_t)in[ii] - a.in_zp) * (int32_t)w[wi];
+                        acc_i += ((int32_t)in[ii] - a.in_zp) * ((int32_t)w[wi] - wz);
                     } else {
                         acc_f = __fadd_rn(acc_f, __fmul_rn((float)in[ii], (float)w[wi]));
                     }

@@ -326,9 +326,25 @@ using namespace shl;
 
 extern "C" {
 
+static int plan_create_impl(const struct shl_mi355x_conv_desc *desc, const void *kernel_host, const float *mult_host,
+                            const float *bias_host, const int32_t *kernel_zp, void *stream, shl_mi355x_conv_plan **plan_out);
+
 int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const void *kernel_host,
                                 const float *mult_host, const float *bias_host, void *stream,
                                 shl_mi355x_conv_plan **plan_out)
+{
+    return plan_create_impl(desc, kernel_host, mult_host, bias_host, nullptr, stream, plan_out);
+}
+
+int shl_mi355x_conv_plan_create_wzp(const struct shl_mi355x_conv_desc *desc, const void *kernel_host,
+                                    const float *mult_host, const float *bias_host, const int32_t *kernel_zp,
+                                    void *stream, shl_mi355x_conv_plan **plan_out)
+{
+    return plan_create_impl(desc, kernel_host, mult_host, bias_host, kernel_zp, stream, plan_out);
+}
+
+static int plan_create_impl(const struct shl_mi355x_conv_desc *desc, const void *kernel_host, const float *mult_host,
+                            const float *bias_host, const int32_t *kernel_zp, void *stream, shl_mi355x_conv_plan **plan_out)
 {
     if (!desc || !plan_out) {
         set_error("conv_plan_create: NULL argument");
@@ -350,10 +366,20 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
     const bool i8_div_exact = pow2_fold_ok(d, mult_host, bias_host);
     const bool i8_div_fma = !i8_div_exact && fma_division_ok(d, mult_host, bias_host);
     const bool fast_epilogue_ok = d.dtype != SHL_MI355X_I8 || i8_div_exact || i8_div_fma;
+    // asymmetric int8 weights (a non-zero kernel zero point in any record): sum (q - zp_in) (w - zp_k[oc]) over the
+    // in-image taps, which only the one-output-per-thread kernels compute (the MFMA / depthwise kernels fold zp_in into
+    // a per-channel constant and would need a per-PIXEL sum of the receptive field on top)
+    bool w_asym = false;
+    if (kernel_zp && d.dtype == SHL_MI355X_I8)
+        for (int oc = 0; oc < d.out_c; ++oc) w_asym |= kernel_zp[oc] != 0;
     int algo = d.algo;
     if (algo == SHL_MI355X_ALGO_AUTO) {
         algo = choose_algo(d);
-        if (algo >= 0 && !fast_epilogue_ok) algo = SHL_MI355X_ALGO_DIRECT;
+        if (algo >= 0 && (!fast_epilogue_ok || w_asym)) algo = SHL_MI355X_ALGO_DIRECT;
+    }
+    if (w_asym && algo >= 0 && algo != SHL_MI355X_ALGO_DIRECT && algo != SHL_MI355X_ALGO_GROUP) {
+        set_error("conv_plan_create: asymmetric weights run on the DIRECT / GROUP kernels only");
+        return SHL_MI355X_ENOTSUP;
     }
     if (algo < 0) {
         set_error("conv_plan_create: grouped convolution (group=%d) is not supported", d.group);
@@ -491,9 +517,9 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
                 p->kernel_name = "dwconv_mfma_i8";
         }
     } else if (algo == SHL_MI355X_ALGO_GROUP) {
-        p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_group_direct_i8" : "conv_group_direct_f16";
+        p->kernel_name = d.dtype == SHL_MI355X_I8 ? (w_asym ? "conv_group_direct_i8_wzp" : "conv_group_direct_i8") : "conv_group_direct_f16";
     } else {
-        p->kernel_name = d.dtype == SHL_MI355X_I8 ? "conv_direct_i8" : "conv_direct_f16";
+        p->kernel_name = d.dtype == SHL_MI355X_I8 ? (w_asym ? "conv_direct_i8_wzp" : "conv_direct_i8") : "conv_direct_f16";
     }
     // tables are padded to a multiple of 128 channels so that kernels may fetch whole tile rows
     const size_t tab_bytes = align_up((size_t)d.out_c, 128) * 4;
@@ -578,7 +604,7 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc, const v
                 mult[oc] *= p->inv_out_scale;
                 bias[oc] *= p->inv_out_scale;
             }
-            acc[oc] = 0;
+            acc[oc] = w_asym ? kernel_zp[oc] : 0;  // DIRECT / GROUP: the kernel's zero point per output channel
         }
         if (algo == SHL_MI355X_ALGO_STEM) {
             // padding is materialised as zp_in here too

@@ -65,7 +65,84 @@ __global__ __launch_bounds__(256) void f16_round_check_kernel(unsigned long long
     atomicAdd(&out[1], (unsigned long long)admitted);
 }
 
+// issue rate of the matrix instructions the convolution kernels are built from: four independent accumulator chains per
+// wave, WPS waves per SIMD, one workgroup of 256 x WPS threads per CU.  FORM 0: v_mfma_i32_32x32x32_i8 (gfx950's double-K
+// form, what the kernels issue), 1: v_mfma_i32_32x32x16_i8 (the gfx942-era form BASELINE.json's north_star names: half
+// the K per instruction at the same 8 passes -- kept as the named baseline), 2: v_mfma_f32_32x32x16_f16.
+template <int FORM>
+__global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, int *out)
+{
+    v4i a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, (int)blockIdx.x, 7};
+    typedef int v16i_t __attribute__((ext_vector_type(16)));
+    typedef float v16f_t __attribute__((ext_vector_type(16)));
+    typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
+    v16i_t c[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) c[i][r] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (FORM == 0) c[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c[i], 0, 0, 0);
+            if constexpr (FORM == 1) {
+                const long a8 = ((long)a[1] << 32) | (unsigned)a[0], b8 = ((long)b[1] << 32) | (unsigned)b[0];
+                c[i] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a8, b8, c[i], 0, 0, 0);
+            }
+            if constexpr (FORM == 2) {
+                v16f_t t = __builtin_bit_cast(v16f_t, c[i]);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h_t, a), __builtin_bit_cast(v8h_t, b), t, 0, 0, 0);
+                c[i] = __builtin_bit_cast(v16i_t, t);
+            }
+        }
+    }
+    int s = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += c[i][r];
+    if (s == 0x12345678) out[0] = s;
+}
+
 }  // namespace shl
+
+extern "C" int shl_mi355x_debug_mfma_rate(int32_t form, int32_t waves_per_simd, double *tops, double *ns_per_mfma)
+{
+    using namespace shl;
+    if (form < 0 || form > 2 || waves_per_simd < 1 || waves_per_simd > 2 || !tops || !ns_per_mfma) return SHL_MI355X_EINVAL;
+    int dev = 0, cus = 0;
+    SHL_HIP(hipGetDevice(&dev));
+    SHL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int *out = nullptr;
+    SHL_HIP(hipMalloc((void **)&out, 4));
+    hipEvent_t e0, e1;
+    SHL_HIP(hipEventCreate(&e0));
+    SHL_HIP(hipEventCreate(&e1));
+    const int iters = 20000;
+    const dim3 grid((unsigned)cus), block(256u * (unsigned)waves_per_simd);
+    auto launch = [&](int n) {
+        if (form == 0) hipLaunchKernelGGL(mfma_rate_kernel<0>, grid, block, 0, nullptr, n, out);
+        else if (form == 1) hipLaunchKernelGGL(mfma_rate_kernel<1>, grid, block, 0, nullptr, n, out);
+        else hipLaunchKernelGGL(mfma_rate_kernel<2>, grid, block, 0, nullptr, n, out);
+    };
+    launch(100);
+    SHL_HIP(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        SHL_HIP(hipEventRecord(e0, nullptr));
+        launch(iters);
+        SHL_HIP(hipEventRecord(e1, nullptr));
+        SHL_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SHL_HIP(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    SHL_HIP(hipGetLastError());
+    const double ops_per = form == 0 ? 65536.0 : 32768.0;  // 2 x 32 x 32 x K
+    const double n_mfma = (double)iters * 4 * waves_per_simd;  // per SIMD
+    *ns_per_mfma = best * 1e6 / n_mfma;
+    *tops = ops_per * n_mfma * 4 * cus / (best * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return SHL_MI355X_OK;
+}
 
 extern "C" int shl_mi355x_debug_f16_round_check(uint64_t *out3)
 {

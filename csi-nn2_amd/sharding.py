@@ -128,6 +128,30 @@ def shared_devices(bus_ids):
 
 
 LAST_BROADCAST = {}  # facts about the last broadcast_weights call of this process (bench.py puts them into its JSON line)
+# bench.py installs a callable here: called (from a timer thread) with a message when the RCCL section of
+# broadcast_weights -- ncclCommInitRank + the grouped ncclBroadcast, the one place a multi-GPU run can wait for a peer
+# for ever -- has not returned after RCCL_STALL_SECONDS; the handler reports and ends the process
+STALL_HANDLER = None
+RCCL_STALL_SECONDS = 240.0
+
+
+class _StallWatch:
+    def __init__(self, what):
+        import threading
+        self.t = None
+        if STALL_HANDLER is not None:
+            self.t = threading.Timer(RCCL_STALL_SECONDS, STALL_HANDLER, args=("%s did not return within %.0f s" % (what, RCCL_STALL_SECONDS),))
+            self.t.daemon = True
+
+    def __enter__(self):
+        if self.t:
+            self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t:
+            self.t.cancel()
+        return False
 
 
 def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c=True, bus_id=None):
@@ -162,29 +186,37 @@ def broadcast_weights(chain, torch, dist, hip, opt, rank, world, src=0, prefer_c
             dist.broadcast(t, src=src)
             uid = (C.c_ubyte * 128)(*t.cpu().tolist())
             comm = C.c_void_p()
-            rc = hip.shl_mi355x_comm_create(uid, rank, world, C.byref(comm))
-            good = torch.tensor([int(rc == 0)], dtype=torch.int32, device=ctl)
-            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            with _StallWatch("ncclCommInitRank (rank %d of %d)" % (rank, world)):
+                rc = hip.shl_mi355x_comm_create(uid, rank, world, C.byref(comm))
+                err = "" if rc == 0 else hip.shl_mi355x_last_error().decode()
+                good = torch.tensor([int(rc == 0)], dtype=torch.int32, device=ctl)
+                dist.all_reduce(good, op=dist.ReduceOp.MIN)
             if int(good.item()) == 1:
                 nr, me, dv = C.c_int32(), C.c_int32(), C.c_int32()
                 if hip.shl_mi355x_comm_info(comm, C.byref(nr), C.byref(me), C.byref(dv)) == 0:
                     LAST_BROADCAST.update(rccl_nranks=nr.value, rccl_rank=me.value, rccl_device=dv.value)
                 n = len(chain.entries)
                 params = (C.c_void_p * n)(*[C.cast(e["params"], C.c_void_p) for e in chain.entries])
-                rc = opt.shl_mi355x_bcast_const_blocks(comm, params, n, src, chain.sess)
+                with _StallWatch("the grouped ncclBroadcast of %d blocks (rank %d of %d)" % (n, rank, world)):
+                    rc = opt.shl_mi355x_bcast_const_blocks(comm, params, n, src, chain.sess)
                 hip.shl_mi355x_comm_destroy(comm)
                 if rc != 1:
                     raise RuntimeError("shl_mi355x_bcast_const_blocks failed: " + hip.shl_mi355x_last_error().decode())
+                LAST_BROADCAST.update(transport="RCCL ncclBroadcast")
                 return "RCCL ncclBroadcast behind the C-ABI (shl_mi355x_bcast_const_blocks), %d blocks in one group, communicator of ranks 0..%d" % (n, world - 1)
             if comm:
                 hip.shl_mi355x_comm_destroy(comm)
-            why = "ncclCommInitRank failed on some rank: " + hip.shl_mi355x_last_error().decode()
+            why = "ncclCommInitRank failed on some rank" + (" (this one: %s)" % err if err else "")
+            LAST_BROADCAST.update(rccl_error=why)
     n = broadcast_plan_blocks(chain, torch, dist, hip, src=src)
     # tables and the code path chosen for them come from the same rank: adopt the root's flags records
     cnt = len(chain.entries)
     params = (C.c_void_p * cnt)(*[C.cast(e["params"], C.c_void_p) for e in chain.entries])
     if opt.shl_mi355x_params_adopt_blocks(params, cnt, chain.sess) != 1:
         raise RuntimeError("shl_mi355x_params_adopt_blocks failed: " + hip.shl_mi355x_last_error().decode())
+    LAST_BROADCAST.update(transport="torch.distributed %s fallback" % dist.get_backend())
+    if prefer_c and "rccl_error" not in LAST_BROADCAST:
+        LAST_BROADCAST.update(rccl_error=why)
     return "torch.distributed broadcast, %d buckets (%s)" % (n, why)
 
 

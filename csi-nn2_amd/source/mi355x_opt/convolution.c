@@ -49,7 +49,7 @@ static int scale_is_one(float s) { return fabsf(s - 1.0f) <= 1.1920929e-07f; }
  * Returns CSINN_TRUE or a negative status. */
 static int build_tables(const struct shl_mi355x_conv_desc *d, struct csinn_tensor *input,
                         struct csinn_tensor *kernel, struct csinn_tensor *bias, int fuse_zp2bias,
-                        int dw_weights_last, float *mult, float *bias_f)
+                        int dw_weights_last, float *mult, float *bias_f, int32_t *kzp)
 {
     const int co = d->out_c;
     const int has_bias = bias != NULL && bias->dim_count != 0 && bias->data != NULL;
@@ -61,13 +61,9 @@ static int build_tables(const struct shl_mi355x_conv_desc *d, struct csinn_tenso
                             kernel->quant_channel, co);
             return CSINN_FALSE;
         }
-        for (int q = 0; q < kernel->quant_channel; q++) {
-            if (kernel->qinfo[q].zero_point != 0) {
-                shl_debug_error("mi355x: asymmetric weights (zero point %d) are not supported\n",
-                                kernel->qinfo[q].zero_point);
-                return CSINN_UNSUPPORT_DTYPE;
-            }
-        }
+        /* asymmetric weights: int8_to_float_base subtracts the record's zero point from weights as from activations
+         * (source/nn2/utils.c:499-502, :920-945); the plan then runs on the direct kernels (shl_mi355x_conv_plan_create_wzp) */
+        for (int oc = 0; oc < co; oc++) kzp[oc] = kernel->qinfo[kernel->quant_channel > 1 ? oc : 0].zero_point;
         const float s_in = input->qinfo->scale;
         for (int oc = 0; oc < co; oc++)
             mult[oc] = s_in * kernel->qinfo[kernel->quant_channel > 1 ? oc : 0].scale;
@@ -94,7 +90,7 @@ static int build_tables(const struct shl_mi355x_conv_desc *d, struct csinn_tenso
                     float t = dw ? bias_f[oc] : 0.0f;
                     for (int64_t j = 0; j < inner; j++) {
                         const int8_t wq = dw_weights_last ? w[j * co + oc] : w[oc * inner + j];
-                        t = t + ((float)wq * sk) * sp;
+                        t = t + (((float)wq - kzp[oc]) * sk) * sp; /* the DEQUANTISED kernel value, as the reference folds it */
                     }
                     bias_f[oc] = dw ? t : bias_f[oc] + t;
                 }
@@ -112,6 +108,7 @@ static int build_tables(const struct shl_mi355x_conv_desc *d, struct csinn_tenso
         for (int oc = 0; oc < co; oc++) {
             mult[oc] = 1.0f;
             bias_f[oc] = 0.0f;
+            kzp[oc] = 0;
         }
         if (has_bias) {
             if (bias->dtype != CSINN_DTYPE_FLOAT16) {
@@ -156,10 +153,11 @@ static int create_plan(struct csinn_session *sess, struct shl_mi355x_conv_desc *
     float *bias_f = shl_mem_alloc((int64_t)d->out_c * sizeof(float));
     /* depthwise 1HWO weights; a grouped convolution (ALGO_GROUP) keeps OHWI rows and the conv2d form of the fold */
     const int dw_last = d->group > 1 && d->algo != SHL_MI355X_ALGO_GROUP && d->layout == SHL_MI355X_NHWC;
-    int rc = build_tables(d, input, kernel, bias, fuse_zp2bias, dw_last, mult, bias_f);
+    int32_t *kzp = shl_mem_alloc((int64_t)d->out_c * sizeof(int32_t));
+    int rc = build_tables(d, input, kernel, bias, fuse_zp2bias, dw_last, mult, bias_f, kzp);
     if (rc == CSINN_TRUE) {
-        int st = shl_mi355x_conv_plan_create(d, kernel->data, mult, bias_f,
-                                             shl_mi355x_ctx_stream(shl_mi355x_ctx_of(sess)), plan_out);
+        int st = shl_mi355x_conv_plan_create_wzp(d, kernel->data, mult, bias_f, kzp,
+                                                 shl_mi355x_ctx_stream(shl_mi355x_ctx_of(sess)), plan_out);
         if (st != SHL_MI355X_OK) {
             shl_debug_error("mi355x: plan creation failed (%d): %s\n", st, shl_mi355x_last_error());
             rc = st == SHL_MI355X_ENOTSUP ? CSINN_UNSUPPORT_LAYOUT : CSINN_FALSE;
@@ -167,6 +165,7 @@ static int create_plan(struct csinn_session *sess, struct shl_mi355x_conv_desc *
     }
     shl_mem_free(mult);
     shl_mem_free(bias_f);
+    shl_mem_free(kzp);
     return rc;
 }
 
@@ -410,12 +409,9 @@ static int conv2d_channel_init_act(CSINN_CONV_ARGS, int act)
     }
     if (kernel->data == NULL || kernel->mtype == CSINN_MEM_TYPE_DMABUF) return CSINN_FALSE;
     const int co = d.out_c;
-    for (int oc = 0; oc < co; oc++)
-        if (kernel->qinfo[oc].zero_point != 0) {
-            shl_debug_error("mi355x: conv2d_channel: asymmetric weights (zero point %d) are not supported\n",
-                            kernel->qinfo[oc].zero_point);
-            return CSINN_UNSUPPORT_DTYPE;
-        }
+    /* channel_kernel_to_common (convolution_channel.c:31-56): ((float)w - zero_point[oc]) * scale[oc] */
+    int32_t *kzp = shl_mem_alloc((int64_t)co * sizeof(int32_t));
+    for (int oc = 0; oc < co; oc++) kzp[oc] = kernel->qinfo[oc].zero_point;
     float *mult = shl_mem_alloc((int64_t)co * sizeof(float));
     float *bias_f = shl_mem_alloc((int64_t)co * sizeof(float));
     const int has_bias = bias != NULL && bias->dim_count != 0 && bias->data != NULL;
@@ -429,10 +425,11 @@ static int conv2d_channel_init_act(CSINN_CONV_ARGS, int act)
         }
     }
     shl_mi355x_conv_plan *plan = NULL;
-    int st = shl_mi355x_conv_plan_create(&d, kernel->data, mult, bias_f,
-                                         shl_mi355x_ctx_stream(shl_mi355x_ctx_of(params->base.sess)), &plan);
+    int st = shl_mi355x_conv_plan_create_wzp(&d, kernel->data, mult, bias_f, kzp,
+                                             shl_mi355x_ctx_stream(shl_mi355x_ctx_of(params->base.sess)), &plan);
     shl_mem_free(mult);
     shl_mem_free(bias_f);
+    shl_mem_free(kzp);
     if (st != SHL_MI355X_OK) {
         shl_debug_error("mi355x: conv2d_channel plan creation failed (%d): %s\n", st, shl_mi355x_last_error());
         return CSINN_FALSE;

@@ -169,6 +169,15 @@ int shl_mi355x_conv_plan_create(const struct shl_mi355x_conv_desc *desc,
                                 const void *kernel_host, const float *mult_host,
                                 const float *bias_host, void *stream,
                                 shl_mi355x_conv_plan **plan_out);
+/* The same with ASYMMETRIC int8 weights: kernel_zp[oc] = zero point of output channel oc's kernel record (out_c
+ * entries; a per-tensor record repeated).  The reference dequantises weights as ((float)w - zero_point) * scale
+ * (int8_to_float_base, source/nn2/utils.c:499-502, through nchw/nhwc_int8_to_float :920-945), so shl_ref_conv2d_quant
+ * (source/reference/convolution.c:370-400) accepts CSINN_QUANT_INT8_ASYM kernels.  With any non-zero entry the plan runs
+ * on the one-output-per-thread kernels (ALGO_DIRECT / ALGO_GROUP: sum (q - zp_in)(w - zp_k) over in-image taps); with
+ * all zeros (or NULL) it is shl_mi355x_conv_plan_create. */
+int shl_mi355x_conv_plan_create_wzp(const struct shl_mi355x_conv_desc *desc, const void *kernel_host,
+                                    const float *mult_host, const float *bias_host, const int32_t *kernel_zp,
+                                    void *stream, shl_mi355x_conv_plan **plan_out);
 /* ---- multi-GPU: the one collective of the path ---------------------------------
  * The batch shards over the GPUs of a node with no collective on the data path; the only exchange is the
  * one-time broadcast of the plans' constant blocks from the rank that packed the weights.  RCCL
@@ -204,6 +213,11 @@ int shl_mi355x_debug_div_check(const float *divisors_host, int32_t n, uint64_t *
  * pushed through both the one-value and the packed two-value shortcut (csrc/common.h) and compared with the literal
  * restatement.  out3[0] = mismatches, out3[1] = patterns the packed shortcut admits, out3[2] = one offending pattern. */
 int shl_mi355x_debug_f16_round_check(uint64_t *out3);
+/* Measured issue rate of a matrix instruction on every CU (four accumulator chains per wave, 1 or 2 waves per SIMD):
+ * form 0 = v_mfma_i32_32x32x32_i8 (what the int8 kernels issue), 1 = v_mfma_i32_32x32x16_i8 (the form BASELINE.json's
+ * north_star names; half the K at the same pass count), 2 = v_mfma_f32_32x32x16_f16.  *tops = TOP/s (TFLOP/s) of the
+ * whole device, *ns_per_mfma = nanoseconds per instruction and SIMD.  bench.py prints both int8 forms. */
+int shl_mi355x_debug_mfma_rate(int32_t form, int32_t waves_per_simd, double *tops, double *ns_per_mfma);
 
 /*
  * Plan for CSINN_OP_DEPTHWISE_CONV2D_CHANNEL{,_RELU,_RELU6} (int8, NCHW, kernel O1HW): the reference's one

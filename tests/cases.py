@@ -31,7 +31,7 @@ def out_size(i, k, s, p0, p1, d):
 
 def make_case(seed, layout=NHWC, dtype="int8", n=1, h=8, w=8, c=16, co=16, k=(3, 3), stride=(1, 1),
               pad=(1, 1, 1, 1), dilation=(1, 1), depthwise=False, multiplier=1, act=0,
-              per_channel=False, fuse_zp2bias=False, has_bias=True, exact=True, fc=False, groups=1):
+              per_channel=False, fuse_zp2bias=False, has_bias=True, exact=True, fc=False, groups=1, kernel_zp=False):
     """Returns a dict describing one problem with numpy operands."""
     rng = np.random.default_rng(seed)
     kh, kw = k
@@ -71,7 +71,10 @@ def make_case(seed, layout=NHWC, dtype="int8", n=1, h=8, w=8, c=16, co=16, k=(3,
         else:
             case["in_scale"] = float(np.float32(0.0431 + 0.01 * rng.random()))
             case["k_scale"] = (0.0071 + 0.004 * rng.random(kq)).astype(np.float32)
-        case["k_zp"] = np.zeros(kq, dtype=np.int32)
+        # kernel_zp: asymmetric weights (CSINN_QUANT_INT8_ASYM kernels: the reference dequantises ((float)w - zp_k) * s_k)
+        case["k_zp"] = rng.integers(-6, 7, kq).astype(np.int32) if kernel_zp else np.zeros(kq, dtype=np.int32)
+        if kernel_zp and not case["k_zp"].any():
+            case["k_zp"][0] = 3
         # bias scale = s_in * s_k (per channel when the kernel is)
         case["b_scale"] = (np.float32(case["in_scale"]) * case["k_scale"]).astype(np.float32)
         # output scale: ~3 sigma of the accumulator maps to 127
@@ -83,6 +86,8 @@ def make_case(seed, layout=NHWC, dtype="int8", n=1, h=8, w=8, c=16, co=16, k=(3,
         if fuse_zp2bias:
             # the caller-side fold of tests/utils/test_utils.c:684-720: b' = b - zp_in * sum(w)
             wsum = _wsum_per_oc(case)
+            if kernel_zp:  # the fold is over the dequantised kernel: sum (w - zp_k)
+                wsum = wsum - case["k_zp"].astype(np.int64) * (kh * kw * cpg)
             case["bias"] = (case["bias"].astype(np.int64) - case["in_zp"] * wsum).astype(np.int32)
     else:
         case["input"] = rng.standard_normal(in_shape).astype(np.float16)

@@ -57,6 +57,13 @@ GOLDEN_CASES = [
     ("f16_dw_relu_nhwc", dict(dtype="f16", depthwise=True, act=1)),
     ("f16_dw_nchw", dict(dtype="f16", depthwise=True, layout=NCHW)),
     ("f16_fc", dict(dtype="f16", fc=True, n=2, c=64, co=10)),
+    # asymmetric int8 weights (kernel records with a zero point: CSINN_QUANT_INT8_ASYM kernels, source/nn2/utils.c:499-502)
+    ("asym_w_conv3x3_nhwc", dict(kernel_zp=True, c=32, co=24, h=9, w=7)),
+    ("asym_w_conv3x3_nchw_per_channel", dict(kernel_zp=True, per_channel=True, layout=NCHW, n=2, c=16, co=20, act=1)),
+    ("asym_w_dw3x3_nhwc", dict(kernel_zp=True, depthwise=True, c=32, stride=(2, 2), h=9, w=9)),
+    ("asym_w_dw3x3_nchw_per_channel", dict(kernel_zp=True, per_channel=True, depthwise=True, c=24, layout=NCHW)),
+    ("asym_w_conv_fuse_zp2bias", dict(kernel_zp=True, fuse_zp2bias=True)),
+    ("asym_w_fc_b2_64_10", dict(kernel_zp=True, fc=True, n=2, c=64, co=10)),
 ]
 
 ARRAY_KEYS = ("input", "kernel", "bias", "k_scale", "k_zp", "b_scale")

@@ -294,6 +294,7 @@ class MiniNet:
         # the reference's gref setup handler returns void: only this repo's front-end reports a status
         assert rc == pkg.CSINN_TRUE or getattr(fe, "kind", "") == "reference"
         self._keep, self._sess, self._out_shape, self._in_q = keep, sess, cur_shape, self.q_in
+        self._conv_params = [args[-1] for (_, _, args), (kind, _, _) in zip(ops, self.layers) if kind == "conv"]
         return sess
 
     def run(self, fe, x):

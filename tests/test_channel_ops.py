@@ -95,7 +95,7 @@ def gpu():
     return fe, hip, opt, cases.HipDevice(hip)
 
 
-DEVICE_NAMES = [n for n in NAMES if n != "conv_kernel_zp"]   # asymmetric weights on the float path are refused (below)
+DEVICE_NAMES = list(NAMES)   # (incl. "conv_kernel_zp": asymmetric weights run on the direct kernel since round 6)
 
 
 @pytest.mark.gpu
@@ -195,9 +195,6 @@ def test_channel_exec_plans_once_per_layer_however_many_layers(gpu):
 @pytest.mark.gpu
 def test_unsupported_channel_requests_are_refused(gpu):
     fe, hip, opt, dev = gpu
-    case, _ = golden("conv_kernel_zp")           # asymmetric weights on the float path
-    with pytest.raises(pkg.MI355XError):
-        cases.csinn_channel_run(fe, pkg.API_MI355X, case)
     nhwc = cases.make_channel_case(1, "conv")
     nhwc["layout"] = "NHWC"                      # the reference supports NCHW only; so does the backend
     keep = pkg.Keep()

@@ -424,10 +424,28 @@ def test_exec_without_init_fails_loudly(gpu):
     assert fe.csinn_conv2d(t, o, w, b, params) != pkg.CSINN_TRUE
 
 
+def test_asymmetric_weights_run_on_the_direct_kernel(gpu):
+    """kernel records with a zero point (VERDICT r05 missing #3): accepted, computed as sum (q - zp_in)(w - zp_k[oc]) by the
+    one-output-per-thread kernel, bit-identical to the oracle; an MFMA-sized layer included (it must not take the MFMA path)"""
+    fe, hip, opt, dev = gpu
+    for seed, kw in ((31, dict(c=64, co=64, h=14, w=14, kernel_zp=True)),
+                     (32, dict(c=64, co=64, h=14, w=14, kernel_zp=True, per_channel=True, layout=cases.NCHW, n=2)),
+                     (33, dict(c=32, depthwise=True, kernel_zp=True, act=2)),
+                     (34, dict(c=32, co=48, k=(1, 1), pad=(0, 0, 0, 0), kernel_zp=True, exact=False))):
+        case = cases.make_case(seed, **kw)
+        kept = []
+        got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+        name = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
+        assert name == "conv_direct_i8_wzp", name
+        golden_util.compare(case, got, cases.oracle_run(case, "ref"), "asymmetric weights %r" % (kw,))
+        opt.shl_mi355x_release_params(kept[0][0])
+
+
 def test_unsupported_requests_are_refused(gpu):
     fe, hip, opt, dev = gpu
     case = cases.make_case(5, c=32, co=32)
-    case["k_zp"] = np.array([3], dtype=np.int32)       # asymmetric weights
+    case["k_scale"] = np.array([2.0 ** -7, 2.0 ** -8], dtype=np.float32)   # two kernel records for 32 output channels
+    case["k_zp"] = np.zeros(2, dtype=np.int32)
     with pytest.raises(pkg.MI355XError):
         cases.csinn_run(fe, pkg.API_MI355X, case)
     before = opt.shl_mi355x_live_plans(None)
@@ -457,12 +475,18 @@ for i, kw in enumerate([dict(c=64, co=64, h=28, w=28), dict(layout="NCHW", c=16,
                         dict(c=32, co=48, stride=(2, 2), per_channel=True, act=2)]):
     case = cases.make_case(300 + i, **kw)
     want = cases.csinn_run(fe, pkg.API_REF, case)             # reference C backend, same library
-    got = cases.csinn_run(fe, pkg.API_MI355X, case)           # same front-end, MI355X backend
-    got_dev = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev)
+    kept = []
+    got = cases.csinn_run(fe, pkg.API_MI355X, case, keep_params=kept)           # same front-end, MI355X backend
+    got_dev = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+    # both legs must have run a HIP kernel of the backend: with the weak shl_cb_map_ref fall-through an op that was never
+    # registered would compare the reference with itself on the host-tensor leg (VERDICT r05 weak #1 iii)
+    names = [opt.shl_mi355x_params_kernel_name(k[0]) for k in kept]
+    names = [n.decode() if n else "" for n in names]
+    ok = all(n and any(t in n for t in ("igemm", "dwconv", "gemv", "conv1x1", "conv_direct", "nchw", "stem")) for n in names)
     n1, _ = cases.mismatch_report(got, want)
     n2, _ = cases.mismatch_report(got_dev, want)
-    print("case", i, "mismatches", n1, n2)
-    bad += n1 + n2
+    print("case", i, "mismatches", n1, n2, "kernels", names)
+    bad += n1 + n2 + (0 if ok else 1)
 print("DROPIN_OK" if bad == 0 else "DROPIN_FAIL")
 """
 

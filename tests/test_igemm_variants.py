@@ -146,6 +146,58 @@ def _one_image(case, i):
                 out_shape=(1,) + tuple(case["out_shape"][1:]))
 
 
+DISTINCT = 4   # distinct images a batch of 128 is drawn from (the oracle replays each once)
+
+
+def _patterned_batch(case, batch, seed):
+    """Every one of the `batch` images is one of DISTINCT base images, in a seeded irregular order (the first DISTINCT slots
+    hold each base image once; no two neighbours are equal): the oracle's four single-image outputs then check ALL 128
+    images bit for bit -- a tile that straddles images 17 / 18, a halo row fetched from the neighbouring image or a pair
+    offset that lands a whole number of images off all show up, which "sampled images + not constant" did not (VERDICT r05
+    weak #1 i)."""
+    rng = np.random.default_rng(seed)
+    pattern = np.concatenate([np.arange(DISTINCT), rng.integers(0, DISTINCT, batch - DISTINCT)])
+    for i in range(1, batch):
+        if pattern[i] == pattern[i - 1]:
+            pattern[i] = (pattern[i] + 1 + int(rng.integers(0, DISTINCT - 1))) % DISTINCT
+    base = case["input"][:DISTINCT]
+    big = dict(case, n=batch, input=np.ascontiguousarray(base[pattern]), in_shape=(batch,) + tuple(case["in_shape"][1:]),
+               out_shape=(batch,) + tuple(case["out_shape"][1:]))
+    return big, pattern
+
+
+def _check_full_size(gpu, idx, layout, exact, expect_name=None):
+    fe, hip, opt, dev = gpu
+    batch = 128
+    small = cases.make_case(9100 + idx, n=DISTINCT, layout=layout, act=1, exact=exact, per_channel=not exact, **RESNET_3X3[idx])
+    case, pattern = _patterned_batch(small, batch, 77 + idx)
+    kept = []
+    got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
+    kname = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
+    assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
+    assert "igemm" in kname and any(k in kname for k in BLOCK_TILE_KERNELS), \
+        "batch-128 ResNet-50 3x3 must run on a block-tile MFMA kernel, the plan chose " + kname
+    # (1) the oracle, bit for bit, on ALL 128 images (each is one of DISTINCT base images)
+    want = [cases.oracle_run(_one_image(small, b), "exact") for b in range(DISTINCT)]
+    wrong = [i for i in range(batch) if not np.array_equal(got[i:i + 1], want[pattern[i]])]
+    if wrong:
+        i = wrong[0]
+        n, worst = cases.mismatch_report(got[i:i + 1], want[pattern[i]])
+        raise AssertionError("%s via %s: images %s differ from the oracle (image %d: %d mismatches, max %d)" % (
+            layout, kname, wrong[:12], i, n, worst))
+    if not exact:
+        # converter scales: also the reference's own float formulation (R) under SURVEY 8(c)'s general-scale gate
+        # (|delta| <= 1 LSB on at most 2e-4 of the outputs) next to the equality with formulation X
+        for b in (0, DISTINCT - 1):
+            golden_util.compare(_one_image(small, b), got[b:b + 1], cases.oracle_run(_one_image(small, b), "ref"),
+                                "%s image %d via %s vs formulation R" % (layout, b, kname))
+    # (2) two images against their own single-image run through the product (a different kernel at M/128)
+    for i in (1, 100):
+        single = cases.csinn_run(fe, pkg.API_MI355X, _one_image(case, i), device=dev)
+        assert np.array_equal(single, got[i:i + 1]), "%s image %d differs from its single-image run" % (layout, i)
+    return kname
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout,exact", [(NHWC, True), (NCHW, True), (NHWC, False), (NCHW, False)],
                          ids=["NHWC", "NCHW", "NHWC-converter-scales", "NCHW-converter-scales"])
@@ -153,32 +205,30 @@ def _one_image(case, i):
 def test_resnet50_3x3_batch128_full_size(gpu, idx, layout, exact):
     """exact=False: arbitrary (converter) scales, per channel -- the epilogue then divides by the output scale with
     div_by_scale (tests/test_div_by_scale.py) inside the block-tile kernels at their full size."""
+    _check_full_size(gpu, idx, layout, exact)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [NHWC, NCHW], ids=["NHWC", "NCHW"])
+@pytest.mark.parametrize("idx", range(len(RESNET_3X3)), ids=["%d_%d_at%d" % (s["c"], s["co"], s["h"]) for s in RESNET_3X3])
+def test_resnet50_3x3_batch128_full_size_as_bench_runs_it(gpu, idx, layout, monkeypatch, capsys):
+    """The same full-size check with SHL_MI355X_TUNE unset -- the shipped default, what bench.py times: the plan MEASURES
+    its kernel family (conv_plan.hip:tune_plan), and whatever it picked at configs[2]'s own size is held against the oracle
+    on all 128 images (the rest of the suite pins the selection rules: tests/conftest.py; VERDICT r05 weak #1 ii).  A second
+    plan of the shape -- what bench.py's LayerChain creates -- takes the cached pick: same kernel name."""
+    monkeypatch.delenv("SHL_MI355X_TUNE", raising=False)
+    first = _check_full_size(gpu, idx, layout, True)
     fe, hip, opt, dev = gpu
-    batch = 128
-    case = cases.make_case(9100 + idx, n=batch, layout=layout, act=1, exact=exact, per_channel=not exact, **RESNET_3X3[idx])
-    kept = []
-    got = cases.csinn_run(fe, pkg.API_MI355X, case, device=dev, keep_params=kept)
-    kname = opt.shl_mi355x_params_kernel_name(kept[0][0]).decode()
-    assert opt.shl_mi355x_release_params(kept[0][0]) == pkg.CSINN_TRUE
-    assert "igemm" in kname and any(k in kname for k in BLOCK_TILE_KERNELS), \
-        "batch-128 ResNet-50 3x3 must run on a block-tile MFMA kernel, the plan chose " + kname
-    # (1) oracle, bit for bit, on sampled images (first, last, two inside: tiles straddle image boundaries)
-    for i in (0, 41, 86, batch - 1):
-        want = cases.oracle_run(_one_image(case, i), "exact")
-        n, worst = cases.mismatch_report(got[i:i + 1], want)
-        assert n == 0, "%s image %d via %s: %d mismatches vs the oracle (max %d)" % (layout, i, kname, n, worst)
-        if not exact and i in (0, batch - 1):
-            # converter scales: also the reference's own float formulation (R) under SURVEY 8(c)'s general-scale gate
-            # (|delta| <= 1 LSB on at most 2e-4 of the outputs) next to the equality with formulation X
-            golden_util.compare(_one_image(case, i), got[i:i + 1], cases.oracle_run(_one_image(case, i), "ref"),
-                                "%s image %d via %s vs formulation R" % (layout, i, kname))
-    # (2) more images against their own single-image run through the product (a different kernel at M/128)
-    for i in (1, 63, 64, 100, 126):
-        single = cases.csinn_run(fe, pkg.API_MI355X, _one_image(case, i), device=dev)
-        assert np.array_equal(single, got[i:i + 1]), "%s image %d differs from its single-image run" % (layout, i)
-    # (3) every image was written: a batch output is never constant over an image (random inputs)
-    flat = got.reshape(batch, -1)
-    assert np.all(flat.max(axis=1) != flat.min(axis=1))
+    case = cases.make_case(9100 + idx, n=128, layout=layout, act=1, **RESNET_3X3[idx])
+    import importlib
+    wl = importlib.import_module("csi-nn2_amd.workloads")
+    L = wl._conv(case["c"], case["co"], case["h"], 3, case["stride"][0])
+    chain = wl.LayerChain(fe, hip, opt, [L], 128, dev.alloc, dev.upload, dtype="int8", layout=layout, seed=4321, chained=False, fuse=False)
+    again = chain.unit_kernel_name(0)
+    chain.release()
+    with capsys.disabled():
+        print("\n  tuned pick for %s %s at batch 128: %s" % (RESNET_3X3[idx], layout, first))
+    assert again == first, "bench.py's plan of the same shape runs %s, the checked one %s" % (again, first)
 
 
 @pytest.mark.gpu

@@ -261,7 +261,51 @@ def test_bench_gpus_2_spawns_two_ranks_without_a_launcher():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     line = json.loads(lines[-1])
+    assert len(lines[-1]) <= 1900, len(lines[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    assert "replicas x2" in line["config"]["parallelism"] and "broadcast" in line["config"]["parallelism"]
-    assert len(line["config"]["device_bus_ids"]) == 2 and line["config"]["process_group"].startswith("gloo")
-    assert line["value"] > 0
+    assert "replicas x2" in line["config"]["parallelism"]
+    assert line["value"] > 0 and "rccl_error" not in line
+    full = json.loads([l for l in res.stderr.splitlines() if l.startswith("BENCH_FULL ")][-1][len("BENCH_FULL "):])
+    assert "broadcast" in full["config"]["parallelism"]
+    assert len(full["config"]["device_bus_ids"]) == 2 and full["config"]["process_group"].startswith("gloo")
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device_flags_the_line_and_fails():
+    """`--gpus 2` on a box with ONE device (no test hook): RCCL cannot form a communicator of two, the
+    run finishes on the fallback transport, the JSON line is still printed -- with `rccl_error` and the transport named --
+    and the exit code is non-zero."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SHL_BENCH_SINGLE_DEVICE")}
+    res = subprocess.run([sys.executable, os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--windows", "2",
+                          "--no-cpu-baseline", "--no-configs"], capture_output=True, text=True, timeout=900, env=env, cwd=cases.ROOT)
+    assert res.returncode != 0, res.stdout[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert lines, res.stderr[-3000:]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "share device" in line["rccl_error"] and line["config"]["distinct_devices"] == 1
+    assert "fallback" in line["config"]["transport"]
+
+
+def test_bench_stdout_line_is_compact_and_carries_every_config():
+    """the driver stores the last 2 000 characters of stdout -- the ONE line must fit and must hold
+    configs[2]'s ms_per_pass and roofline fraction.  Fed with the full record of round 5 (profiles/r05_e_bench_line.json)."""
+    import json
+    sys.path.insert(0, cases.ROOT)
+    import bench
+    with open(os.path.join(cases.ROOT, "profiles", "r05_e_bench_line.json")) as f:
+        full = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1])
+    full["mfma_rate"] = {"i32_32x32x32_i8_TOPs": 4312.123456, "i32_32x32x16_i8_TOPs": 2156.061728, "f32_32x32x16_f16_TFLOPs": 2156.5}
+    line = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(line) <= 1900, len(line)
+    got = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(got["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(got["cpu_baseline"])
+    tags = [c["baseline_config"] for c in got["configs"]]
+    assert tags[0] == "configs[2]" and "configs[3]" in tags and len(tags) == len(full["configs"]) - 1
+    c2 = got["configs"][0]
+    assert c2["ms_per_pass"] > 0 and 0 < c2["roofline"]["frac"] < 1 and c2["roofline"]["kernel"]

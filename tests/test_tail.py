@@ -241,6 +241,11 @@ for dtype, layout in (("int8", "NHWC"), ("f16", "NCHW")):
     ref = tail.MiniNet(dtype, layout); ref.build(fe, pkg.API_REF)
     net = tail.MiniNet(dtype, layout); sess = net.build(fe, pkg.API_MI355X)
     mode = opt.shl_mi355x_session_is_device_resident(sess)
+    # every convolution of the graph carries a plan of THIS backend (a HIP kernel's name), not a fall-through callback
+    names = [opt.shl_mi355x_params_kernel_name(p) for p in net._conv_params]
+    names = [n.decode() if n else "" for n in names]
+    print(dtype, layout, "kernels", names)
+    bad += int(not names or not all(n for n in names))
     for k in range(2):
         x = net.input(k)
         want, got = ref.run(fe, x), net.run(fe, x)

@@ -133,6 +133,7 @@ def test_mobilenetv1_fp16_nchw_chain_with_fused_pairs(gpu):
     pairs = [u for u in chain.units if len(u) == 2]
     assert len(pairs) == 13 and len(chain.units) == 15, chain.units
     feeds = chain_inputs(chain)
+    beyond_strict, pairs_beyond = 0, 0   # outputs of fused pairs beyond north_star's STRICT 1e-3 (of the value itself)
     for u in chain.units:
         first = u[0]
         x = feeds[first] if first in feeds else outs[first - 1]
@@ -174,6 +175,46 @@ def test_mobilenetv1_fp16_nchw_chain_with_fused_pairs(gpu):
         bad = np.abs(g - w) > 1e-3 * np.abs(w) + 1e-3 * cond + 1e-6
         assert not bad.any(), "%s: %d of %d values beyond 1e-3 (|out| + sum |mid||w|), worst excess %.3e" % (
             what, int(bad.sum()), g.size, float((np.abs(g - w) - 1e-3 * np.abs(w) - 1e-3 * cond).max()))
+        beyond_strict += int((strict & big).sum())
+        pairs_beyond += int((strict & big).any())
+    # the bar that is green above is the condition-aware one; how far the network is from the STRICT bar is counted over
+    # all 13 pairs and gated at what round 5 measured (5 values in 3 pairs, each a cancellation residue): the count may
+    # shrink, it may not grow unnoticed (VERDICT r05 weak #1 iv)
+    print("fused binary16 pairs: %d outputs in %d of 13 pairs beyond the strict 1e-3" % (beyond_strict, pairs_beyond))
+    assert beyond_strict <= 5 and pairs_beyond <= 3, (beyond_strict, pairs_beyond)
+    chain.release()
+
+
+@pytest.mark.gpu
+def test_mobilenetv1_int8_batch128_chain_equals_the_oracle_chain(gpu):
+    """The pass bench.py's throughput view times: MobileNetV1 int8 NHWC at batch 128 as csinn_session_setup launches it
+    (depthwise -> pointwise blocks of 32 .. 256 channels in one launch each: dwpw_stream; resident-weights pointwise and
+    MFMA depthwise kernels for the rest: 23 launches), against the oracle CHAIN on images 0, 63 and 127 -- every launch's
+    output, bit for bit (VERDICT r05 weak #1 v: the session was checked at batch 8, one block at 128)."""
+    fe, hip, opt, dev = gpu
+    batch, imgs = 128, (0, 63, 127)
+    chain = wl.LayerChain(fe, hip, opt, wl.MOBILENETV1, batch, dev.alloc, dev.upload, dtype="int8", layout="NHWC", seed=SEED,
+                          chained=True, fuse=True)
+    assert len(chain.units) < 28
+    names = [chain.unit_kernel_name(u) for u in range(len(chain.units))]
+    assert any("dwpw_stream" in n for n in names), names
+    opt.shl_mi355x_set_stream(None)
+    chain.run_eager()
+    ends = {u[-1]: k for k, u in enumerate(chain.units)}
+    feeds = chain_inputs(chain)
+    cur = None
+    checked = 0
+    for i, e in enumerate(chain.entries):
+        x = feeds[i][list(imgs)] if i in feeds else cur
+        case = layer_case(e["layer"], dict(e["ops"], in_scale=e["in_scale"], in_zp=e["in_zp"]), "int8", "NHWC", x)
+        cur = cases.oracle_run(case, "ref")
+        if i in ends:
+            got = dev.download(e["d_out"], e["out_dims"], np.int8)[list(imgs)]
+            n, worst = cases.mismatch_report(got, cur)
+            assert n == 0, "layer %d (%s via %s): %d mismatches vs the oracle chain on images %s (max %d)" % (
+                i, wl.layer_name(e["layer"]), names[ends[i]], n, imgs, worst)
+            checked += 1
+    assert checked == len(chain.units)
     chain.release()
 
 
