@@ -409,7 +409,7 @@ def compact_line(result):
     out["config"]["workload"] = out["config"].pop("workload_short", str(cfg.get("workload"))[:96])
     out["config"]["parallelism"] = out["config"].pop("parallelism_short", cfg.get("parallelism"))
     if result.get("rccl_error"):
-        out["rccl_error"] = str(result["rccl_error"])[:160]
+        out["rccl_error"] = str(result["rccl_error"])[:200]
     roof = result.get("roofline")
     if roof:
         out["roofline"] = {k: _r(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")}
@@ -489,7 +489,10 @@ def spawn_ranks(n):
     inherits stdout (its JSON line stays the last line written); the other ranks' stdout goes to stderr.  Any rank
     failing fails the run: its siblings are terminated by PID and the exit code is the first non-zero one."""
     import socket
+    # (the port is free when it is picked, not reserved: should another process take it before rank 0 binds it, the children's
+    # rendezvous fails, every rank exits non-zero and so does this process -- loudly; SO_REUSEADDR keeps TIME_WAIT out of the way)
     with socket.socket() as s:
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
@@ -499,6 +502,7 @@ def spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
+    t_kill = 0.0
     pending = set(range(n))
     while pending:
         for r in sorted(pending):
@@ -511,6 +515,10 @@ def spawn_ranks(n):
                 sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
                 for q in pending:
                     procs[q].terminate()
+                t_kill = time.time() + 20.0  # a rank stuck inside a HIP / RCCL call ignores SIGTERM: SIGKILL after a grace period
+        if rc != 0 and pending and time.time() > t_kill:
+            for q in pending:
+                procs[q].kill()
         time.sleep(0.05)
     sys.exit(rc)
 
@@ -621,8 +629,8 @@ def main():
         # WITH `rccl_error` and the transport named -- a flagged number beats an empty record -- and exits non-zero.
         got_dev, got_nr = par.LAST_BROADCAST.get("distinct_devices"), par.LAST_BROADCAST.get("rccl_nranks")
         if got_dev != world or got_nr != world:
-            rccl_error = "--gpus %d: %s distinct devices, RCCL communicator of %s ranks; %s" % (
-                world, got_dev, got_nr, par.LAST_BROADCAST.get("rccl_error") or bcast)
+            rccl_error = "%s [--gpus %d: %s distinct devices, RCCL communicator of %s ranks]" % (
+                par.LAST_BROADCAST.get("rccl_error") or bcast, world, got_dev, got_nr)
             sys.stderr.write("bench.py: " + rccl_error + "\n")
 
     stream = hip.shl_mi355x_stream_create()

@@ -208,6 +208,9 @@ def load_hip():
         "shl_mi355x_conv_plan_adopt_block": (C.c_int, [vp, vp]),
         "shl_mi355x_conv_forward": (C.c_int, [vp, vp, vp, i32, vp]),
         "shl_mi355x_pwdw_fusable": (C.c_int, [vp, vp, i32]),
+        "shl_mi355x_pool_conv_fusable": (C.c_int, [vp, i32, i32]),
+        "shl_mi355x_pool_conv_forward": (C.c_int, [vp, vp, vp, i32, i32, f32, i32, f32, i32, vp]),
+        "shl_mi355x_conv_plan_set_no_stream_consumer": (C.c_int, [vp, i32]),
         "shl_mi355x_pwdw_forward": (C.c_int, [vp, vp, vp, vp, i32, vp]),
         "shl_mi355x_relu_i8": (C.c_int, [vp, vp, sz, f32, i32, f32, i32, i32, vp]),
         "shl_mi355x_relu_f16": (C.c_int, [vp, vp, sz, i32, vp]),
@@ -309,6 +312,9 @@ def load_backend(frontend):
         opt.shl_mi355x_params_kernel_name.argtypes = [C.c_void_p]
         opt.shl_mi355x_session_is_device_resident.argtypes = [C.POINTER(Session)]
         opt.shl_mi355x_session_fused_pairs.argtypes = [C.POINTER(Session)]
+        opt.shl_mi355x_session_fused_pools.argtypes = [C.POINTER(Session)]
+        opt.shl_mi355x_registry_get.restype = C.c_void_p
+        opt.shl_mi355x_registry_get.argtypes = [C.c_void_p]
         opt.shl_mi355x_session_folded_activations.argtypes = [C.POINTER(Session)]
         opt.shl_mi355x_session_stream.argtypes = [C.POINTER(Session)]
         opt.shl_mi355x_session_stream.restype = C.c_void_p

@@ -146,6 +146,20 @@ __device__ __forceinline__ float div_by_scale(float f, float s, float y)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// SHL_EPI_PACKED_F32 = 1 (default): the int8 requantisation on packed fp32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: half
+// the instructions).  0: one-value instructions, which do not wait for another wave's MFMAs (see requant4_i8_t) -- measured
+// in round 6 (profiles/r06_notes.md): no faster anywhere (the kernels' phases are not limited by that wait), 2 - 4 % slower
+// where the requantisation itself is the bound (dwpw_stream, converter scales).  Kept as a build switch.
+#ifndef SHL_EPI_PACKED_F32
+#define SHL_EPI_PACKED_F32 1
+#endif
+// keeps the SLP vectoriser from re-packing neighbouring one-value operations (an empty asm the value passes through)
+__device__ __forceinline__ float opaque_f32(float x)
+{
+    asm("" : "+v"(x));  // (not volatile: the scheduler may still move it)
+    return x;
+}
+
 __device__ __forceinline__ v2f div_by_scale2(v2f f, float s, float y)
 {
     const v2f ns = {-s, -s}, yy = {y, y};
@@ -213,7 +227,9 @@ __device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3
         // x = fl(fl(S m) + b) / s on packed fp32: two IEEE operations when s is a power of two (the plan folded
         // 1 / s into both tables, which is exact), six when the plan admits div_by_scale, the hardware's division
         // otherwise.
-        v2f lo = {(float)s0, (float)s1}, hi = {(float)s2, (float)s3};
+        v2f lo, hi;
+#if SHL_EPI_PACKED_F32
+        lo = v2f{(float)s0, (float)s1}, hi = v2f{(float)s2, (float)s3};
         const v2f mlo = {m.x, m.y}, mhi = {m.z, m.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
         lo = lo * mlo;
         hi = hi * mhi;
@@ -228,6 +244,26 @@ __device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3
             lo = v2f{__fdiv_rn(lo.x, a.out_scale), __fdiv_rn(lo.y, a.out_scale)};
             hi = v2f{__fdiv_rn(hi.x, a.out_scale), __fdiv_rn(hi.y, a.out_scale)};
         }
+#else
+        // one-value fp32 instructions (same operations, same roundings): v_pk_mul / add / fma_f32 execute on the matrix
+        // pipe's datapath and wait for a v_mfma in flight on the SIMD -- of ANY wave (tools/probes/mfma_valu_intrawave.hip:
+        // one packed instruction behind an MFMA costs the slot 19 cycles, six plain ones nothing;
+        // tools/probes/mfma_valu_prio.hip: a wave of plain fp32 VALU work runs at 85 - 100 % of its own pace beside another
+        // wave's back-to-back MFMAs).  With plain instructions the requantisation of one wave hides under the K loop of its
+        // neighbour on the SIMD.
+        float x0 = opaque_f32(__fadd_rn(__fmul_rn((float)s0, m.x), b.x)), x1 = opaque_f32(__fadd_rn(__fmul_rn((float)s1, m.y), b.y));
+        float x2 = opaque_f32(__fadd_rn(__fmul_rn((float)s2, m.z), b.z)), x3 = opaque_f32(__fadd_rn(__fmul_rn((float)s3, m.w), b.w));
+        if constexpr (EPI >= 3) {
+            // power-of-two scale: the plan multiplied both tables by 1 / s (exact), fl(fl(S m') + b') IS the quotient
+        } else if (!kHwDiv || a.div_fma) {
+            x0 = opaque_f32(div_by_scale(x0, a.out_scale, a.inv_out_scale)), x1 = opaque_f32(div_by_scale(x1, a.out_scale, a.inv_out_scale));
+            x2 = opaque_f32(div_by_scale(x2, a.out_scale, a.inv_out_scale)), x3 = opaque_f32(div_by_scale(x3, a.out_scale, a.inv_out_scale));
+        } else {
+            x0 = __fdiv_rn(x0, a.out_scale), x1 = __fdiv_rn(x1, a.out_scale);
+            x2 = __fdiv_rn(x2, a.out_scale), x3 = __fdiv_rn(x3, a.out_scale);
+        }
+        lo = v2f{x0, x1}, hi = v2f{x2, x3};
+#endif
         // clamp FIRST, to [lo - zp, hi - zp]: both bounds are integers, rint is monotone and fixes integers, so
         //   rint(clamp(x)) + zp == clamp(rint(x) + zp)  -- the order the reference uses;
         // rint by the magic constant: |x| <= 383 after the clamp, so fl(x + 1.5 * 2^23) holds rint(x) (ties to
@@ -238,8 +274,13 @@ __device__ __forceinline__ uint32_t requant4_i8_t(int s0, int s1, int s2, int s3
         const v2f magic = {12582912.0f, 12582912.0f};
         v2f c0 = {__builtin_amdgcn_fmed3f(lo.x, cl, ch), __builtin_amdgcn_fmed3f(lo.y, cl, ch)};
         v2f c1 = {__builtin_amdgcn_fmed3f(hi.x, cl, ch), __builtin_amdgcn_fmed3f(hi.y, cl, ch)};
+#if SHL_EPI_PACKED_F32
         c0 = c0 + magic;
         c1 = c1 + magic;
+#else
+        c0 = v2f{opaque_f32(__fadd_rn(c0.x, magic.x)), opaque_f32(__fadd_rn(c0.y, magic.x))};
+        c1 = v2f{opaque_f32(__fadd_rn(c1.x, magic.x)), opaque_f32(__fadd_rn(c1.y, magic.x))};
+#endif
         typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
         const uint32_t p01 = __builtin_amdgcn_perm(__float_as_uint(c0.y), __float_as_uint(c0.x), 0x05040100u);
         const uint32_t p23 = __builtin_amdgcn_perm(__float_as_uint(c1.y), __float_as_uint(c1.x), 0x05040100u);
@@ -519,6 +560,8 @@ int launch_conv1x1_stream(const ConvArgs &a, hipStream_t s);
 int launch_dwconv_channel(const ConvArgs &a, hipStream_t s);  // dwconv_channel.hip
 bool conv_gemv_pick(const ConvArgs &a, int esize);             // conv_gemv.hip: 1x1 on <= 8 pixels
 int launch_conv_gemv(const ConvArgs &a, int dtype, hipStream_t s);
+bool pool_gemv_pick(const ConvArgs &a, int hw);                     // conv_gemv.hip: global_avgpool2d + the GEMV in one launch
+int launch_pool_gemv(const ConvArgs &a, int hw, float in_scale, int in_zp, float mid_scale, int mid_zp, hipStream_t s);
 bool stem_supports(const shl_mi355x_conv_desc &d);
 void stem_pack_weights(const shl_mi355x_conv_desc &d, const int8_t *ohwi, int32_t *dst);
 size_t stem_weight_bytes(const shl_mi355x_conv_desc &d);

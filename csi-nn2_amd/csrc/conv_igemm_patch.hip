@@ -349,6 +349,7 @@ bool patch_setup(ConvArgs &a)
     const int cbytes = a.C * (PT_F16(a.pt_geom) ? 2 : 1);
     if (PT_F16(a.pt_geom) && !PT_S2(a.pt_geom) && (a.sh != 1 || a.sw != 1)) return false;
     if (PT_S2(a.pt_geom) && (!a.in_nchw || a.sh != 2 || a.sw != 2)) return false;
+    if (PT_NBT(a.pt_geom) != PT_NB && !a.in_nchw) return false;  // small tiles exist as NCHW instantiations only (patch_launch_one)
     if (!patch_shape(a.N, a.H, a.W, cbytes, a.Co, a.in_nchw != 0, a.pt_geom, &ps)) return false;
     a.pt_rows = ps.rows;
     a.pt_prows = ps.prows;

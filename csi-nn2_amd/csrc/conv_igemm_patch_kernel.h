@@ -11,6 +11,15 @@
 
 namespace shl {
 
+#ifndef SHL_PT_LEAD_PRIO
+#define SHL_PT_LEAD_PRIO 0
+#endif
+#ifndef SHL_PT_TRACE2
+#define SHL_PT_TRACE2 0
+#endif
+#ifndef SHL_PT_KPRIO
+#define SHL_PT_KPRIO 0
+#endif
 constexpr int PT_NB = 13;                // MFMA pixel blocks (32 pixels) per wave
 constexpr int PT_PIX = PT_NB * 32;       // 416
 constexpr int PT_D = 7;                  // B fragments are read this many MFMAs ahead (ring of 8)
@@ -87,7 +96,12 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
     static_assert(!kF16 || (!kPair && NW == 8), "binary16: eight waves, no pair mode");
     int trace_k = 0;
     auto mark = [&]() {
-        if ((a.debug & 32) && blockIdx.x == 0 && threadIdx.x == 0 && trace_k < 64) g_pt_trace[trace_k++] = __builtin_amdgcn_s_memtime();
+#if SHL_PT_TRACE2  // (a trace build: wave 0 -> stamps 0 .. 31, wave 4 -- the other half of wave 0's role, on the same SIMD -- -> 32 .. 63:
+                   // tools/dev/patch_trace2.py; the product build stamps wave 0 only -- four NHWC instantiations spill with the wider test)
+        if ((a.debug & 32) && blockIdx.x == 0 && (threadIdx.x & 255) == 0 && trace_k < 32) g_pt_trace[(threadIdx.x >> 8) * 32 + trace_k++] = __builtin_amdgcn_s_memtime();
+#else
+        if ((a.debug & 32) && blockIdx.x == 0 && threadIdx.x == 0 && trace_k < 32) g_pt_trace[trace_k++] = __builtin_amdgcn_s_memtime();
+#endif
     };
     mark();
     if ((a.debug & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_pt_span[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -571,8 +585,20 @@ __device__ __forceinline__ void patch_body(const ConvArgs &a, char *const smem, 
                 rb[j] = *reinterpret_cast<const v4i *>(smem + (pbase[j] + cur));
             });
         }
+        // -DSHL_PT_LEAD_PRIO=1 (experiment, round 6): half 0 of a role runs the K steps no barrier follows at a higher
+        // priority -- it takes the matrix pipe first, finishes early and requantises (plain fp32 VALU: common.h) under
+        // half 1's MFMAs instead of beside half 1's requantisation
+        const bool lead = SHL_PT_LEAD_PRIO && NW == 8 && KP == 1 && h == 0 && st + 1 == nstg && (!kPair || PASS == 1);
+        if (lead) __builtin_amdgcn_s_setprio(2);
+#if SHL_PT_KPRIO  // every wave's K steps above every wave's requantisation in the SIMD's arbitration
+        __builtin_amdgcn_s_setprio(SHL_PT_KPRIO);
+#endif
         for (int step = 0; step < NSTEP; step += SPI)
             static_for<SPI>([&](auto fc) { kstep(passc, fc, s, step + decltype(fc)::value, bufoff, more); });
+        if (lead) __builtin_amdgcn_s_setprio(0);
+#if SHL_PT_KPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         mark();        // 6 + 2 s: K steps of the stage done
         // behind the LAST stage nothing of LDS is touched again when a wave finishes its blocks from its own registers
         // (one K part; the second tile of a pair): a wave that is done starts its epilogue at once.  (Worth ~1 %: the VALU
@@ -943,57 +969,80 @@ static void patch_launch_nw(const ConvArgs &a, unsigned tiles, size_t lds, hipSt
     hipLaunchKernelGGL(kernel, dim3(tiles), dim3(NW * 64), lds, s, a);
 }
 
+// (returns false where the geometry / layout pair has no instantiation: the caller reports ENOTSUP instead of leaving the
+// output tensor stale behind an OK -- ADVICE r05)
 template <bool kF16, int EPI, bool kNchw, int KC, int PG, int OB, int KP>
-static void patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
+static bool patch_launch_one(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
+    const int nbt = PT_NBT(a.pt_geom);
     if constexpr (kF16) {  // stride 1, no pair mode, eight waves (the host sets the bit: patch_choose_geom)
-        if constexpr (kNchw && KC == 128 && KP == 1) {
-            const bool s2 = PT_S2(a.pt_geom) != 0;
-            if constexpr (PG == 1 && OB == 4) {  // small tiles, as for int8 below
-                if (PT_NBT(a.pt_geom) == 7) {
-                    if (s2) return patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
-                    return patch_launch_nw<true, 0, true, false, false, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
+        const bool s2 = PT_S2(a.pt_geom) != 0;
+        if (nbt != PT_NB) {  // small tiles, as for int8 below
+            if constexpr (kNchw && KC == 128 && KP == 1 && PG == 1 && OB == 4) {
+                if (nbt == 7) {
+                    if (s2) patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
+                    else patch_launch_nw<true, 0, true, false, false, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
+                } else {
+                    if (s2) patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
+                    else patch_launch_nw<true, 0, true, false, false, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
                 }
-                if (PT_NBT(a.pt_geom) == 4) {
-                    if (s2) return patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
-                    return patch_launch_nw<true, 0, true, false, false, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
-                }
+                return true;
             }
-            if (s2) return patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
+            return false;
+        }
+        if (s2) {
+            if constexpr (kNchw && KC == 128 && KP == 1) {
+                patch_launch_nw<true, 0, true, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
+                return true;
+            }
+            return false;
         }
         patch_launch_nw<true, 0, kNchw, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
-    } else if (PT_NBT(a.pt_geom) != PT_NB) {
+        return true;
+    } else if (nbt != PT_NB) {
         // small tiles (7 / 4 blocks per role): NCHW, eight waves, one K part, four channel blocks, 128-byte stages
         if constexpr (KC == 128 && KP == 1 && kNchw && PG == 1 && OB == 4) {
             const bool s2 = PT_S2(a.pt_geom) != 0;
-            if (PT_NBT(a.pt_geom) == 7) {
+            if (nbt == 7) {
                 if (s2) patch_launch_nw<false, EPI, true, false, true, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
                 else patch_launch_nw<false, EPI, true, false, false, KC, PG, OB, KP, 8, 7>(a, tiles, lds, s);
             } else {
                 if (s2) patch_launch_nw<false, EPI, true, false, true, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
                 else patch_launch_nw<false, EPI, true, false, false, KC, PG, OB, KP, 8, 4>(a, tiles, lds, s);
             }
+            return true;
         }
+        return false;
     } else if (PT_S2(a.pt_geom)) {
-        if constexpr (KC == 128 && KP == 1 && kNchw) patch_launch_nw<false, EPI, true, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
+        if constexpr (KC == 128 && KP == 1 && kNchw) {
+            patch_launch_nw<false, EPI, true, false, true, KC, PG, OB, KP, 8>(a, tiles, lds, s);  // the stride-2 form
+            return true;
+        }
+        return false;
     } else if (PT_NW8(a.pt_geom)) {
         if constexpr (KP == 1) {  // pair mode exists for eight waves, one K part
-            if (a.pt_pair_in) return patch_launch_nw<false, EPI, kNchw, true, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+            if (a.pt_pair_in) {
+                patch_launch_nw<false, EPI, kNchw, true, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+                return true;
+            }
         }
         patch_launch_nw<false, EPI, kNchw, false, false, KC, PG, OB, KP, 8>(a, tiles, lds, s);
+        return true;
     } else {
         patch_launch_nw<false, EPI, kNchw, false, false, KC, PG, OB, KP, 4>(a, tiles, lds, s);
+        return true;
     }
 }
 
 template <bool kF16, bool kNchw, int KC, int PG, int OB, int KP>
-static void patch_launch_geom(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
+static bool patch_launch_geom(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
     if constexpr ((KC / 32) % KP == 0) {
-        if constexpr (kF16) patch_launch_one<true, 0, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
-        else if (a.div_exact != 0) patch_launch_one<false, 3, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
-        else patch_launch_one<false, 0, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
+        if constexpr (kF16) return patch_launch_one<true, 0, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
+        else if (a.div_exact != 0) return patch_launch_one<false, 3, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
+        else return patch_launch_one<false, 0, kNchw, KC, PG, OB, KP>(a, tiles, lds, s);
     }
+    return false;
 }
 
 // every geometry of one layout (one translation unit per layout: the 40 kernels of a layout take ~2 minutes)
@@ -1001,12 +1050,13 @@ template <bool kNchw, bool kF16 = false>
 static int patch_launch_layout(const ConvArgs &a, unsigned tiles, size_t lds, hipStream_t s)
 {
     const int kc = PT_KC(a.pt_geom), key = PT_PG(a.pt_geom) * 100 + PT_OB(a.pt_geom) * 10 + PT_KP(a.pt_geom);
+    bool launched = false;
 #define SHL_PT(KCV)                                                                \
     switch (key) {                                                                 \
-        case 141: patch_launch_geom<kF16, kNchw, KCV, 1, 4, 1>(a, tiles, lds, s); break; \
-        case 221: patch_launch_geom<kF16, kNchw, KCV, 2, 2, 1>(a, tiles, lds, s); break; \
-        case 122: patch_launch_geom<kF16, kNchw, KCV, 1, 2, 2>(a, tiles, lds, s); break; \
-        case 114: patch_launch_geom<kF16, kNchw, KCV, 1, 1, 4>(a, tiles, lds, s); break; \
+        case 141: launched = patch_launch_geom<kF16, kNchw, KCV, 1, 4, 1>(a, tiles, lds, s); break; \
+        case 221: launched = patch_launch_geom<kF16, kNchw, KCV, 2, 2, 1>(a, tiles, lds, s); break; \
+        case 122: launched = patch_launch_geom<kF16, kNchw, KCV, 1, 2, 2>(a, tiles, lds, s); break; \
+        case 114: launched = patch_launch_geom<kF16, kNchw, KCV, 1, 1, 4>(a, tiles, lds, s); break; \
         default: return SHL_MI355X_ENOTSUP;                                        \
     }
     if (kc == 128) {
@@ -1015,6 +1065,10 @@ static int patch_launch_layout(const ConvArgs &a, unsigned tiles, size_t lds, hi
         SHL_PT(64)
     }
 #undef SHL_PT
+    if (!launched) {
+        set_error("conv_igemm_patch: no instantiation for geometry 0x%x in this layout", a.pt_geom);
+        return SHL_MI355X_ENOTSUP;
+    }
     return SHL_MI355X_OK;
 }
 

@@ -38,6 +38,7 @@ struct shl_mi355x_conv_plan {
     int32_t cchunks;
     const char *kernel_name;
     const char *variant;  // implicit-GEMM family measured best at plan time (tune_plan), nullptr = the selection rules
+    int32_t no_stream_consumer;  // a depthwise layer whose consumer is NOT a pointwise layer dwpw_stream fuses with (set by the graph's owner)
 };
 
 namespace shl {
@@ -234,14 +235,32 @@ static void release_unused_pix_tab(shl_mi355x_conv_plan *p, bool rules_need_it)
     }
 }
 
+static std::vector<int32_t> tune_key(const shl_mi355x_conv_plan *p)
+{
+    const shl_mi355x_conv_desc &d = p->desc;
+    return {d.layout, d.dtype, d.act, d.batch, d.in_h, d.in_w, d.in_c, d.out_h, d.out_w, d.out_c,
+            d.kernel_h, d.kernel_w, d.stride_h, d.stride_w, d.pad_top, d.pad_left, d.dilation_h,
+            d.dilation_w, p->div_exact, p->div_fma, p->act_clamp, p->pt_geom};
+}
+
+// a cached verdict for the plan's shape that does not need the per-pixel table: the table (8 B x N Ho Wo, built on the host
+// and uploaded) need not exist at all -- it used to be built, uploaded and freed again on every cache hit.
+// Limitation, by design: a plan whose table was released runs a LATER forward with a smaller batch on whatever the rules
+// pick without the table (the producer / consumer family is then not a candidate) -- correct, possibly slower than a plan
+// created for that batch.
+static bool tune_cached_without_pix_tab(const shl_mi355x_conv_plan *p)
+{
+    std::lock_guard<std::mutex> g(g_tune_lock);
+    auto it = g_tune_cache.find(tune_key(p));
+    return it != g_tune_cache.end() && !(it->second.variant && !strcmp(it->second.variant, "pc"));
+}
+
 static void tune_plan(shl_mi355x_conv_plan *p, hipStream_t stream, bool rules_need_pix_tab)
 {
     const shl_mi355x_conv_desc &d = p->desc;
     if (!tuning_enabled(d.dtype) || d.batch <= 0) return;
     const bool i8 = d.dtype == SHL_MI355X_I8;
-    const std::vector<int32_t> key = {d.layout, d.dtype, d.act, d.batch, d.in_h, d.in_w, d.in_c, d.out_h, d.out_w, d.out_c,
-                                      d.kernel_h, d.kernel_w, d.stride_h, d.stride_w, d.pad_top, d.pad_left, d.dilation_h,
-                                      d.dilation_w, p->div_exact, p->div_fma, p->act_clamp, p->pt_geom};
+    const std::vector<int32_t> key = tune_key(p);
     {
         std::lock_guard<std::mutex> g(g_tune_lock);
         auto it = g_tune_cache.find(key);
@@ -657,7 +676,8 @@ static int plan_create_impl(const struct shl_mi355x_conv_desc *desc, const void 
         return hip_fail(e, "upload(plan block)");
     }
     const bool rules_need_pix_tab = want_pix_tab;
-    if (algo == SHL_MI355X_ALGO_IGEMM && tuning_enabled(d.dtype) && d.batch > 0 && kernel_host) want_pix_tab = true;  // a candidate of tune_plan
+    if (algo == SHL_MI355X_ALGO_IGEMM && tuning_enabled(d.dtype) && d.batch > 0 && kernel_host && !tune_cached_without_pix_tab(p))
+        want_pix_tab = true;  // a candidate of tune_plan
     if (want_pix_tab) {
         const int64_t M = (int64_t)d.batch * d.out_h * d.out_w;
         std::vector<int2> tab((size_t)M);
@@ -973,7 +993,7 @@ int shl_mi355x_debug_trace(uint64_t *host, int32_t count)
 /* which fused kernel runs the pair (first layer `pw`, second `dw`; 6 is the pair in the other order): 0 none, 1 latency form (pwdw_fused.hip: small grids), 3 stem + depthwise
  * (stemdw_fused.hip), 4 binary16 NCHW (pwdw_f16_nchw.hip), 5 binary16 NCHW stem + depthwise (stemdw_f16_nchw.hip).  (2 was the int8 bandwidth form for large batches: it only
  * broke even with the two stand-alone kernels, attic/README.md.)  6 = depthwise -> pointwise in bandwidth form (dwpw_stream.hip): the
- * 32 / 64 / 128-channel blocks at large batches. */
+ * 32 / 64 / 128 / 256-channel blocks at large batches. */
 static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, const ConvArgs &a,
                            const ConvArgs &b)
 {
@@ -992,10 +1012,56 @@ static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv
     // (dwpw_stream.hip); a chain pairs up one way round
     {
         static const char *sel = getenv("SHL_MI355X_PWDW");  // "2": latency forms without size rules (A/B)
-        if (!(sel && sel[0] == '2') && dw_dot4 && dwpw_stream_takes(b)) return 0;
+        // (... unless the graph's owner said that this depthwise layer has no such consumer -- MobileNetV2's dw 32 -> pw 16, two
+        // consumers, a non-1x1 layer behind it: shl_mi355x_conv_plan_set_no_stream_consumer; without the hint both fusions were lost)
+        if (!(sel && sel[0] == '2') && dw_dot4 && dwpw_stream_takes(b) && !dw->no_stream_consumer) return 0;
     }
     if (pw->algo == SHL_MI355X_ALGO_STEM) return dw_dot4 && stemdw_fusable(a, b) ? 3 : 0;  // stem + depthwise
     return pwdw_fusable(a, b, pw_igemm, dw_dot4) ? 1 : 0;
+}
+
+int shl_mi355x_conv_plan_set_no_stream_consumer(shl_mi355x_conv_plan *plan, int32_t on)
+{
+    if (!plan) return SHL_MI355X_EINVAL;
+    plan->no_stream_consumer = on ? 1 : 0;
+    return SHL_MI355X_OK;
+}
+
+/* global_avgpool2d + the convolution / fullyconnected layer on the pooled map in one launch (conv_gemv.hip:pool_gemv_i8_kernel) */
+int shl_mi355x_pool_conv_fusable(const shl_mi355x_conv_plan *plan, int32_t batch, int32_t pixels)
+{
+    if (!plan || plan->algo != SHL_MI355X_ALGO_IGEMM || plan->desc.dtype != SHL_MI355X_I8) return 0;
+    static const char *off = getenv("SHL_MI355X_NO_FUSION");
+    if (off && off[0] == '1') return 0;
+    // OFF unless SHL_MI355X_POOLGEMV=1 (read per call).  Measured in round 6 (tools/dev/pool_gemv_time.py, session_ab.py;
+    // profiles/r06_notes.md): 7 x 7 x 1024 -> 1000: avgpool 4.19 us + GEMV 2.45 us = 6.77 us as two launches, 8.52 us fused
+    // (every workgroup that needs the pooled vector repeats the pooling: 16 x the additions per CU), csinn_session_run
+    // 84.5 -> 87.0 us.  Kept as a tested, bit-exact entry point; the session does not take it by default.
+    const char *sel = getenv("SHL_MI355X_POOLGEMV");
+    if (!(sel && sel[0] == '1')) return 0;
+    if (plan->desc.in_h * plan->desc.in_w != 1 || igemm_env_override()) return 0;
+    ConvArgs a;
+    static char dummy[16];
+    if (fill_args(plan, dummy, dummy, batch, a) != SHL_MI355X_OK) return 0;
+    return pool_gemv_pick(a, pixels) ? 1 : 0;
+}
+
+int shl_mi355x_pool_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev, void *output_dev, int32_t batch,
+                                 int32_t pixels, float in_scale, int32_t in_zp, float mid_scale, int32_t mid_zp, void *stream)
+{
+    if (!plan || !input_dev || !output_dev) {
+        set_error("pool_conv_forward: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    if (!shl_mi355x_pool_conv_fusable(plan, batch, pixels) || mid_zp != plan->desc.in_zp) {
+        set_error("pool_conv_forward: the pair does not qualify for the fused kernel");
+        return SHL_MI355X_ENOTSUP;
+    }
+    ConvArgs a;
+    int rc = fill_args(plan, input_dev, output_dev, batch, a);
+    if (rc != SHL_MI355X_OK) return rc;
+    if (a.M == 0) return SHL_MI355X_OK;
+    return launch_pool_gemv(a, pixels, in_scale, in_zp, mid_scale, mid_zp, (hipStream_t)stream);
 }
 
 /* pointwise 1x1 + the depthwise 3x3 consuming it, fused into one launch */

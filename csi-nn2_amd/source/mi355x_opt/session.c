@@ -45,6 +45,7 @@ struct dev_session {
     unsigned char *fused;  /* per layer: 2 = runs fused with the depthwise layer behind it (pointwise + depthwise) */
     unsigned char *folded; /* per layer: 1 = the relu / relu6 layer behind it runs in this convolution's epilogue */
     int nfused, nfolded;
+    int npool; /* global_avgpool2d layers that run inside their consumer's launch */
     struct dev_session *next;
 };
 
@@ -181,7 +182,7 @@ static struct shl_node *final_out(struct dev_session *ds, struct shl_ref_graph *
  *        converter emits for a RISC-V target -- example/c906_mobilenetv1_f16.c is 28 csinn_conv2d + 27 csinn_relu --
  *        runs as 28 launches, not 55
  *   1x1 convolution -> depthwise 3x3   one launch of csrc/pwdw_fused.hip (int8 NHWC) / pwdw_f16_nchw.hip (fused[i] = 2)
- *   depthwise 3x3 -> 1x1 convolution   one launch of csrc/dwpw_stream.hip at throughput batches (32 / 64 / 128 channels:
+ *   depthwise 3x3 -> 1x1 convolution   one launch of csrc/dwpw_stream.hip at throughput batches (32 / 64 / 128 / 256 channels:
  *        the requantised depthwise tile is the pointwise MFMA operand); the latency form of this pairing recomputed the
  *        depthwise tile in every channel slice and is parked (attic/README.md) */
 static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
@@ -202,6 +203,23 @@ static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
             i++; /* the activation layer is taken */
         }
     }
+    /* a depthwise layer whose output does not feed ONE pointwise layer that the bandwidth form takes keeps its latency pair
+     * (the plan pair test below cannot see a layer's consumer: ADVICE r05 -- dw 32 -> pw 16 of MobileNetV2, two consumers, ...) */
+    for (int i = 0; i < g->layer_index; i++) {
+        struct shl_node *a = g->layer[i];
+        if (!is_dw_op(a->type)) continue;
+        shl_mi355x_conv_plan *pa = shl_mi355x_registry_get(a->data);
+        if (pa == NULL) continue;
+        const int j = i + 1 + ds->folded[i];
+        struct shl_node *mid = final_out(ds, g, i);
+        struct csinn_tensor *in = a->in[0]->data;
+        int streams = 0;
+        if (j < g->layer_index && g->layer[j]->in[0] == mid && is_conv_op(g->layer[j]->type) && consumers_of(g, mid) == 1) {
+            shl_mi355x_conv_plan *pb = shl_mi355x_registry_get(g->layer[j]->data);
+            streams = pb != NULL && shl_mi355x_pwdw_fusable(pa, pb, in->dim[0]);
+        }
+        shl_mi355x_conv_plan_set_no_stream_consumer(pa, !streams);
+    }
     for (int i = 0; i + 1 < g->layer_index; i++) {
         const int j = i + 1 + ds->folded[i]; /* the next layer that still runs */
         if (j >= g->layer_index) break;
@@ -210,6 +228,22 @@ static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
         if (b->in[0] != mid) {
             i = j - 1;
             continue;
+        }
+        /* global_avgpool2d -> the convolution / fullyconnected layer on the pooled map: one launch (csrc/conv_gemv.hip) */
+        if (a->type == CSINN_OP_GLOBAL_AVGPOOL2D && (is_conv_op(b->type) || b->type == CSINN_OP_FULLYCONNECTED) &&
+            consumers_of(g, mid) == 1) {
+            struct csinn_tensor *pin = a->in[0]->data, *pmid = mid->data;
+            struct csinn_pool_params *pp = a->data;
+            shl_mi355x_conv_plan *pb = shl_mi355x_registry_get(b->data);
+            const int nhwc = pp->base.layout == CSINN_LAYOUT_NHWC;
+            if (pb && nhwc && pin->dim_count == 4 && pin->dtype == CSINN_DTYPE_INT8 && pin->qinfo && pmid->qinfo &&
+                pin->quant_channel <= 1 && pmid->quant_channel <= 1 &&
+                shl_mi355x_pool_conv_fusable(pb, pin->dim[0], pin->dim[1] * pin->dim[2])) {
+                ds->fused[i] = 3;
+                ds->npool++;
+                i = j + ds->folded[j];
+                continue;
+            }
         }
         /* pointwise -> depthwise (latency form, small batches) or depthwise -> pointwise (bandwidth form, large
          * batches: csrc/dwpw_stream.hip); shl_mi355x_pwdw_fusable tells the orders apart by the plans */
@@ -242,7 +276,18 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
         struct dev_tensor *out = lookup(ds, folded ? g->layer[i + 1]->out[0] : n->out[0]);
         int (*f)() = params->cb->exec;
         int rc;
-        if (ds->fused && ds->fused[i]) {
+        if (ds->fused && ds->fused[i] == 3) { /* global_avgpool2d + the layer on the pooled map */
+            const int j = i + 1;
+            struct shl_node *nx = g->layer[j];
+            const int folded2 = ds->folded && ds->folded[j];
+            struct dev_tensor *out2 = lookup(ds, folded2 ? g->layer[j + 1]->out[0] : nx->out[0]);
+            struct csinn_tensor *pin = n->in[0]->data, *pmid = n->out[0]->data;
+            int st = shl_mi355x_pool_conv_forward(shl_mi355x_registry_get(nx->data), in->dev, out2->dev, in->shadow.dim[0],
+                                                  pin->dim[1] * pin->dim[2], pin->qinfo->scale, pin->qinfo->zero_point,
+                                                  pmid->qinfo->scale, pmid->qinfo->zero_point, ds->stream);
+            rc = st == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
+            i = j + folded2;
+        } else if (ds->fused && ds->fused[i]) {
             const int j = i + 1 + folded;
             struct shl_node *nx = g->layer[j];
             const int folded2 = ds->folded && ds->folded[j];
@@ -474,6 +519,12 @@ void shl_mi355x_session_deinit(struct csinn_session *sess)
 }
 
 /* number of depthwise + pointwise pairs that run as one launch in `sess` */
+int shl_mi355x_session_fused_pools(struct csinn_session *sess)
+{
+    struct dev_session *ds = find_session(sess);
+    return ds ? ds->npool : 0;
+}
+
 int shl_mi355x_session_fused_pairs(struct csinn_session *sess)
 {
     struct dev_session *ds = find_session(sess);

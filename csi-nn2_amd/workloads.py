@@ -183,6 +183,16 @@ class LayerChain:
         self.units = []  # launches of one pass: [layer index] or [pointwise index, depthwise index]
         opt.shl_mi355x_registry_get.restype = C.c_void_p
         opt.shl_mi355x_registry_get.argtypes = [C.c_void_p]
+        # a depthwise layer whose output does not feed a pointwise layer the bandwidth form takes keeps its latency pair
+        # (session.c:plan_fusion does the same: the plan-pair test cannot see a layer's consumer)
+        for k, e in enumerate(self.entries):
+            if not e["layer"]["depthwise"]:
+                continue
+            nxt = self.entries[k + 1] if k + 1 < len(self.entries) else None
+            streams = bool(fuse and nxt is not None and not nxt["layer"]["depthwise"] and nxt["d_in"] == e["d_out"]
+                           and hip.shl_mi355x_pwdw_fusable(opt.shl_mi355x_registry_get(e["params"]),
+                                                           opt.shl_mi355x_registry_get(nxt["params"]), batch) == 1)
+            hip.shl_mi355x_conv_plan_set_no_stream_consumer(opt.shl_mi355x_registry_get(e["params"]), 0 if streams else 1)
         i = 0
         while i < len(self.entries):
             a = self.entries[i]

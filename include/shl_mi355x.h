@@ -268,6 +268,18 @@ int shl_mi355x_conv_plan_adopt_block(shl_mi355x_conv_plan *plan, void *stream);
 int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev,
                             void *output_dev, int32_t batch, void *stream);
 
+/* global_avgpool2d + the convolution / fullyconnected layer that consumes the pooled [N, 1, 1, C] map, in ONE launch
+ * (MobileNetV1's tail; int8 NHWC, at most 64 pooled pixels and 8 images): `input_dev` is the POOL's input [N][pixels][C],
+ * (in_scale, in_zp) its record, (mid_scale, mid_zp) the pooled tensor's record (= the plan's input record).  Bit-identical to
+ * shl_mi355x_global_avgpool2d followed by shl_mi355x_conv_forward (the same operations in the reference's order:
+ * source/reference/global_averagepool.c:46-50, averagepool.c:21-119).  _fusable: 1 when the plan and the sizes qualify. */
+int shl_mi355x_pool_conv_fusable(const shl_mi355x_conv_plan *plan, int32_t batch, int32_t pixels);
+int shl_mi355x_pool_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev, void *output_dev, int32_t batch,
+                                 int32_t pixels, float in_scale, int32_t in_zp, float mid_scale, int32_t mid_zp, void *stream);
+/* A hint from the owner of the graph: this depthwise layer's output does NOT feed a pointwise layer the bandwidth form
+ * (depthwise -> pointwise in one launch, large batches) takes -- the latency form (pointwise -> depthwise) then keeps the
+ * layer instead of yielding it (shl_mi355x_pwdw_fusable asks plan pairs, it cannot see a layer's consumer). */
+int shl_mi355x_conv_plan_set_no_stream_consumer(shl_mi355x_conv_plan *plan, int32_t on);
 /*
  * Pointwise 1x1 + the depthwise 3x3 that consumes its output, as ONE launch (int8 NHWC): a workgroup
  * owns a 32-channel slice of shl_ref_conv2d_quant's output over a small pixel patch, keeps the int8
@@ -276,7 +288,7 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
  * written.  `input_dev` is the pointwise layer's input, `output_dev` the depthwise layer's output.
  *
  * The same two entry points take the pair in the OTHER order -- first plan = a depthwise 3x3 layer, second plan =
- * the pointwise layer consuming it (32 / 64 / 128 channels, int8 NHWC, throughput batches; csrc/dwpw_stream.hip):
+ * the pointwise layer consuming it (32 / 64 / 128 / 256 channels, int8 NHWC, throughput batches; csrc/dwpw_stream.hip):
  * the requantised depthwise tile is the pointwise layer's MFMA operand and never leaves the chip.  `input_dev` is
  * always the first layer's input and `output_dev` the second layer's output; the plans say which order it is.
  */

@@ -115,6 +115,8 @@ int shl_mi355x_session_is_device_resident(struct csinn_session *sess);
 void *shl_mi355x_session_stream(struct csinn_session *sess);
 /* depthwise + pointwise pairs of `sess` that run as one fused launch (graph-level fusion) */
 int shl_mi355x_session_fused_pairs(struct csinn_session *sess);
+/* global_avgpool2d layers that run inside the launch of the convolution / fullyconnected layer consuming them */
+int shl_mi355x_session_fused_pools(struct csinn_session *sess);
 /* relu / relu6 layers of `sess` that were folded into the epilogue of the convolution they follow */
 int shl_mi355x_session_folded_activations(struct csinn_session *sess);
 

@@ -182,6 +182,9 @@ def test_bench_shards_a_total_batch_over_two_ranks_on_one_device():
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=cases.ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    # (stdout carries the compact line; the full record -- config details, windows -- is the BENCH_FULL line on stderr)
+    compact, line = line, json.loads([l for l in res.stderr.splitlines() if l.startswith("BENCH_FULL ")][-1][len("BENCH_FULL "):])
+    assert compact["n_gpus"] == 2 and compact["value"] == pytest.approx(line["value"], rel=1e-3)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["per_gpu_batch"] == 5
     assert "batch shard x2" in line["config"]["parallelism"] and "broadcast" in line["config"]["parallelism"]
     assert line["value"] > 0 and len(line["windows_ms"]) == 2

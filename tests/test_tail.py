@@ -268,3 +268,72 @@ def test_whole_model_drop_in_behind_the_genuine_graph_executor(gpu):
     code = DROPIN_MODEL % dict(tests=os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "MODEL_OK" in res.stdout, res.stdout + res.stderr
+
+
+# ------------------------------------------------------------------------------------ global_avgpool2d inside the classifier's launch
+POOL_GEMV = [dict(n=1, hw=7, c=1024, co=1000), dict(n=3, hw=3, c=64, co=10), dict(n=8, hw=8, c=48, co=7, exact=False),
+             dict(n=2, hw=5, c=2048, co=36, act=1), dict(n=1, hw=1, c=32, co=40)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(POOL_GEMV)))
+def test_pool_plus_classifier_in_one_launch_equals_the_two_launches_and_the_oracle(gpu, i, monkeypatch):
+    """csrc/conv_gemv.hip:pool_gemv_i8_kernel: global_avgpool2d and the 1x1 convolution on the pooled map
+    as ONE launch, through the C-ABI -- against the two stand-alone launches and against the oracle's pool -> conv chain.
+    (Opt-in, SHL_MI355X_POOLGEMV=1: measured slower than the two launches, profiles/r06_notes.md.)"""
+    monkeypatch.setenv("SHL_MI355X_POOLGEMV", "1")
+    fe, hip, opt = gpu
+    dev = cases.HipDevice(hip)
+    kw = dict(POOL_GEMV[i])
+    n, hw, c, co = kw.pop("n"), kw.pop("hw"), kw.pop("c"), kw.pop("co")
+    rng = np.random.default_rng(500 + i)
+    x = rng.integers(-128, 128, (n, hw, hw, c), dtype=np.int8)
+    in_q = (float(np.float32(0.02 + 0.05 * rng.random())), int(rng.integers(-20, 20)))
+    conv = cases.make_case(600 + i, n=n, h=1, w=1, c=c, co=co, k=(1, 1), pad=(0, 0, 0, 0), **kw)
+    mid_q = (float(conv["in_scale"]), int(conv["in_zp"]))
+    pooled = tail.siso_oracle(dict(kind="pool", x=x, dtype="int8", layout="NHWC", axis=1, in_q=in_q, out_q=mid_q))
+    conv["input"] = np.ascontiguousarray(pooled.reshape(conv["in_shape"]))
+    want = cases.oracle_run(conv, "ref")
+    kept = []
+    two = cases.csinn_run(fe, pkg.API_MI355X, conv, device=dev, keep_params=kept)   # the stand-alone GEMV on the oracle's pooled map
+    golden_exact = conv["exact"]
+    plan = opt.shl_mi355x_registry_get(kept[0][0])
+    assert hip.shl_mi355x_pool_conv_fusable(plan, n, hw * hw) == 1, opt.shl_mi355x_params_kernel_name(kept[0][0])
+    d_x, d_mid, d_a, d_b = dev.alloc(x.nbytes), dev.alloc(n * c), dev.alloc(n * co), dev.alloc(n * co)
+    dev.upload(d_x, x)
+    pkg.check(hip.shl_mi355x_global_avgpool2d(d_x, d_mid, pkg.SHL_I8, pkg.SHL_NHWC, n, c, hw * hw, in_q[0], in_q[1], mid_q[0], mid_q[1], None),
+              hip, "avgpool")
+    pkg.check(hip.shl_mi355x_conv_forward(plan, d_mid, d_a, n, None), hip, "conv_forward")
+    pkg.check(hip.shl_mi355x_pool_conv_forward(plan, d_x, d_b, n, hw * hw, in_q[0], in_q[1], mid_q[0], mid_q[1], None), hip, "pool_conv_forward")
+    sep = dev.download(d_a, conv["out_shape"], np.int8)
+    fused = dev.download(d_b, conv["out_shape"], np.int8)
+    assert np.array_equal(dev.download(d_mid, (n, c), np.int8).reshape(-1), pooled.reshape(-1)), "stand-alone pooling vs the oracle"
+    assert np.array_equal(fused, sep), "fused launch vs the two launches: %d differ" % int((fused != sep).sum())
+    if golden_exact:
+        assert np.array_equal(fused, want) and np.array_equal(two, want)
+    else:
+        import golden_util
+        golden_util.compare(conv, fused, want, "pool + classifier, converter scales")
+    # what does not qualify is refused, not computed: a wrong pooled record, too many pooled pixels
+    assert hip.shl_mi355x_pool_conv_forward(plan, d_x, d_b, n, hw * hw, in_q[0], in_q[1], mid_q[0], mid_q[1] + 1, None) == -3
+    assert hip.shl_mi355x_pool_conv_fusable(plan, n, 65) == 0
+    for p in (d_x, d_mid, d_a, d_b):
+        dev.free(p)
+    opt.shl_mi355x_release_params(kept[0][0])
+
+
+@pytest.mark.gpu
+def test_sessions_run_the_pooling_inside_the_classifier_launch_on_request(gpu, monkeypatch):
+    fe, hip, opt = gpu
+    plain = tail.MiniNet("int8", "NHWC")
+    assert opt.shl_mi355x_session_fused_pools(plain.build(fe, pkg.API_MI355X)) == 0   # the default: its own launch
+    plain.close(fe)
+    monkeypatch.setenv("SHL_MI355X_POOLGEMV", "1")
+    net = tail.MiniNet("int8", "NHWC")
+    sess = net.build(fe, pkg.API_MI355X)
+    assert opt.shl_mi355x_session_is_device_resident(sess) == 2
+    assert opt.shl_mi355x_session_fused_pools(sess) == 1
+    for k in range(2):
+        x, want = golden("mininet_int8_NHWC_%d" % k, "int8")
+        assert_same(net.run(fe, x), want, "int8", "mini model with the pooling fused")
+    net.close(fe)

@@ -47,7 +47,7 @@ def main():
     print(wl.layer_name(chain.entries[0]["layer"]), chain.entries[0]["kernel_name"])
     if a.patch:
         # stamps: start | items | padding | pixel offsets | stage 0 written | barrier | per stage: steps done, barrier | end
-        n = int((t[:64] != 0).sum())
+        n = int((t[:32] != 0).sum())  # (wave 0's stamps; 32 .. 63 are wave 4's: tools/dev/patch_trace2.py)
         d = np.diff(t[:n])
         names = ["tile decode", "weight loads issued", "row tables", "barrier", "staging items", "padding", "pixel offsets", "stage-0 wait+write", "barrier"]
         k = 0
