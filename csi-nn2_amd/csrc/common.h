@@ -583,6 +583,10 @@ bool stem_mfma_pick(const ConvArgs &a);  // conv_stem.hip: the matrix-core form 
 bool dwpw_stream_fusable(const ConvArgs &dw, const ConvArgs &pw, int dw_dot4_packed, int pw_is_igemm);
 bool dwpw_stream_takes(const ConvArgs &dw);  // the depthwise layer belongs to a depthwise -> pointwise launch (throughput sizes)
 int launch_dwpw_stream(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);
+// ... for the deep blocks (512 channels, stride 1): resident pointwise weights behind a depthwise stage (dwpw_resident.hip)
+bool dwpw_resident_fusable(const ConvArgs &dw, const ConvArgs &pw, int dw_dot4_packed, int pw_is_igemm);
+bool dwpw_resident_takes(const ConvArgs &dw);
+int launch_dwpw_resident(const ConvArgs &dw, const ConvArgs &pw, hipStream_t s);
 bool pwdw_f16_nchw_fusable(const ConvArgs &pw, const ConvArgs &dw);  // binary16 NCHW form (pwdw_f16_nchw.hip)
 int launch_pwdw_f16_nchw(const ConvArgs &pw, const ConvArgs &dw, hipStream_t s);
 bool stemdw_fusable(const ConvArgs &stem, const ConvArgs &dw);

@@ -998,10 +998,12 @@ static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv
                            const ConvArgs &b)
 {
     // the other order (6): `pw` is the depthwise layer and `dw` the pointwise one consuming it (dwpw_stream.hip, large batches)
-    if (pw->algo == SHL_MI355X_ALGO_DW)
-        return pw->desc.dtype == SHL_MI355X_I8 &&
-                       dwpw_stream_fusable(a, b, pw->kstride == 12, dw->algo == SHL_MI355X_ALGO_IGEMM)
-                   ? 6 : 0;
+    if (pw->algo == SHL_MI355X_ALGO_DW) {
+        if (pw->desc.dtype != SHL_MI355X_I8) return 0;
+        if (dwpw_stream_fusable(a, b, pw->kstride == 12, dw->algo == SHL_MI355X_ALGO_IGEMM)) return 6;
+        // 7: the deep blocks (512 channels): resident pointwise weights behind a depthwise stage (dwpw_resident.hip)
+        return dwpw_resident_fusable(a, b, pw->kstride == 12, dw->algo == SHL_MI355X_ALGO_IGEMM) ? 7 : 0;
+    }
     const int pw_igemm = pw->algo == SHL_MI355X_ALGO_IGEMM, dw_dot4 = dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12;
     if (pw->desc.dtype == SHL_MI355X_F16) {  // binary16 NCHW (pwdw_f16_nchw.hip, stemdw_f16_nchw.hip)
         if (dw->algo != SHL_MI355X_ALGO_DW) return 0;
@@ -1014,7 +1016,7 @@ static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv
         static const char *sel = getenv("SHL_MI355X_PWDW");  // "2": latency forms without size rules (A/B)
         // (... unless the graph's owner said that this depthwise layer has no such consumer -- MobileNetV2's dw 32 -> pw 16, two
         // consumers, a non-1x1 layer behind it: shl_mi355x_conv_plan_set_no_stream_consumer; without the hint both fusions were lost)
-        if (!(sel && sel[0] == '2') && dw_dot4 && dwpw_stream_takes(b) && !dw->no_stream_consumer) return 0;
+        if (!(sel && sel[0] == '2') && dw_dot4 && (dwpw_stream_takes(b) || dwpw_resident_takes(b)) && !dw->no_stream_consumer) return 0;
     }
     if (pw->algo == SHL_MI355X_ALGO_STEM) return dw_dot4 && stemdw_fusable(a, b) ? 3 : 0;  // stem + depthwise
     return pwdw_fusable(a, b, pw_igemm, dw_dot4) ? 1 : 0;
@@ -1100,6 +1102,7 @@ int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     if (rc != SHL_MI355X_OK) return rc;
     if (b.M == 0) return SHL_MI355X_OK;
     switch (pwdw_kernel_for(pw, dw, a, b)) {
+        case 7: return launch_dwpw_resident(a, b, (hipStream_t)stream);
         case 6: return launch_dwpw_stream(a, b, (hipStream_t)stream);
         case 5: return launch_stemdw_f16_nchw(a, b, (hipStream_t)stream);
         case 4: return launch_pwdw_f16_nchw(a, b, (hipStream_t)stream);

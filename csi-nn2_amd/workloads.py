@@ -227,8 +227,8 @@ class LayerChain:
         idx = self.units[u]
         if len(idx) == 1:
             return self.entries[idx[0]]["kernel_name"]
-        if self.entries[idx[0]]["layer"]["depthwise"]:
-            return "dwpw_stream_i8"
+        if self.entries[idx[0]]["layer"]["depthwise"]:  # depthwise -> pointwise: dwpw_stream.hip, or (512 channels) dwpw_resident.hip
+            return "dwpw_resident_i8" if self.entries[idx[0]]["layer"]["cin"] >= 512 else "dwpw_stream_i8"
         if self.dtype != "int8":
             return "pwdw_f16_nchw" if "igemm" in self.entries[idx[0]]["kernel_name"] or "1x1" in self.entries[idx[0]]["kernel_name"] else "stemdw_f16_nchw"
         return "stemdw_fused_i8" if self.entries[idx[0]]["kernel_name"].startswith("conv_stem") else "pwdw_fused_i8"
