@@ -246,3 +246,35 @@ def test_whole_mobilenet_is_identical_with_and_without_fusion(gpu):
         outs[name] = (int(lines["PAIRS"]), lines["OUT"])
     assert outs["none"][0] == 0 and outs["pwdw"][0] == 13   # 12 pointwise + the stem pair
     assert outs["none"][1] == outs["pwdw"][1]
+
+
+@pytest.mark.gpu
+def test_a_depthwise_layer_without_a_streamable_consumer_keeps_its_latency_pair(gpu):
+    """at throughput batches the latency form (pointwise -> depthwise) yields every 32 .. 256-channel depthwise layer
+    to the bandwidth form (depthwise -> pointwise) -- also when the layer's consumer is NOT a pointwise layer that form takes
+    (MobileNetV2's dw 32 -> pw 16: no instantiation for 16 output channels), and then both fusions were lost.  The owner of the
+    graph now tells the plan (shl_mi355x_conv_plan_set_no_stream_consumer; LayerChain and session.c:plan_fusion do)."""
+    import importlib
+    fe, hip, opt = gpu
+    wl = importlib.import_module("csi-nn2_amd.workloads")
+    dev = cases.HipDevice(hip)
+    layers = [wl._conv(64, 32, 28, 1, 1), wl._conv(32, 32, 28, 3, 1, dw=True), wl._conv(32, 16, 28, 1, 1)]
+    chain = wl.LayerChain(fe, hip, opt, layers, 8, dev.alloc, dev.upload, dtype="int8", layout="NHWC", seed=77, chained=True, fuse=True)
+    units = [list(u) for u in chain.units]
+    assert units == [[0, 1], [2]], units
+    opt.shl_mi355x_set_stream(None)
+    chain.run_eager()
+    import test_whole_network as twn
+    x = np.random.default_rng(77 + 1000).integers(-64, 64, chain.entries[0]["in_dims"], dtype=np.int8)
+    cur = x
+    for e in chain.entries:
+        cur = cases.oracle_run(twn.layer_case(e["layer"], dict(e["ops"], in_scale=e["in_scale"], in_zp=e["in_zp"]), "int8", "NHWC", cur), "ref")
+    got = dev.download(chain.entries[2]["d_out"], chain.entries[2]["out_dims"], np.int8)
+    n, worst = cases.mismatch_report(got, cur)
+    assert n == 0, (n, worst)
+    # with a consumer the bandwidth form takes, the depthwise layer pairs up the other way round
+    layers2 = [wl._conv(64, 32, 28, 1, 1), wl._conv(32, 32, 28, 3, 1, dw=True), wl._conv(32, 64, 28, 1, 1)]
+    chain2 = wl.LayerChain(fe, hip, opt, layers2, 8, dev.alloc, dev.upload, dtype="int8", layout="NHWC", seed=78, chained=True, fuse=True)
+    assert [list(u) for u in chain2.units] == [[0], [1, 2]], chain2.units
+    chain.release()
+    chain2.release()

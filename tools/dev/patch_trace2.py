@@ -24,5 +24,9 @@ names = ["start", "tile decoded", "weights issued", "row tables", "barrier", "st
 t0 = t[0]
 for half in (0, 1):
     s = t[half * 32: half * 32 + 32]; s = s[s != 0] - t0
-    lab = names + ["K steps done" if (k % 2 == 0) else "barrier/skip" for k in range(len(s) - len(names) - 1)] + ["epilogue done"]
+    n_rest = len(s) - len(names)
+    if n_rest == 6:   # pair mode: [K steps | barrier | epilogue] of tile 0, then of tile 1
+        lab = names + ["tile 0 K steps done", "barrier", "tile 0 epilogue done", "tile 1 K steps done", "(no barrier)", "tile 1 epilogue done"]
+    else:
+        lab = names + ["K steps done" if (k % 2 == 0) else "barrier/skip" for k in range(n_rest - 1)] + ["epilogue done"]
     print("half %d (wave %d):" % (half, 4 * half) + "".join("\n   %-18s @ %7d" % (lab[i] if i < len(lab) else "?", s[i]) for i in range(len(s))))
