@@ -356,6 +356,38 @@ def measure_config(tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, cha
              "mfma_frac_whole_set": ops_total / world / t_pass / 1e12 / peak}
     if how:
         entry["parallelism"] = "batch shard x%d, %d images per GPU (weights broadcast once: %s)" % (world, batch_x, how)
+    if not chained_x and dist is None and dtype_x == "int8" and not PROFILER:
+        # what the launch boundaries of the pass cost (informational; `ms_per_pass` above is the figure of merit): the set's
+        # layers do not depend on each other, so the even and the odd ones can run as two captured graphs on two streams --
+        # a kernel's ramp and drain then overlap the neighbour's.  A network whose layers DO depend on each other has no such
+        # second graph (tools/dev/two_stream.py --interleave; profiles/r06_notes.md)
+        try:
+            hb2 = CHbm(hip)
+            pairs = []
+            for k, sub in enumerate((layers_x[0::2], layers_x[1::2])):
+                ck = wl.LayerChain(fe, hip, opt, sub, batch_x, hb2.alloc, hb2.upload, dtype=dtype_x, layout=layout_x, seed=seed + 50 * (k + 1),
+                                   chained=False, fuse=False)
+                sk = hip.shl_mi355x_stream_create()
+                ck.capture(sk)
+                pairs.append((ck, sk))
+
+            def replay2():
+                for ck, _ in pairs:
+                    ck.replay()
+
+            def sync2():
+                for _, sk in pairs:
+                    hip.shl_mi355x_stream_sync(sk)
+            w2 = timed_windows(replay2, sync2, steps, warmup, windows)
+            entry["two_streams"] = {"ms_per_pass": float(np.median(w2)) / steps * 1e3,
+                                    "note": "even / odd layers of the set as two graphs on two streams (the layers are independent): "
+                                            "launch ramp / drain / boundary overlapped; not the figure of merit"}
+            for ck, sk in pairs:
+                ck.release()
+                hip.shl_mi355x_stream_destroy(sk)
+            hb2.free_all()
+        except Exception as e:  # informational only
+            entry["two_streams"] = {"error": repr(e)}
     if env["rank"] == 0:
         rt = time_groups(rc, hip, opt, stream, reps=20)
         rroof, rgroups = summarise_kernels(rc, wl, rt, bound_x)
@@ -439,6 +471,8 @@ def compact_line(result):
                           "traffic": _r(r.get("traffic"), 4)}}
         if e.get("n_gpus", 1) > 1:
             c["n_gpus"] = e["n_gpus"]
+        if "ms_per_pass" in e.get("two_streams", {}):  # (informational: the set's independent layers on two streams)
+            c["two_streams_ms"] = _r(e["two_streams"]["ms_per_pass"], 4)
         cl.append(c)
     if cl:
         out["configs"] = cl

@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--parts", type=int, default=2)
     ap.add_argument("--set", default="mobilenet", choices=["mobilenet", "resnet"])
     ap.add_argument("--layout", default="NHWC")
+    ap.add_argument("--interleave", action="store_true",
+                    help="resnet set: the even and the odd LAYERS at full batch on two streams (the set's layers are independent: how much of "
+                         "the pass is launch boundary -- something a dependent network cannot hide this way)")
     a = ap.parse_args()
     import cases
     pkg = cases.pkg
@@ -57,6 +60,18 @@ def main():
             best.append((time.perf_counter() - t0) / reps)
         return sorted(best)[2]
 
+    if a.interleave:
+        def build_layers(layers, seed):
+            c = wl.LayerChain(fe, hip, opt, layers, a.batch, dev.alloc, dev.upload, dtype="int8", layout=a.layout, chained=False, fuse=False, seed=seed)
+            s = hip.shl_mi355x_stream_create()
+            c.capture(s)
+            return (c, s)
+        L = wl.RESNET50_3X3
+        t1 = timed([build_layers(L, 1234)])
+        print("16 layers, one stream:                 %8.1f us" % (t1 * 1e6), flush=True)
+        t2 = timed([build_layers(L[0::2], 1234), build_layers(L[1::2], 2234)])
+        print("even / odd layers on two streams:      %8.1f us" % (t2 * 1e6), flush=True)
+        return
     one = build(a.batch, 1)
     t1 = timed(one)
     print("one chain of batch %d:            %8.1f us per %d images" % (a.batch, t1 * 1e6, a.batch), flush=True)
