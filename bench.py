@@ -388,6 +388,35 @@ def measure_config(tag, name, layers_x, batch_x, dtype_x, layout_x, bound_x, cha
             hb2.free_all()
         except Exception as e:  # informational only
             entry["two_streams"] = {"error": repr(e)}
+    if chained_x and dist is None and dtype_x == "int8" and batch_x >= 64 and batch_x % 2 == 0 and not PROFILER:
+        # the same question for a DEPENDENT network at a throughput batch: the batch as two half-batch chains on two streams (each
+        # chain's launches fill the other's boundaries; tools/dev/two_stream.py).  Informational: csinn_session_run captures ONE chain
+        try:
+            hb2 = CHbm(hip)
+            pairs = []
+            for k in range(2):
+                ck = wl.LayerChain(fe, hip, opt, layers_x, batch_x // 2, hb2.alloc, hb2.upload, dtype=dtype_x, layout=layout_x, seed=seed + k,
+                                   chained=True, fuse=fuse)
+                sk = hip.shl_mi355x_stream_create()
+                ck.capture(sk)
+                pairs.append((ck, sk))
+
+            def replay2():
+                for ck, _ in pairs:
+                    ck.replay()
+
+            def sync2():
+                for _, sk in pairs:
+                    hip.shl_mi355x_stream_sync(sk)
+            w2 = timed_windows(replay2, sync2, steps, warmup, windows)
+            entry["two_streams"] = {"ms_per_pass": float(np.median(w2)) / steps * 1e3,
+                                    "note": "the batch as two half-batch chains on two streams (per %d images); not the figure of merit" % batch_x}
+            for ck, sk in pairs:
+                ck.release()
+                hip.shl_mi355x_stream_destroy(sk)
+            hb2.free_all()
+        except Exception as e:
+            entry["two_streams"] = {"error": repr(e)}
     if env["rank"] == 0:
         rt = time_groups(rc, hip, opt, stream, reps=20)
         rroof, rgroups = summarise_kernels(rc, wl, rt, bound_x)
@@ -693,7 +722,7 @@ def main():
                                % (args.workload, args.dtype, layout, len(layers), len(chain.units),
                                   " (pointwise+depthwise pairs fused as csinn_session_setup does)" if len(chain.units) < len(layers) else "",
                                   batch, " (total batch %d sharded)" % args.total_batch if sharded else ""),
-                   "workload_short": "%s %s %s batch %d/GPU%s, %d conv layers in %d launches, hipGraph replay via csinn_* C API" % (
+                   "workload_short": "%s %s %s batch %d/GPU%s, %d conv layers in %d launches, hipGraph replay via csinn_*" % (
                        args.workload, args.dtype, layout, batch, " (total %d sharded)" % args.total_batch if sharded else "",
                        len(layers), len(chain.units)),
                    "parallelism_short": ("batch shard x%d" % world if sharded else "replicas x%d" % world),

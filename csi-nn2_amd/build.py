@@ -64,6 +64,45 @@ def spilled_kernels(usage_file):
 PATCH_SOURCES = ("conv_igemm_patch.hip", "conv_igemm_patch_nchw.hip", "conv_igemm_patch_f16.hip", "conv_igemm_patch_nchw_f16.hip")
 
 
+def _patch_template_args(mangled):
+    """(kF16, EPI, kNchw, kPair, kS2, KC, PG, OB, KP, NW, NBT) of a conv_igemm_patch_kernel instantiation, parsed from the
+    DEMANGLED name (VERDICT r05 weak #9: the whitelist below used to match substrings of the mangled one)"""
+    try:
+        dem = subprocess.run(["c++filt", mangled], capture_output=True, text=True, check=True).stdout.strip()
+    except Exception:
+        return None
+    m = re.search(r"conv_igemm_patch_kernel<([^>]*)>", dem)
+    if not m:
+        return None
+    vals = []
+    for tok in m.group(1).split(","):
+        tok = tok.strip()
+        vals.append(1 if tok == "true" else 0 if tok == "false" else int(re.sub(r"[^0-9-]", "", tok) or 0))
+    if len(vals) == 10:
+        vals.append(13)  # NBT defaults to PT_NB in older manglings
+    keys = ("f16", "epi", "nchw", "pair", "s2", "kc", "pg", "ob", "kp", "nw", "nbt")
+    return dict(zip(keys, vals)) if len(vals) == 11 else None
+
+
+def patch_scratch_allowance(t):
+    """bytes of scratch a given eight-wave row-patch instantiation is known to carry and was MEASURED with"""
+    if t["nw"] != 8:
+        return None  # four-wave instantiations: a fallback and a test switch, not checked
+    # NCHW, two K parts of 128-byte stages (256 -> 256 @14 before the 7-block tiles): 12 bytes since round 4, 21 - 23 us with them
+    if not t["f16"] and t["nchw"] and not t["pair"] and not t["s2"] and (t["kc"], t["pg"], t["ob"], t["kp"]) == (128, 1, 2, 2):
+        return 12
+    # the stride-2 NCHW form (round 5: a stride-1 layer on the half-resolution grid): three more scalars than its stride-1 twin
+    # at 253 of 256 registers -- 14 spilled registers, 60 bytes; 128 -> 128 @56 stride 2 at batch 128 34.1 - 35.2 -> 30.7 - 31.0 us WITH them
+    if t["nchw"] and t["s2"] and t["kc"] == 128:
+        return 64
+    # binary16 NHWC, 64-byte stages, one K part (round 5: the sixteen-value epilogue keeps both activation bounds in registers):
+    # two spilled registers, measured with them
+    if t["f16"] and not t["nchw"] and not t["pair"] and not t["s2"] and t["kc"] == 64 and t["kp"] == 1 and t["nbt"] == 13 and \
+            (t["pg"], t["ob"]) in ((1, 4), (2, 2)):
+        return 8
+    return 0
+
+
 def patch_kernels_with_scratch(usage_file):
     bad, name = [], "?"
     with open(usage_file) as f:
@@ -72,22 +111,15 @@ def patch_kernels_with_scratch(usage_file):
                 name = ln.split("Function Name:")[1].split("[")[0].strip()
             elif "ScratchSize [bytes/lane]:" in ln:
                 n = int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0].strip() or 0)
-                # mangled template arguments end in ...ELi<NW>E[Lb<kBuild>E]EEvNS_8ConvArgsE
-                # (known and measured harmless since round 4: 12 bytes in the NCHW instantiation with two K parts of 128-byte
-                # stages -- 256 -> 256 @14, 21 - 23 us with it; it does not read the memo)
-                known = "ILb0ELi3ELb1ELb0ELb0ELi128ELi1ELi2ELi2ELi8E" in name or "ILb0ELi0ELb1ELb0ELb0ELi128ELi1ELi2ELi2ELi8E" in name
-                # the stride-2 NCHW instantiations (round 5: a stride-1 layer on the half-resolution grid) carry three more
-                # scalars than their stride-1 twins at 253 of 256 registers: 14 spilled registers, 60 bytes -- measured WITH
-                # them: 128 -> 128 @56 stride 2 at batch 128 34.1 - 35.2 -> 30.7 - 31.0 us (profiles/r05_notes.md)
-                if "ELb1ELb0ELb1ELi128E" in name and n <= 64:
+                if n == 0 or "conv_igemm_patch_kernel" not in name:
                     continue
-                # binary16 NHWC, 64-byte stages, one K part (round 5: the sixteen-value epilogue needs the two activation bounds in
-                # registers -- v_med3_f32 takes one scalar operand): two spilled registers in the epilogue, measured with them
-                if ("ILb1ELi0ELb0ELb0ELb0ELi64ELi1ELi4ELi1ELi8ELi13E" in name or "ILb1ELi0ELb0ELb0ELb0ELi64ELi2ELi2ELi1ELi8ELi13E" in name) and n <= 8:
+                t = _patch_template_args(name)
+                if t is None:
+                    bad.append("%s (%d bytes; template arguments not recognised)" % (name, n))
                     continue
-                # (... ELi<NW>ELi<NBT>EEEv: eight waves, 13 / 7 / 4 pixel blocks per role)
-                if n > (12 if known else 0) and "conv_igemm_patch_kernel" in name and re.search(r"ELi8ELi\d+EEEvNS_8ConvArgsE", name):
-                    bad.append("%s (%d bytes)" % (name, n))
+                allow = patch_scratch_allowance(t)
+                if allow is not None and n > allow:
+                    bad.append("%s (%d bytes, allowed %d)" % (name, n, allow))
     return bad
 
 
