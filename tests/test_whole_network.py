@@ -278,3 +278,22 @@ def test_mobilenetv1_int8_session_at_batch_8_fuses_depthwise_pointwise_blocks(gp
     n, worst = cases.mismatch_report(got, want)
     assert n == 0, "softmax output: %d mismatches (max %d)" % (n, worst)
     ms.close()
+
+
+@pytest.mark.gpu
+def test_mobilenetv1_int8_session_at_batch_128_equals_the_oracle_model_on_sampled_images(gpu):
+    """csinn_session_run at the throughput batch bench.py's batch-128 view stands for: plan_fusion pairs the 32 .. 256-channel
+    blocks (dwpw_stream.hip) AND the five 512-channel blocks (dwpw_resident.hip, round 6) as depthwise -> pointwise launches;
+    the probabilities of images 0, 63 and 127 equal the oracle's replay of the whole model bit for bit."""
+    fe, hip, opt, dev = gpu
+    ms = wl.ModelSession(fe, pkg.API_MI355X, "int8", "NHWC", batch=128)
+    assert opt.shl_mi355x_session_is_device_resident(ms.sess) == 2
+    fused = opt.shl_mi355x_session_fused_pairs(ms.sess)
+    assert fused >= 10, "only %d fused pairs in a batch-128 session" % fused
+    x = ms.synthetic_input(5)
+    got = ms.run(x).reshape(128, -1)
+    pick = [0, 63, 127]
+    want = oracle_whole_model(ms, np.ascontiguousarray(x[pick]), "int8", "NHWC").reshape(3, -1)
+    n, worst = cases.mismatch_report(got[pick], want)
+    assert n == 0, "softmax output of images %s: %d mismatches (max %d)" % (pick, n, worst)
+    ms.close()
