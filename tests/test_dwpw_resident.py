@@ -91,3 +91,20 @@ def test_small_batches_keep_two_launches(gpu):
     names = [chain.unit_kernel_name(u) for u in range(len(chain.units))]
     assert not any("dwpw_resident" in n for n in names), names
     chain.release()
+
+
+@pytest.mark.gpu
+def test_seeded_random_pairs(gpu, monkeypatch):
+    """a sweep over the shapes the form takes: even maps of 4 .. 16 pixels, 256 / 512 / 1024 output channels, relu on or off,
+    ragged tile ranges (tile counts that do not divide by the workgroup count)"""
+    rng = np.random.default_rng(20260930)
+    for k in range(10):
+        hw = int(rng.choice([4, 6, 8, 10, 12, 14, 16]))
+        cout = int(rng.choice([256, 512, 1024]))
+        need = 24 * 2 // hw + 1                          # at least 24 tiles of two rows
+        batch = need + int(rng.integers(0, 5))
+        act = int(rng.integers(0, 2))
+        got, want, units, names = run_pair(gpu, batch, hw, cout, 4400 + k, act=act, monkeypatch=monkeypatch)
+        assert units == [[0, 1]] and "dwpw_resident" in names[0], (hw, cout, batch, units, names)
+        n, worst = cases.mismatch_report(got, want)
+        assert n == 0, "hw %d cout %d batch %d act %d: %d mismatches (max %d)" % (hw, cout, batch, act, n, worst)
