@@ -5,8 +5,8 @@
 // read back: 118 of the 450 us of the batch-128 pass (VERDICT r05 next #4 a).
 //
 // = conv1x1_resident.hip with a depthwise stage in front of its pixel stream:
-//   workgroup  PERSISTENT, one per CU: 256 output channels (8 waves x 32; a wave's 32 x 512 weight slice in 64 registers,
-//              loaded once per launch) x a contiguous range of pixel TILES; a tile = two whole rows of the map
+//   workgroup  PERSISTENT, one per CU: 256 NOG output channels (8 waves x NOG groups of 32; a wave's NOG slices of 32 x 512 weights in
+//              64 NOG registers, loaded once per launch; NOG = 2 where Cout is a multiple of 512) x a contiguous range of pixel TILES; a tile = two whole rows of the map
 //              (2 W <= 32 pixels: W = 14 -> 28 of a block's 32 pixel columns)
 //   input      the depthwise layer's input rows stream through a RING of eight row slots in LDS (W x 512 bytes each) by
 //              global_load_lds_dwordx4, every row of the tensor once per workgroup range (a tile needs rows 2 T - 1 .. 2 T + 2:
@@ -25,9 +25,11 @@
 //              ds_read_b128 per group and tile: the LDS pipe was the bound, 25.5 us = no faster than the two launches).  The four
 //              lanes of a quad then transpose their 4 x 4 bytes (two DPP moves + two v_perm_b32 per dword) and every lane
 //              writes dwords of four consecutive channels of one pixel: into the stage (depthwise) or to HBM (pointwise)
-// Where it stands (batch 128, 512 -> 512 @14): 23.3 us against 11.5 + 14.0 us for the two launches -- the launch is bound by VALU
-// issue (~640 instructions per wave and tile: three requantisations, the quad transpositions, tap addressing), not by the
-// 25.7 MB of intermediate tensor it no longer moves; profiles/r06_notes.md has the two versions and their instruction counts.
+// Where it stands (batch 128, 512 -> 512 @14): 21.2 us (workgroups of 512 output channels, NOG = 2; 23.3 us with workgroups of 256,
+// whose pairs both compute the depthwise tile) against 11.5 + 14.0 us for the two launches -- the launch is bound by VALU issue
+// (three / four requantisations per wave and tile, the quad transpositions, tap addressing, fragment rebuild; 63 % of its cycles
+// by the counters), not by the 25.7 MB of intermediate tensor it no longer moves; 896 tiles on 256 workgroups are 3 or 4 each.
+// profiles/r06_notes.md has the versions and their instruction counts.
 // The intermediate tensor is bit-identical to what the stand-alone depthwise kernel writes, so the pair is bit-identical to the
 // two launches and to the oracle chain (tests/test_dwpw_resident.py).  Both layers keep their own plans.
 // Restates shl_ref_depthwise_conv2d_quant followed by shl_ref_conv2d_quant (source/reference/convolution.c:416-460, 370-400)
@@ -66,7 +68,10 @@ constexpr int DR_RING = 8;          // row slots
 constexpr int DR_STAGE_B = 32 * DR_KB;
 
 // EPI_D / EPI_Q: common.h epilogue flavours of the depthwise / the pointwise layer (0 / 3: division flavour, activation as a clamp)
-template <int EPI_D, int EPI_Q>
+// NOG: groups of 32 output channels per wave.  1: a workgroup owns 256 output channels and the two workgroups of a pixel range
+// (Cout = 512) both compute the whole depthwise tile.  2: a workgroup owns 512 -- the depthwise tile is computed once per pixel
+// range, a wave holds 128 registers of pointwise weights and rebuilds ALL its diagonal fragments per tile.
+template <int EPI_D, int EPI_Q, int NOG>
 __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs q, int ncb, int ranges, int ntiles)
 {
     constexpr int KB = DR_KB;
@@ -110,30 +115,42 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
         for (int i = tid; i < KB / 4; i += 512) reinterpret_cast<uint32_t *>(padpx)[i] = zp4;
     }
     // ---- this wave's pointwise weights: 32 channels x 512, fragment order (conv_plan.hip: [32-channel group][K / 32][lane][16 B])
-    const int ch0 = cb * 256 + wave * 32;
-    const char *wp = static_cast<const char *>(q.w_frag) + ((int64_t)(ch0 >> 5) * NSUB) * 1024 + lane * 16;
-    v4i fw[NSUB];
+    // (output group og of wave w: channels cb 256 NOG + (w + 8 og) 32 ..)
+    const int ch0 = cb * 256 * NOG + wave * 32;
+    v4i fw[NOG][NSUB];
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) fw[s] = *reinterpret_cast<const v4i *>(wp + s * 1024);
+    for (int og = 0; og < NOG; ++og) {
+        const char *wp = static_cast<const char *>(q.w_frag) + ((int64_t)((ch0 >> 5) + 8 * og) * NSUB) * 1024 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) fw[og][s] = *reinterpret_cast<const v4i *>(wp + s * 1024);
+    }
     // ---- this wave's depthwise groups g = wave, wave + 8: nine diagonal fragments each (dw_mfma.h)
     // (256 registers: 64 of pointwise weights + 72 of these.  The last two filter rows of the second group are rebuilt per tile from
     // their six shifted weight bytes -- 6 registers instead of 24; with all eighteen resident three fragments lived in scratch,
     // and a scratch reload is a vector memory instruction the counted waits of the tile loop do not know)
-    v4i fa[2][9];
-    uint32_t wb2[6];  // group 1, taps 3 .. 8: the lane's weight byte at its place in the dword (0 on the lanes off the diagonal)
+    constexpr int NFA = NOG == 1 ? 9 : 1;       // resident fragments of group 0 (NOG = 2: none, `fa` is a placeholder)
+    constexpr int RB0 = NOG == 1 ? 9 : 0;       // first tap of group 0 that is rebuilt per tile
+    constexpr int RB1 = NOG == 1 ? 3 : 0;       // ... of group 1
+    v4i fa[2][NOG == 1 ? 9 : 1];
+    uint32_t wb[2][NOG == 1 ? 9 : 3];  // NOG = 1: the lane's weight byte of tap t at its place in the dword (0 off the diagonal);
+                                       // NOG = 2: the three dot4-packed weight words themselves (registers), shifted per use
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
         const int g = wave + 8 * gi;
         const uint32_t *wq = reinterpret_cast<const uint32_t *>(static_cast<const char *>(d.w) + (int64_t)(g * 32 + row) * 12);
         const uint32_t wd[3] = {wq[0], wq[1], wq[2]};  // taps 0-3 | 4-7 | 8
-        dw_diag_fragments(wd, row, half, fa[gi]);
-        if (gi == 1) {
-            const bool active = (row >> 4) == half;
-            const int sh = 8 * (row & 3);
+        if constexpr (NOG == 1) dw_diag_fragments(wd, row, half, fa[gi]);
+        const bool active = (row >> 4) == half;
+        const int sh = 8 * (row & 3);
+        if constexpr (NOG == 1) {
 #pragma unroll
-            for (int t = 3; t < 9; ++t) wb2[t - 3] = active ? (__builtin_amdgcn_ubfe(wd[t >> 2], 8 * (t & 3), 8) << sh) : 0u;
+            for (int t = 0; t < 9; ++t) wb[gi][t] = active ? (__builtin_amdgcn_ubfe(wd[t >> 2], 8 * (t & 3), 8) << sh) : 0u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wb[gi][k] = active ? wd[k] : 0u;  // (lanes off the diagonal: zero weights)
         }
     }
+    const int wsh = 8 * (row & 3);
     const int mydw = (row & 15) >> 2;  // which dword of a diagonal fragment is the lane's
     // ---- per-channel tables: lane = channel `row` of the group (both halves of the wave hold the same channel, different pixels)
     int d_ai[2];
@@ -143,8 +160,13 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
         const int c = (wave + 8 * gi) * 32 + row;
         d_ai[gi] = d.acc_init[c], d_mu[gi] = d.mult[c], d_bi[gi] = d.bias[c];
     }
-    const int q_ai = q.acc_init[ch0 + row];
-    const float q_mu = q.mult[ch0 + row], q_bi = q.bias[ch0 + row];
+    int q_ai[NOG];
+    float q_mu[NOG], q_bi[NOG];
+#pragma unroll
+    for (int og = 0; og < NOG; ++og) {
+        const int c = ch0 + 256 * og + row;
+        q_ai[og] = q.acc_init[c], q_mu[og] = q.mult[c], q_bi[og] = q.bias[c];
+    }
     // 4 x 4 byte transposition inside a quad of lanes (channels 4 m .. 4 m + 3 x the four pixels of a packed dword): lane j of
     // the quad ends up with the four channels of pixel j.  Round 1 exchanges bytes with lane ^ 1, round 2 halves with lane ^ 2.
     const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
@@ -193,7 +215,15 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
             v16i acc;
             {
                 // the nine taps in three batches of three (one filter row each), two batches in flight: 24 registers instead of 36
-                v4i fb[2][3];
+                v4i fb[NOG == 1 ? 2 : 1][3];
+                // tap t's diagonal fragment of group gi: resident, or rebuilt from the lane's shifted weight byte (gi, t: compile time)
+                auto frag = [&](int g2, int t) -> v4i {
+                    if ((g2 == 0 && t < RB0) || (g2 == 1 && t < RB1)) return fa[g2][t < NFA ? t : 0];
+                    int wv;
+                    if constexpr (NOG == 1) wv = (int)opaque_u32(wb[g2][t]);
+                    else wv = (int)(__builtin_amdgcn_ubfe(opaque_u32(wb[g2][t >> 2]), 8 * (t & 3), 8) << wsh);
+                    return v4i{mydw == 0 ? wv : 0, mydw == 1 ? wv : 0, mydw == 2 ? wv : 0, mydw == 3 ? wv : 0};
+                };
                 auto request = [&](int ky, v4i (&dst)[3]) {
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
@@ -202,33 +232,32 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
                     }
                 };
                 const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (NOG == 2) {
+                    // (one filter row in flight: the second set of three fragments would not fit beside 128 registers of weights)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        request(ky, fb[0]);
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])::"memory");
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, 3 * ky + kx), ky + kx == 0 ? zero16 : acc, 0, 0, 0);
+                        asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(acc));
+                    }
+                } else {
                 request(0, fb[0]);
                 request(1, fb[1]);
                 // rows = pixels: D[pixel][channel] -- lane (channel `row`, half) holds pixels 8 e + 4 half + i as acc[4 e + i]
                 asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])::"memory");
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], fa[gi][kx], kx == 0 ? zero16 : acc, 0, 0, 0);
+                for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, kx), kx == 0 ? zero16 : acc, 0, 0, 0);
                 asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(acc));  // (the MFMAs above have read fb[0] before it is requested into again)
                 request(2, fb[0]);
                 asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2])::"memory");
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    v4i f3 = fa[gi][3 + kx];
-                    if (gi == 1) {  // (compile time: gi is unrolled)
-                        const int wv = (int)opaque_u32(wb2[kx]);
-                        f3 = v4i{mydw == 0 ? wv : 0, mydw == 1 ? wv : 0, mydw == 2 ? wv : 0, mydw == 3 ? wv : 0};
-                    }
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[1][kx], f3, acc, 0, 0, 0);
-                }
+                for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[1][kx], frag(gi, 3 + kx), acc, 0, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])::"memory");
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    v4i f6 = fa[gi][6 + kx];
-                    if (gi == 1) {  // (compile time: gi is unrolled)
-                        const int wv = (int)opaque_u32(wb2[3 + kx]);
-                        f6 = v4i{mydw == 0 ? wv : 0, mydw == 1 ? wv : 0, mydw == 2 ? wv : 0, mydw == 3 ? wv : 0};
-                    }
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], f6, acc, 0, 0, 0);
+                for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, 6 + kx), acc, 0, 0, 0);
                 }
             }
             const float4 m4 = make_float4(d_mu[gi], d_mu[gi], d_mu[gi], d_mu[gi]), b4 = make_float4(d_bi[gi], d_bi[gi], d_bi[gi], d_bi[gi]);
@@ -257,7 +286,8 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
         // at most the two row requests and the four stores of the previous iteration stay in flight: the rows of tile T + 1
         // (requested two iterations ago) and every older store have landed.  (Every iteration issues exactly 2 + 4 -- a wave
         // without row pieces 0 + 4 -- vector memory instructions: the stores are unconditional, see below.)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (NOG == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // (2 + 4 NOG)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage T complete; stage T - 1 free; rows of tile T + 1 visible
         __builtin_amdgcn_sched_barrier(0);
@@ -269,35 +299,47 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
         }
         // ---- pointwise layer on stage T
         const uint32_t stq = lds0 + (uint32_t)((stage - smem) + (T & 1) * DR_STAGE_B + row * KB);
-        v16i acc[2];
-        {
-            const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            // the stage's 16 fragments in two halves of eight (registers: the weights and the diagonal fragments take 136)
-            static_for<2>([&](auto hc) {
-                constexpr int h8 = decltype(hc)::value * 8;
-                v4i fb[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) dr_read(fb[u], stq + (uint32_t)((((2 * (h8 + u) + half) ^ aswz) & 31) << 4));
-                dr_landed(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], fb[7]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int uu = h8 + u;  // rows = pixels (A = the stage's fragment, B = the weights): lane = output channel
-                    acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[u], fw[uu], uu < 2 ? zero16 : acc[u & 1], 0, 0, 0);
-                }
-            });
-        }
-        const float4 m4 = make_float4(q_mu, q_mu, q_mu, q_mu), b4 = make_float4(q_bi, q_bi, q_bi, q_bi);
         const int64_t p0 = (int64_t)T * 2 * W;  // the tile's pixels are 2 W consecutive pixels of the tensor
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t pk = requant4_i8_t<EPI_Q>(acc[0][4 * e] + acc[1][4 * e] + q_ai, acc[0][4 * e + 1] + acc[1][4 * e + 1] + q_ai,
-                                                     acc[0][4 * e + 2] + acc[1][4 * e + 2] + q_ai, acc[0][4 * e + 3] + acc[1][4 * e + 3] + q_ai, m4, b4, q);
-            const uint32_t v = quad_transpose(pk);  // output channels ch0 + 4 qm .. + 3 of pixel P
-            // pixel columns past the tile (2 W .. 31) hold copies of pixel 2 W - 1 (phase A computes that pixel again for them):
-            // they store the same bytes to the same place -- no lane is masked, so the store instruction is never skipped
-            // and the counted wait above can rely on four stores per iteration
-            const int P = min(8 * e + 4 * half + qj, 2 * W - 1);
-            *reinterpret_cast<uint32_t *>(outp + (p0 + P) * q.Co) = v;
+        for (int og = 0; og < NOG; ++og) {
+            v16i acc[NOG == 1 ? 2 : 1];
+            {
+                const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                // the stage's 16 fragments in two halves of eight (registers: the weights take 64 NOG; NOG = 2 reads the stage twice)
+                constexpr int BS = NOG == 1 ? 8 : 4;  // fragments per batch (NOG = 2: 128 registers of weights leave room for four)
+                static_for<NSUB / BS>([&](auto hc) {
+                    constexpr int h8 = decltype(hc)::value * BS;
+                    v4i fb[BS];
+#pragma unroll
+                    for (int u = 0; u < BS; ++u) dr_read(fb[u], stq + (uint32_t)((((2 * (h8 + u) + half) ^ aswz) & 31) << 4));
+                    if constexpr (BS == 8) dr_landed(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], fb[7]);
+                    else dr_landed(fb[0], fb[1], fb[2], fb[3]);
+#pragma unroll
+                    for (int u = 0; u < BS; ++u) {
+                        const int uu = h8 + u;  // rows = pixels (A = the stage's fragment, B = the weights): lane = output channel
+                        // (NOG = 1: two chains over the even / odd sub-steps; NOG = 2: one -- 16 registers, and the launch is bound by VALU issue)
+                        constexpr int NCHAIN = NOG == 1 ? 2 : 1;
+                        acc[u % NCHAIN] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[u], fw[og][uu], uu < NCHAIN ? zero16 : acc[u % NCHAIN], 0, 0, 0);
+                    }
+                });
+            }
+            const float4 m4 = make_float4(q_mu[og], q_mu[og], q_mu[og], q_mu[og]), b4 = make_float4(q_bi[og], q_bi[og], q_bi[og], q_bi[og]);
+            const int qa = q_ai[og];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t pk;
+                if constexpr (NOG == 1)
+                    pk = requant4_i8_t<EPI_Q>(acc[0][4 * e] + acc[1][4 * e] + qa, acc[0][4 * e + 1] + acc[1][4 * e + 1] + qa,
+                                              acc[0][4 * e + 2] + acc[1][4 * e + 2] + qa, acc[0][4 * e + 3] + acc[1][4 * e + 3] + qa, m4, b4, q);
+                else
+                    pk = requant4_i8_t<EPI_Q>(acc[0][4 * e] + qa, acc[0][4 * e + 1] + qa, acc[0][4 * e + 2] + qa, acc[0][4 * e + 3] + qa, m4, b4, q);
+                const uint32_t v = quad_transpose(pk);  // output channels ch0 + 256 og + 4 qm .. + 3 of pixel P
+                // pixel columns past the tile (2 W .. 31) hold copies of pixel 2 W - 1 (phase A computes that pixel again for them):
+                // they store the same bytes to the same place -- no lane is masked, so the store instruction is never skipped
+                // and the counted wait above can rely on 4 NOG stores per iteration
+                const int P = min(8 * e + 4 * half + qj, 2 * W - 1);
+                *reinterpret_cast<uint32_t *>(outp + 256 * og + (p0 + P) * q.Co) = v;
+            }
         }
     }
 }
@@ -307,9 +349,17 @@ static bool dr_clamp_epilogue(const ConvArgs &a)
     return (a.act == SHL_MI355X_ACT_NONE || a.act_clamp) && (a.div_exact || a.div_fma);
 }
 
+// output groups per wave: 2 (workgroups of 512 output channels: the depthwise tile once per pixel range) where Cout allows it
+static int dr_nog(const ConvArgs &q)
+{
+    static const char *env = getenv("SHL_MI355X_DWPW_RES_NOG");  // "1": workgroups of 256 output channels (A/B, tests)
+    if (env && env[0] == '1') return 1;
+    return (q.Co % 512) == 0 ? 2 : 1;
+}
+
 static bool dr_geom(const ConvArgs &d, const ConvArgs &q, int *ncb, int *ranges, int *ntiles, int *grid, size_t *lds)
 {
-    const int nb = q.Co / 256;
+    const int nb = q.Co / (256 * dr_nog(q));
     if (nb < 1 || nb > 32 || 32 % nb != 0) return false;
     const int64_t tiles = (int64_t)d.N * d.H / 2;
     int r = 256 / nb;
@@ -353,11 +403,16 @@ int launch_dwpw_resident(const ConvArgs &d, const ConvArgs &q, hipStream_t s)
         set_error("dwpw_resident: the pair does not fit");
         return SHL_MI355X_ENOTSUP;
     }
-#define SHL_DR(ED, EQ)                                                                                                  \
+#define SHL_DR2(ED, EQ, NG)                                                                                             \
     do {                                                                                                                \
         static LdsOptIn opted;                                                                                          \
-        lds_opt_in(opted, reinterpret_cast<const void *>(dwpw_resident_kernel<ED, EQ>));                               \
-        hipLaunchKernelGGL((dwpw_resident_kernel<ED, EQ>), dim3((unsigned)grid), dim3(512), lds, s, d, q, ncb, ranges, ntiles); \
+        lds_opt_in(opted, reinterpret_cast<const void *>(dwpw_resident_kernel<ED, EQ, NG>));                           \
+        hipLaunchKernelGGL((dwpw_resident_kernel<ED, EQ, NG>), dim3((unsigned)grid), dim3(512), lds, s, d, q, ncb, ranges, ntiles); \
+    } while (0)
+#define SHL_DR(ED, EQ)                  \
+    do {                                \
+        if (dr_nog(q) == 2) SHL_DR2(ED, EQ, 2); \
+        else SHL_DR2(ED, EQ, 1);        \
     } while (0)
     if (d.div_exact) {
         if (q.div_exact) SHL_DR(3, 3);
@@ -366,6 +421,7 @@ int launch_dwpw_resident(const ConvArgs &d, const ConvArgs &q, hipStream_t s)
         if (q.div_exact) SHL_DR(0, 3);
         else SHL_DR(0, 0);
     }
+#undef SHL_DR2
 #undef SHL_DR
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
