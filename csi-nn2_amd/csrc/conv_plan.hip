@@ -1000,9 +1000,11 @@ static int pwdw_kernel_for(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv
     // the other order (6): `pw` is the depthwise layer and `dw` the pointwise one consuming it (dwpw_stream.hip, large batches)
     if (pw->algo == SHL_MI355X_ALGO_DW) {
         if (pw->desc.dtype != SHL_MI355X_I8) return 0;
-        if (dwpw_stream_fusable(a, b, pw->kstride == 12, dw->algo == SHL_MI355X_ALGO_IGEMM)) return 6;
-        // 7: the deep blocks (512 channels): resident pointwise weights behind a depthwise stage (dwpw_resident.hip)
-        return dwpw_resident_fusable(a, b, pw->kstride == 12, dw->algo == SHL_MI355X_ALGO_IGEMM) ? 7 : 0;
+        // 7: the deep blocks (512 channels; 256 @28) at throughput batches: resident pointwise weights behind a depthwise stage
+        // (dwpw_resident.hip) -- asked first: where its rule takes a 256-channel pair the streaming form would re-fetch the
+        // pointwise weights per 64 pixels
+        if (dwpw_resident_fusable(a, b, pw->kstride == 12, dw->algo == SHL_MI355X_ALGO_IGEMM)) return 7;
+        return dwpw_stream_fusable(a, b, pw->kstride == 12, dw->algo == SHL_MI355X_ALGO_IGEMM) ? 6 : 0;
     }
     const int pw_igemm = pw->algo == SHL_MI355X_ALGO_IGEMM, dw_dot4 = dw->algo == SHL_MI355X_ALGO_DW && dw->kstride == 12;
     if (pw->desc.dtype == SHL_MI355X_F16) {  // binary16 NCHW (pwdw_f16_nchw.hip, stemdw_f16_nchw.hip)
@@ -1067,7 +1069,7 @@ int shl_mi355x_pool_conv_forward(const shl_mi355x_conv_plan *plan, const void *i
 }
 
 /* pointwise 1x1 + the depthwise 3x3 consuming it, fused into one launch */
-int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch)
+int shl_mi355x_pwdw_form(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch)
 {
     if (!dw || !pw) return 0;
     static const char *off = getenv("SHL_MI355X_NO_FUSION");
@@ -1082,7 +1084,12 @@ int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_con
     static char dummy[16];
     if (fill_args(pw, dummy, dummy, batch, a) != SHL_MI355X_OK || fill_args(dw, dummy, dummy, batch, b) != SHL_MI355X_OK)
         return 0;
-    return pwdw_kernel_for(pw, dw, a, b) ? 1 : 0;
+    return pwdw_kernel_for(pw, dw, a, b);
+}
+
+int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch)
+{
+    return shl_mi355x_pwdw_form(pw, dw, batch) ? 1 : 0;
 }
 
 int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, const void *input_dev,

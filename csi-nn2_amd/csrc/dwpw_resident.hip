@@ -51,6 +51,7 @@ namespace shl {
 // requests just made, i.e. serialise the stream with the arithmetic
 __device__ __forceinline__ void dr_read(v4i &r, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr)); }
 __device__ __forceinline__ void dr_tie(v4i &r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void dr_tie16(v16i &r) { asm volatile("" : "+v"(r)); }
 __device__ __forceinline__ uint32_t opaque_u32(uint32_t x)  // (keeps a per-tile rebuild from being hoisted out of the tile loop)
 {
     asm volatile("" : "+v"(x));
@@ -63,24 +64,45 @@ __device__ __forceinline__ void dr_landed(T &...r)
     (dr_tie(r), ...);
 }
 
-constexpr int DR_KB = 512;          // channels = bytes of a pixel
-constexpr int DR_RING = 8;          // row slots
-constexpr int DR_STAGE_B = 32 * DR_KB;
+
+// build switch (tools/dev): SHL_DR_TRACE=1 stamps s_memtime at the phase boundaries of waves 0 and 4 of workgroup 0
+// (tools/dev/dr_trace.py reads them through shl_mi355x_debug_dr_trace)
+#ifndef SHL_DR_TRACE
+#define SHL_DR_TRACE 0
+#endif
+#if SHL_DR_TRACE
+constexpr int DR_TR_TILES = 6, DR_TR_POINTS = 8;
+static __device__ unsigned long long g_dr_trace[2 * DR_TR_TILES * DR_TR_POINTS];
+#endif
 
 // EPI_D / EPI_Q: common.h epilogue flavours of the depthwise / the pointwise layer (0 / 3: division flavour, activation as a clamp)
 // NOG: groups of 32 output channels per wave.  1: a workgroup owns 256 output channels and the two workgroups of a pixel range
 // (Cout = 512) both compute the whole depthwise tile.  2: a workgroup owns 512 -- the depthwise tile is computed once per pixel
 // range, a wave holds 128 registers of pointwise weights and rebuilds ALL its diagonal fragments per tile.
-template <int EPI_D, int EPI_Q, int NOG>
-__global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs q, int ncb, int ranges, int ntiles)
+// KB: channels (= bytes of a pixel), 512 or 256.  R: whole rows of the map per tile (R W <= 32): 2 at 512 channels (W <= 16),
+// 1 at 256 (W = 28: MobileNetV1's 256 -> 256 block; eight waves = eight channel groups = one depthwise group per wave).
+template <int EPI_D, int EPI_Q, int NOG, int KB, int R>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dwpw_resident_kernel(ConvArgs d, ConvArgs q, int ncb, int ranges, int ntiles)
 {
-    constexpr int KB = DR_KB;
-    constexpr int NSUB = KB / 32;  // channel groups = K sub-steps (16)
+    constexpr int NSUB = KB / 32;  // channel groups = K sub-steps (16 | 8)
+    constexpr int NDG = NSUB / 8;  // depthwise groups per wave (2 | 1)
+    constexpr int SL = KB / 16;    // 16-byte slots of a pixel (32 | 16)
+    constexpr int PPP = 1024 / KB; // pixels of a 1 KiB row piece (2 | 4)
+    constexpr int DR_STAGE_B = 32 * KB;
+    // LEAN: the register-poor arrangement (all depthwise fragments rebuilt per tile, one accumulator chain, batches of four) where
+    // a wave holds 128 registers of weights (NOG = 2).  (The 256-channel form in this arrangement fits 128 registers = two workgroups
+    // per CU, and was no faster -- 28.2 vs 27.9 us: the launch is bound by VALU issue, not by latency; profiles/r06_notes.md)
+    constexpr bool LEAN = NOG == 2;
+    constexpr bool AIC = KB == 256;  // (where there are registers for it: the 256-channel form) the layers' accumulator start values as the first MFMA's C operand (16 registers each) instead of 16 additions per requantisation
+    static_assert((KB == 512 || KB == 256) && (R == 1 || R == 2) && (KB == 512 || NOG == 1), "dwpw_resident: unsupported form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = d.W, H = d.H;
     const int rowb = W * KB;                    // bytes of an input row
-    char *const ring = smem;                    // [DR_RING][W][KB]
-    char *const stage = smem + DR_RING * rowb;  // [2][32][KB]
+    // row slots: tile T + 1 is read while the rows of tiles T + 2 and T + 3 are in flight -- R = 2: the whole ring of eight rows
+    constexpr int RING = 8;
+    auto ring_slot = [](int G) { return G & (RING - 1); };
+    char *const ring = smem;                    // [RING][W][KB]
+    char *const stage = smem + RING * rowb;     // [2][32][KB]
     char *const padpx = stage + 2 * DR_STAGE_B; // [KB] input zero points
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -97,17 +119,17 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
     // ---- row requests: row G (global: image * H + y) -> ring slot G & 7; piece j (1 KiB = two pixels) by wave j < W / 2.
     // LDS slot j' of pixel x holds the pixel's 16-byte slot j' ^ (x & 15) (conflict-free ds_read_b128 at a 512-byte pitch).
     const char *const in = static_cast<const char *>(d.in);
-    const int dpx = 2 * wave + half;  // the lane's pixel of the row (pieces exist for 2 wave < W)
-    const int dsrc = ((row ^ (dpx & 15)) & 31) << 4;  // lane -> 16-byte slot `row` of its pixel, swizzled on the source side
+    const int dpx = PPP * wave + lane / SL;  // the lane's pixel of the row (pieces exist for PPP wave < W)
+    const int dsrc = (((lane % SL) ^ (dpx & 15)) & (SL - 1)) << 4;  // lane -> 16-byte slot lane % SL of its pixel, swizzled on the source side
     auto issue_row = [&](int G) {
-        if (2 * wave < W) {
+        if (PPP * wave < W) {
             const int Gc = G < 0 ? 0 : (G >= total_rows ? total_rows - 1 : G);  // rows past the tensor: any valid row (never used as data)
-            glds16(in + ((int64_t)Gc * W + dpx) * KB + dsrc, ring + (G & (DR_RING - 1)) * rowb + wave * 1024);
+            glds16(in + ((int64_t)Gc * W + dpx) * KB + dsrc, ring + ring_slot(G) * rowb + wave * 1024);
         }
     };
-    // the first three tiles' rows (2 t_lo - 1 .. 2 t_lo + 6: the whole ring) before anything else: one cold round trip
+    // the first three tiles' rows (R t_lo - 1 .. R t_lo + 3 R; R = 2: the whole ring) before anything else: one cold round trip
 #pragma unroll 1
-    for (int G = 2 * t_lo - 1; G <= 2 * t_lo + 6; ++G) issue_row(G);
+    for (int G = R * t_lo - 1; G <= R * t_lo + 3 * R; ++G) issue_row(G);
 
     // ---- the pad pixel
     {
@@ -128,21 +150,27 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
     // (256 registers: 64 of pointwise weights + 72 of these.  The last two filter rows of the second group are rebuilt per tile from
     // their six shifted weight bytes -- 6 registers instead of 24; with all eighteen resident three fragments lived in scratch,
     // and a scratch reload is a vector memory instruction the counted waits of the tile loop do not know)
-    constexpr int NFA = NOG == 1 ? 9 : 1;       // resident fragments of group 0 (NOG = 2: none, `fa` is a placeholder)
-    constexpr int RB0 = NOG == 1 ? 9 : 0;       // first tap of group 0 that is rebuilt per tile
-    constexpr int RB1 = NOG == 1 ? 3 : 0;       // ... of group 1
-    v4i fa[2][NOG == 1 ? 9 : 1];
-    uint32_t wb[2][NOG == 1 ? 9 : 3];  // NOG = 1: the lane's weight byte of tap t at its place in the dword (0 off the diagonal);
+    constexpr int NFA = !LEAN ? 9 : 1;       // resident fragments of group 0 (NOG = 2: none, `fa` is a placeholder)
+    constexpr int RB0 = !LEAN ? 9 : 0;       // first tap of group 0 that is rebuilt per tile
+    constexpr int RB1 = !LEAN ? 3 : 0;       // ... of group 1
+    v4i fa[NDG][!LEAN ? 9 : 1];
+    uint32_t wb[NDG][!LEAN ? 9 : 3];  // NOG = 1: the lane's weight byte of tap t at its place in the dword (0 off the diagonal);
                                        // NOG = 2: the three dot4-packed weight words themselves (registers), shifted per use
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
+    for (int gi = 0; gi < NDG; ++gi) {
         const int g = wave + 8 * gi;
         const uint32_t *wq = reinterpret_cast<const uint32_t *>(static_cast<const char *>(d.w) + (int64_t)(g * 32 + row) * 12);
         const uint32_t wd[3] = {wq[0], wq[1], wq[2]};  // taps 0-3 | 4-7 | 8
-        if constexpr (NOG == 1) dw_diag_fragments(wd, row, half, fa[gi]);
+        if constexpr (!LEAN) {
+            dw_diag_fragments(wd, row, half, fa[gi]);
+            // (pinned: the register allocator otherwise REBUILDS the fragments inside the tile loop from the three weight words --
+            // five instructions per tap and tile on the pipe that bounds the launch)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dr_tie(fa[gi][t]);
+        }
         const bool active = (row >> 4) == half;
         const int sh = 8 * (row & 3);
-        if constexpr (NOG == 1) {
+        if constexpr (!LEAN) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) wb[gi][t] = active ? (__builtin_amdgcn_ubfe(wd[t >> 2], 8 * (t & 3), 8) << sh) : 0u;
         } else {
@@ -153,12 +181,18 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
     const int wsh = 8 * (row & 3);
     const int mydw = (row & 15) >> 2;  // which dword of a diagonal fragment is the lane's
     // ---- per-channel tables: lane = channel `row` of the group (both halves of the wave hold the same channel, different pixels)
-    int d_ai[2];
-    float d_mu[2], d_bi[2];
+    int d_ai[NDG];
+    float d_mu[NDG], d_bi[NDG];
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
+    for (int gi = 0; gi < NDG; ++gi) {
         const int c = (wave + 8 * gi) * 32 + row;
         d_ai[gi] = d.acc_init[c], d_mu[gi] = d.mult[c], d_bi[gi] = d.bias[c];
+    }
+    auto splat16 = [](int x) { return v16i{x, x, x, x, x, x, x, x, x, x, x, x, x, x, x, x}; };
+    v16i d_ai16[AIC ? NDG : 1], q_ai16[AIC ? NOG : 1];
+    if constexpr (AIC) {
+#pragma unroll
+        for (int gi = 0; gi < NDG; ++gi) d_ai16[gi] = splat16(d_ai[gi]), dr_tie16(d_ai16[gi]);
     }
     int q_ai[NOG];
     float q_mu[NOG], q_bi[NOG];
@@ -166,10 +200,13 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
     for (int og = 0; og < NOG; ++og) {
         const int c = ch0 + 256 * og + row;
         q_ai[og] = q.acc_init[c], q_mu[og] = q.mult[c], q_bi[og] = q.bias[c];
+        if constexpr (AIC) q_ai16[og] = splat16(q_ai[og]), dr_tie16(q_ai16[og]);
     }
     // 4 x 4 byte transposition inside a quad of lanes (channels 4 m .. 4 m + 3 x the four pixels of a packed dword): lane j of
     // the quad ends up with the four channels of pixel j.  Round 1 exchanges bytes with lane ^ 1, round 2 halves with lane ^ 2.
-    const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+    // (pinned -- opaque -- where there are registers: the allocator otherwise recomputes such lane constants inside the tile loop)
+    auto pin_u32 = [](uint32_t x) { return opaque_u32(x); };
+    const uint32_t sel1 = pin_u32((lane & 1) ? 0x03070105u : 0x06020400u), sel2 = pin_u32((lane & 2) ? 0x03020706u : 0x05040100u);
     auto quad_transpose = [&](uint32_t x) {
         const uint32_t t = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);   // quad_perm [1, 0, 3, 2]
         const uint32_t y = __builtin_amdgcn_perm(t, x, sel1);
@@ -177,9 +214,9 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
         return __builtin_amdgcn_perm(u, y, sel2);
     };
     const int qj = lane & 3, qm = row >> 2;  // the lane's pixel inside a packed dword after the transposition; its channel quad
-    // ---- the lane's pixel of a tile: (pr, pc) = (row / W, row % W) for row < 2 W; the lanes beyond compute pixel 2 W - 1 again
-    const int lp = row < 2 * W ? row : 2 * W - 1;
-    const int pr = lp >= W ? 1 : 0, pc = lp - pr * W;
+    // ---- the lane's pixel of a tile: (pr, pc) = (row / W, row % W) for row < R W; the lanes beyond compute pixel R W - 1 again
+    const int lp = row < R * W ? row : R * W - 1;
+    const int pr = (R == 2 && lp >= W) ? 1 : 0, pc = lp - pr * W;
     // column part of the nine tap addresses, per group: input column pc + kx - 1, the lane's logical slot 2 g + half
     // (group wave + 8's slot is 16 further on: 2 (g + 8) + half = (2 g + half) + 16, and the swizzle touches the low four bits only)
     int coloff[3];
@@ -189,160 +226,234 @@ __global__ __launch_bounds__(512) void dwpw_resident_kernel(ConvArgs d, ConvArgs
         const int ci = pc + kx - 1;
         colok[kx] = ci >= 0 && ci < W;
         const int cc = colok[kx] ? ci : 0;
-        coloff[kx] = cc * KB + ((((2 * wave + half) ^ (cc & 15)) & 31) << 4);
+        coloff[kx] = cc * KB + ((((2 * wave + half) ^ (cc & 15)) & (SL - 1)) << 4);
     }
     const int padoff = (int)(padpx - smem) + ((2 * wave + half) << 4);
     const int aswz = row & 15;  // stage swizzle of the lane's pixel (pixel `row` of the tile)
-    char *const outp = static_cast<char *>(q.out) + ch0 + 4 * qm;
+    // the lane's four (x NOG) output dwords of a tile, relative to the tile's first pixel: loop-invariant 32-bit offsets beside a
+    // scalar tile base.  Pixel columns past the tile (R W .. 31) hold copies of pixel R W - 1 (phase A computes that pixel again
+    // for them): they store the same bytes to the same place -- no lane is masked, so the store instruction is never skipped and
+    // the counted wait of the tile loop can rely on 4 NOG stores per iteration
+    uint32_t ooff[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ooff[e] = pin_u32((uint32_t)(min(8 * e + 4 * half + qj, R * W - 1) * q.Co + ch0 + 4 * qm));
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-    // depthwise phase of tile T into stage T & 1
-    auto phase_a = [&](int T) {
-        const int G0 = 2 * T;               // first input row of the tile's own rows (global)
-        const int y0 = G0 % H;              // ... inside its image (scalar; H is even: a tile never straddles images)
+#if SHL_DR_TRACE
+    const uint32_t tr0 = lds0 + (uint32_t)((padpx - smem) + KB);  // [2 waves][tiles][points] of 8 bytes behind the pad pixel
+    const bool tr_on = blockIdx.x == 0 && (wave & 3) == 0;
+    int tr_tile = 0;
+    auto stamp = [&](int point) {
+        if (tr_on && tr_tile < DR_TR_TILES) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            const uint32_t a = tr0 + (uint32_t)((((wave >> 2) * DR_TR_TILES + tr_tile) * DR_TR_POINTS + point) * 8);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b64 %0, %1" ::"v"(a), "v"(t) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int i = tid; i < 2 * DR_TR_TILES * DR_TR_POINTS * 2; i += 512) reinterpret_cast<uint32_t *>(padpx + KB)[i] = 0;
+#else
+    auto stamp = [](int) {};
+#endif
+    // depthwise phase of tile T, channel group gi of the wave, in two parts: the nine MFMAs into an accumulator ...
+    auto a_mfma = [&](int T, auto gi_c) __attribute__((always_inline)) -> v16i {
+        constexpr int gi = decltype(gi_c)::value;
+        const int G0 = R * T;               // first input row of the tile's own rows (global)
+        const int y0 = G0 % H;              // ... inside its image (scalar; R divides H: a tile never straddles images)
         int rowoff[3];
         bool rowok[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y0 + pr + ky - 1;
             rowok[ky] = yy >= 0 && yy < H;
-            rowoff[ky] = ((G0 + pr + ky - 1) & (DR_RING - 1)) * rowb;
+            rowoff[ky] = ring_slot(G0 + pr + ky - 1) * rowb;
         }
-        const uint32_t st0 = lds0 + (uint32_t)((stage - smem) + (T & 1) * DR_STAGE_B);
+        v16i acc;
+        // the nine taps in three batches of three (one filter row each), two batches in flight: 24 registers instead of 36
+        v4i fb[!LEAN ? 2 : 1][3];
+        // tap t's diagonal fragment of group gi: resident, or rebuilt from the lane's shifted weight byte (gi, t: compile time)
+        auto frag = [&](int g2, int t) -> v4i {
+            if ((g2 == 0 && t < RB0) || (g2 == 1 && t < RB1)) return fa[g2][t < NFA ? t : 0];
+            int wv;
+            if constexpr (!LEAN) wv = (int)opaque_u32(wb[g2][t]);
+            else wv = (int)(__builtin_amdgcn_ubfe(opaque_u32(wb[g2][t >> 2]), 8 * (t & 3), 8) << wsh);
+            return v4i{mydw == 0 ? wv : 0, mydw == 1 ? wv : 0, mydw == 2 ? wv : 0, mydw == 3 ? wv : 0};
+        };
+        auto request = [&](int ky, v4i (&dst)[3]) {
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int g = wave + 8 * gi;
-            v16i acc;
-            {
-                // the nine taps in three batches of three (one filter row each), two batches in flight: 24 registers instead of 36
-                v4i fb[NOG == 1 ? 2 : 1][3];
-                // tap t's diagonal fragment of group gi: resident, or rebuilt from the lane's shifted weight byte (gi, t: compile time)
-                auto frag = [&](int g2, int t) -> v4i {
-                    if ((g2 == 0 && t < RB0) || (g2 == 1 && t < RB1)) return fa[g2][t < NFA ? t : 0];
-                    int wv;
-                    if constexpr (NOG == 1) wv = (int)opaque_u32(wb[g2][t]);
-                    else wv = (int)(__builtin_amdgcn_ubfe(opaque_u32(wb[g2][t >> 2]), 8 * (t & 3), 8) << wsh);
-                    return v4i{mydw == 0 ? wv : 0, mydw == 1 ? wv : 0, mydw == 2 ? wv : 0, mydw == 3 ? wv : 0};
-                };
-                auto request = [&](int ky, v4i (&dst)[3]) {
+            for (int kx = 0; kx < 3; ++kx) {
+                const int off = ((rowok[ky] && colok[kx]) ? rowoff[ky] + coloff[kx] : padoff) + 256 * gi;
+                dr_read(dst[kx], lds0 + (uint32_t)off);
+            }
+        };
+        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (LEAN) {
+            // (one filter row in flight: the second set of three fragments would not fit beside 128 registers of weights)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int off = ((rowok[ky] && colok[kx]) ? rowoff[ky] + coloff[kx] : padoff) + 256 * gi;
-                        dr_read(dst[kx], lds0 + (uint32_t)off);
-                    }
-                };
-                const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                if constexpr (NOG == 2) {
-                    // (one filter row in flight: the second set of three fragments would not fit beside 128 registers of weights)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        request(ky, fb[0]);
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])::"memory");
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx)
-                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, 3 * ky + kx), ky + kx == 0 ? zero16 : acc, 0, 0, 0);
-                        asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(acc));
-                    }
-                } else {
-                request(0, fb[0]);
-                request(1, fb[1]);
-                // rows = pixels: D[pixel][channel] -- lane (channel `row`, half) holds pixels 8 e + 4 half + i as acc[4 e + i]
-                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])::"memory");
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, kx), kx == 0 ? zero16 : acc, 0, 0, 0);
-                asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(acc));  // (the MFMAs above have read fb[0] before it is requested into again)
-                request(2, fb[0]);
-                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2])::"memory");
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[1][kx], frag(gi, 3 + kx), acc, 0, 0, 0);
+            for (int ky = 0; ky < 3; ++ky) {
+                request(ky, fb[0]);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])::"memory");
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, 6 + kx), acc, 0, 0, 0);
-                }
+                for (int kx = 0; kx < 3; ++kx)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, 3 * ky + kx), ky + kx == 0 ? zero16 : acc, 0, 0, 0);
+                asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(acc));
             }
-            const float4 m4 = make_float4(d_mu[gi], d_mu[gi], d_mu[gi], d_mu[gi]), b4 = make_float4(d_bi[gi], d_bi[gi], d_bi[gi], d_bi[gi]);
-            const int ai = d_ai[gi];
+        } else {
+            request(0, fb[0]);
+            request(1, fb[1]);
+            // rows = pixels: D[pixel][channel] -- lane (channel `row`, half) holds pixels 8 e + 4 half + i as acc[4 e + i]
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])::"memory");
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t pk = requant4_i8_t<EPI_D>(acc[4 * e] + ai, acc[4 * e + 1] + ai, acc[4 * e + 2] + ai, acc[4 * e + 3] + ai, m4, b4, d);
-                const uint32_t v = quad_transpose(pk);  // channels g 32 + 4 qm .. + 3 of pixel P
-                const int P = 8 * e + 4 * half + qj;
-                // the pixel's 16-byte slot (2 g + qm / 4) swizzled by the pixel as the pointwise reads expect it, + the quad's dword
-                const uint32_t addr = st0 + (uint32_t)(P * KB + ((((2 * g + (qm >> 2)) ^ (P & 15)) & 31) << 4) + 4 * (qm & 3));
-                // (asm for the same reason as the reads: a compiler-placed ds_write waits for every row request in flight)
-                asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-            }
+            for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, kx), kx == 0 ? (AIC ? d_ai16[AIC ? gi : 0] : zero16) : acc, 0, 0, 0);
+            asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(acc));  // (the MFMAs above have read fb[0] before it is requested into again)
+            request(2, fb[0]);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2])::"memory");
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[1][kx], frag(gi, 3 + kx), acc, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])::"memory");
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0][kx], frag(gi, 6 + kx), acc, 0, 0, 0);
         }
+        if constexpr (gi == 0) stamp(1);  // depthwise MFMAs issued
+        return acc;
+    };
+    // ... and the depthwise layer's requantisation of it into stage T & 1
+    auto a_req = [&](int T, auto gi_c, v16i acc) __attribute__((always_inline)) {
+        constexpr int gi = decltype(gi_c)::value;
+        const int g = wave + 8 * gi;
+        const uint32_t st0 = lds0 + (uint32_t)((stage - smem) + (T & 1) * DR_STAGE_B);
+        const float4 m4 = make_float4(d_mu[gi], d_mu[gi], d_mu[gi], d_mu[gi]), b4 = make_float4(d_bi[gi], d_bi[gi], d_bi[gi], d_bi[gi]);
+        const int ai = AIC ? 0 : d_ai[gi];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t pk = requant4_i8_t<EPI_D>(acc[4 * e] + ai, acc[4 * e + 1] + ai, acc[4 * e + 2] + ai, acc[4 * e + 3] + ai, m4, b4, d);
+            const uint32_t v = quad_transpose(pk);  // channels g 32 + 4 qm .. + 3 of pixel P
+            const int P = 8 * e + 4 * half + qj;
+            // the pixel's 16-byte slot (2 g + qm / 4) swizzled by the pixel as the pointwise reads expect it, + the quad's dword
+            const uint32_t addr = st0 + (uint32_t)(P * KB + ((((2 * g + (qm >> 2)) ^ (P & 15)) & (SL - 1)) << 4) + 4 * (qm & 3));
+            // (asm for the same reason as the reads: a compiler-placed ds_write waits for every row request in flight)
+            asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        }
+    };
+    using gi0_t = std::integral_constant<int, 0>;
+    using gi1_t = std::integral_constant<int, 1>;
+    // the rest of a tile's depthwise phase behind its first group's MFMAs
+    auto a_rest = [&](int T, v16i acc0) __attribute__((always_inline)) {
+        a_req(T, gi0_t{}, acc0);
+        if constexpr (NDG == 2) a_req(T, gi1_t{}, a_mfma(T, gi1_t{}));
+        stamp(3);  // depthwise tile written
     };
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows, weights
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (t_lo < t_hi) phase_a(t_lo);
-
-#pragma unroll 1
-    for (int T = t_lo; T < t_hi; ++T) {
-        // at most the two row requests and the four stores of the previous iteration stay in flight: the rows of tile T + 1
-        // (requested two iterations ago) and every older store have landed.  (Every iteration issues exactly 2 + 4 -- a wave
-        // without row pieces 0 + 4 -- vector memory instructions: the stores are unconditional, see below.)
-        if constexpr (NOG == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // (2 + 4 NOG)
+    if (t_lo < t_hi) a_rest(t_lo, a_mfma(t_lo, gi0_t{}));
+    // One barrier per tile, all eight waves in the same block of work at the same time.  Tried and measured no faster (profiles/
+    // r06_notes.md, traces in profiles/r06_dwpw_resident_trace*.txt): the two phases in opposite orders on waves 0-3 / 4-7 (slower:
+    // both orders start with MFMAs), and waves 4-7 passing the barrier one block later (behind the next tile's first MFMAs) so that
+    // the two waves of a SIMD sit on different pipes -- an interval is as long as ONE wave's chain of dependent blocks [LDS reads |
+    // 9 chained MFMAs | requantisation | LDS reads | MFMAs | requantisation], ~3 800 of the ~4 000 cycles.
+    // at most the R row requests and the 4 NOG stores of the previous iteration stay in flight: the rows requested two iterations
+    // ago -- tile T + 1's -- and every older store have landed.  (Every iteration issues exactly R + 4 NOG -- a wave without row
+    // pieces 4 NOG -- vector memory instructions: the stores are unconditional.)
+    auto sync = [&]() __attribute__((always_inline)) {
+        if constexpr (R + 4 * NOG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (R + 4 * NOG == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // (R + 4 NOG)
+        static_assert(R + 4 * NOG == 6 || R + 4 * NOG == 10 || R + 4 * NOG == 5, "dwpw_resident: counted wait");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage T complete; stage T - 1 free; rows of tile T + 1 visible
         __builtin_amdgcn_sched_barrier(0);
-        if (T + 1 < t_hi) phase_a(T + 1);
-        // rows 2 T + 7, 2 T + 8 (tile T + 3) into the slots rows 2 T - 1, 2 T have just left (always: the wait above counts them)
-        if (!(d.debug & 4)) {
-            issue_row(2 * T + 7);
-            issue_row(2 * T + 8);
-        }
+    };
+
+    // pointwise phase: stage T -> the tile's output pixels
+    auto interval_b = [&](int T) __attribute__((always_inline)) {
         // ---- pointwise layer on stage T
         const uint32_t stq = lds0 + (uint32_t)((stage - smem) + (T & 1) * DR_STAGE_B + row * KB);
-        const int64_t p0 = (int64_t)T * 2 * W;  // the tile's pixels are 2 W consecutive pixels of the tensor
+        char *const tile_out = static_cast<char *>(q.out) + (int64_t)T * R * W * q.Co;  // the tile's pixels are R W consecutive pixels of the tensor (scalar)
 #pragma unroll
         for (int og = 0; og < NOG; ++og) {
-            v16i acc[NOG == 1 ? 2 : 1];
+            v16i acc[!LEAN ? 2 : 1];
             {
                 const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 // the stage's 16 fragments in two halves of eight (registers: the weights take 64 NOG; NOG = 2 reads the stage twice)
-                constexpr int BS = NOG == 1 ? 8 : 4;  // fragments per batch (NOG = 2: 128 registers of weights leave room for four)
+                constexpr int BS = !LEAN ? 8 : 4;  // fragments per batch (NOG = 2: 128 registers of weights leave room for four)
                 static_for<NSUB / BS>([&](auto hc) {
                     constexpr int h8 = decltype(hc)::value * BS;
                     v4i fb[BS];
 #pragma unroll
-                    for (int u = 0; u < BS; ++u) dr_read(fb[u], stq + (uint32_t)((((2 * (h8 + u) + half) ^ aswz) & 31) << 4));
+                    for (int u = 0; u < BS; ++u) dr_read(fb[u], stq + (uint32_t)((((2 * (h8 + u) + half) ^ aswz) & (SL - 1)) << 4));
                     if constexpr (BS == 8) dr_landed(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], fb[7]);
-                    else dr_landed(fb[0], fb[1], fb[2], fb[3]);
+                    else if constexpr (BS == 4) dr_landed(fb[0], fb[1], fb[2], fb[3]);
+                    else dr_landed(fb[0], fb[1]);
 #pragma unroll
                     for (int u = 0; u < BS; ++u) {
                         const int uu = h8 + u;  // rows = pixels (A = the stage's fragment, B = the weights): lane = output channel
                         // (NOG = 1: two chains over the even / odd sub-steps; NOG = 2: one -- 16 registers, and the launch is bound by VALU issue)
-                        constexpr int NCHAIN = NOG == 1 ? 2 : 1;
-                        acc[u % NCHAIN] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[u], fw[og][uu], uu < NCHAIN ? zero16 : acc[u % NCHAIN], 0, 0, 0);
+                        constexpr int NCHAIN = !LEAN ? 2 : 1;
+                        acc[u % NCHAIN] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[u], fw[og][uu], uu < NCHAIN ? ((AIC && uu == 0) ? q_ai16[AIC ? og : 0] : zero16) : acc[u % NCHAIN], 0, 0, 0);
                     }
                 });
             }
+#if SHL_DR_TRACE
+            if (og == 0) stamp(5);  // pointwise MFMAs issued
+            if (og == 0) { asm volatile("s_nop 0" : "+v"(acc[0])); stamp(6); }
+#endif
             const float4 m4 = make_float4(q_mu[og], q_mu[og], q_mu[og], q_mu[og]), b4 = make_float4(q_bi[og], q_bi[og], q_bi[og], q_bi[og]);
-            const int qa = q_ai[og];
+            const int qa = AIC ? 0 : q_ai[og];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 uint32_t pk;
-                if constexpr (NOG == 1)
+                if constexpr (!LEAN)
                     pk = requant4_i8_t<EPI_Q>(acc[0][4 * e] + acc[1][4 * e] + qa, acc[0][4 * e + 1] + acc[1][4 * e + 1] + qa,
                                               acc[0][4 * e + 2] + acc[1][4 * e + 2] + qa, acc[0][4 * e + 3] + acc[1][4 * e + 3] + qa, m4, b4, q);
                 else
                     pk = requant4_i8_t<EPI_Q>(acc[0][4 * e] + qa, acc[0][4 * e + 1] + qa, acc[0][4 * e + 2] + qa, acc[0][4 * e + 3] + qa, m4, b4, q);
                 const uint32_t v = quad_transpose(pk);  // output channels ch0 + 256 og + 4 qm .. + 3 of pixel P
-                // pixel columns past the tile (2 W .. 31) hold copies of pixel 2 W - 1 (phase A computes that pixel again for them):
-                // they store the same bytes to the same place -- no lane is masked, so the store instruction is never skipped
-                // and the counted wait above can rely on 4 NOG stores per iteration
-                const int P = min(8 * e + 4 * half + qj, 2 * W - 1);
-                *reinterpret_cast<uint32_t *>(outp + 256 * og + (p0 + P) * q.Co) = v;
+                *reinterpret_cast<uint32_t *>(tile_out + (size_t)(ooff[e] + 256u * og)) = v;
             }
         }
+    };
+
+#pragma unroll 1
+    for (int T = t_lo; T < t_hi; ++T) {
+        sync();
+        stamp(0);  // barrier passed
+        if (T + 1 < t_hi) a_rest(T + 1, a_mfma(T + 1, gi0_t{}));
+        // the R new rows of tile T + 3 (R = 2: rows 2 T + 7, 2 T + 8 into the slots rows 2 T - 1, 2 T have just left) -- always:
+        // the wait counts them
+        if (!(d.debug & 4)) {
+#pragma unroll
+            for (int r = 1; r <= R; ++r) issue_row(R * (T + 3) + r);
+        }
+        stamp(4);  // rows requested
+        interval_b(T);
+        stamp(7);  // stores issued
+#if SHL_DR_TRACE
+        ++tr_tile;
+#endif
     }
+#if SHL_DR_TRACE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (blockIdx.x == 0 && tid < 2 * DR_TR_TILES * DR_TR_POINTS) {
+        unsigned long long v;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tr0 + 8u * tid) : "memory");
+        g_dr_trace[tid] = v;
+    }
+#endif
 }
+
+#if SHL_DR_TRACE
+extern "C" int shl_mi355x_debug_dr_trace(unsigned long long *host, int count)
+{
+    const int n = count < 2 * DR_TR_TILES * DR_TR_POINTS ? count : 2 * DR_TR_TILES * DR_TR_POINTS;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dr_trace), (size_t)n * 8) != hipSuccess) return -1;
+    return n;
+}
+#endif
 
 static bool dr_clamp_epilogue(const ConvArgs &a)
 {
@@ -354,19 +465,22 @@ static int dr_nog(const ConvArgs &q)
 {
     static const char *env = getenv("SHL_MI355X_DWPW_RES_NOG");  // "1": workgroups of 256 output channels (A/B, tests)
     if (env && env[0] == '1') return 1;
-    return (q.Co % 512) == 0 ? 2 : 1;
+    return (q.C == 512 && (q.Co % 512) == 0) ? 2 : 1;
 }
+
+// rows of the map per tile: two where they fit a block of 32 pixels (the 512-channel form), one for the 256-channel form
+static int dr_rows(const ConvArgs &d) { return d.C == 512 ? 2 : 1; }
 
 static bool dr_geom(const ConvArgs &d, const ConvArgs &q, int *ncb, int *ranges, int *ntiles, int *grid, size_t *lds)
 {
     const int nb = q.Co / (256 * dr_nog(q));
     if (nb < 1 || nb > 32 || 32 % nb != 0) return false;
-    const int64_t tiles = (int64_t)d.N * d.H / 2;
-    int r = 256 / nb;
+    const int64_t tiles = (int64_t)d.N * d.H / dr_rows(d);
+    int r = 256 / nb;  // one workgroup per CU
     while (r > 8 && tiles < 3 * (int64_t)r) r >>= 1;  // at least three tiles per workgroup
     if (tiles < 3 * (int64_t)r || (r * nb) % 8 != 0 || ((r * nb) / 8) % nb != 0 || tiles >= (1 << 28)) return false;
     *ncb = nb, *ranges = r, *ntiles = (int)tiles, *grid = r * nb;
-    *lds = (size_t)DR_RING * d.W * DR_KB + 2 * DR_STAGE_B + DR_KB;
+    *lds = (size_t)8 * d.W * d.C + 2 * 32 * (size_t)d.C + d.C + (SHL_DR_TRACE ? 1024 : 0);
     return *lds <= 160 * 1024;
 }
 
@@ -375,12 +489,17 @@ static bool dr_geom(const ConvArgs &d, const ConvArgs &q, int *ncb, int *ranges,
 bool dwpw_resident_takes(const ConvArgs &d)
 {
     if (d.Kh != 3 || d.Kw != 3 || d.dh != 1 || d.dw != 1 || d.sh != 1 || d.sw != 1 || d.pt != 1 || d.pl != 1) return false;
-    if (d.C != DR_KB || d.Co != d.C || d.in_nchw || d.out_nchw || !dr_clamp_epilogue(d)) return false;
-    if (d.Ho != d.H || d.Wo != d.W || (d.W & 1) || d.W > 16 || d.W < 4 || (d.H & 1) || d.in_zp < -128 || d.in_zp > 127) return false;
+    if ((d.C != 512 && d.C != 256) || d.Co != d.C || d.in_nchw || d.out_nchw || !dr_clamp_epilogue(d)) return false;
+    if (d.Ho != d.H || d.Wo != d.W || d.in_zp < -128 || d.in_zp > 127) return false;
+    // 512 channels: row pieces of two pixels, tiles of two rows; 256: pieces of four pixels, tiles of one row wider than 16
+    if (d.C == 512 && ((d.W & 1) || d.W > 16 || d.W < 4 || (d.H & 1))) return false;
+    if (d.C == 256 && ((d.W & 3) || d.W > 32 || d.W <= 16)) return false;
     const char *env = getenv("SHL_MI355X_DWPW_RES");  // "0" never, "1" always (tests, A/B); read per call
     if (env && env[0] == '0') return false;
     if (env && env[0] == '1') return true;
-    return (int64_t)d.N * d.H >= 6 * 256;  // three tiles per workgroup on every CU: MobileNetV1 @14 from batch 110
+    // 512 channels: three tiles of two rows per workgroup on every CU -- MobileNetV1 @14 from batch 110.  256 channels: seven tiles of
+    // one row -- 256 @28 from batch 64 (15.9 vs 18.8 us as dwpw_stream; batch 32: 10.9 vs 11.1, left to the streaming form)
+    return (int64_t)d.N * d.H >= (d.C == 512 ? 6 * 256 : 7 * 256);
 }
 
 bool dwpw_resident_fusable(const ConvArgs &d, const ConvArgs &q, int dw_dot4_packed, int pw_is_igemm)
@@ -403,16 +522,17 @@ int launch_dwpw_resident(const ConvArgs &d, const ConvArgs &q, hipStream_t s)
         set_error("dwpw_resident: the pair does not fit");
         return SHL_MI355X_ENOTSUP;
     }
-#define SHL_DR2(ED, EQ, NG)                                                                                             \
+#define SHL_DR2(ED, EQ, NG, KB, R)                                                                                      \
     do {                                                                                                                \
         static LdsOptIn opted;                                                                                          \
-        lds_opt_in(opted, reinterpret_cast<const void *>(dwpw_resident_kernel<ED, EQ, NG>));                           \
-        hipLaunchKernelGGL((dwpw_resident_kernel<ED, EQ, NG>), dim3((unsigned)grid), dim3(512), lds, s, d, q, ncb, ranges, ntiles); \
+        lds_opt_in(opted, reinterpret_cast<const void *>(dwpw_resident_kernel<ED, EQ, NG, KB, R>));                    \
+        hipLaunchKernelGGL((dwpw_resident_kernel<ED, EQ, NG, KB, R>), dim3((unsigned)grid), dim3(512), lds, s, d, q, ncb, ranges, ntiles); \
     } while (0)
-#define SHL_DR(ED, EQ)                  \
-    do {                                \
-        if (dr_nog(q) == 2) SHL_DR2(ED, EQ, 2); \
-        else SHL_DR2(ED, EQ, 1);        \
+#define SHL_DR(ED, EQ)                                \
+    do {                                              \
+        if (d.C == 256) SHL_DR2(ED, EQ, 1, 256, 1);   \
+        else if (dr_nog(q) == 2) SHL_DR2(ED, EQ, 2, 512, 2); \
+        else SHL_DR2(ED, EQ, 1, 512, 2);              \
     } while (0)
     if (d.div_exact) {
         if (q.div_exact) SHL_DR(3, 3);

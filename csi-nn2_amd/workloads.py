@@ -191,7 +191,7 @@ class LayerChain:
             nxt = self.entries[k + 1] if k + 1 < len(self.entries) else None
             streams = bool(fuse and nxt is not None and not nxt["layer"]["depthwise"] and nxt["d_in"] == e["d_out"]
                            and hip.shl_mi355x_pwdw_fusable(opt.shl_mi355x_registry_get(e["params"]),
-                                                           opt.shl_mi355x_registry_get(nxt["params"]), batch) == 1)
+                                                           opt.shl_mi355x_registry_get(nxt["params"]), batch) != 0)
             hip.shl_mi355x_conv_plan_set_no_stream_consumer(opt.shl_mi355x_registry_get(e["params"]), 0 if streams else 1)
         i = 0
         while i < len(self.entries):
@@ -200,7 +200,7 @@ class LayerChain:
             if (fuse and b is not None and a["layer"]["depthwise"] != b["layer"]["depthwise"]
                     and b["d_in"] == a["d_out"]
                     and hip.shl_mi355x_pwdw_fusable(opt.shl_mi355x_registry_get(a["params"]),
-                                                    opt.shl_mi355x_registry_get(b["params"]), batch) == 1):
+                                                    opt.shl_mi355x_registry_get(b["params"]), batch) != 0):
                 self.units.append([i, i + 1])
                 i += 2
             else:
@@ -227,8 +227,10 @@ class LayerChain:
         idx = self.units[u]
         if len(idx) == 1:
             return self.entries[idx[0]]["kernel_name"]
-        if self.entries[idx[0]]["layer"]["depthwise"]:  # depthwise -> pointwise: dwpw_stream.hip, or (512 channels) dwpw_resident.hip
-            return "dwpw_resident_i8" if self.entries[idx[0]]["layer"]["cin"] >= 512 else "dwpw_stream_i8"
+        if self.entries[idx[0]]["layer"]["depthwise"]:  # depthwise -> pointwise: dwpw_stream.hip (form 6) or dwpw_resident.hip (7)
+            get = self.opt.shl_mi355x_registry_get
+            form = self.hip.shl_mi355x_pwdw_form(get(self.entries[idx[0]]["params"]), get(self.entries[idx[1]]["params"]), self.batch)
+            return "dwpw_resident_i8" if form == 7 else "dwpw_stream_i8"
         if self.dtype != "int8":
             return "pwdw_f16_nchw" if "igemm" in self.entries[idx[0]]["kernel_name"] or "1x1" in self.entries[idx[0]]["kernel_name"] else "stemdw_f16_nchw"
         return "stemdw_fused_i8" if self.entries[idx[0]]["kernel_name"].startswith("conv_stem") else "pwdw_fused_i8"

@@ -293,6 +293,9 @@ int shl_mi355x_conv_plan_set_no_stream_consumer(shl_mi355x_conv_plan *plan, int3
  * always the first layer's input and `output_dev` the second layer's output; the plans say which order it is.
  */
 int shl_mi355x_pwdw_fusable(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch);
+/* which fused kernel would run the pair: 0 none (= not fusable), else the form's number (conv_plan.hip:pwdw_kernel_for: 1 latency
+ * form, 3 stem + depthwise, 4 / 5 binary16 NCHW, 6 dwpw_stream, 7 dwpw_resident) -- for tools and tests that name the kernel */
+int shl_mi355x_pwdw_form(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch);
 int shl_mi355x_pwdw_forward(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw,
                             const void *input_dev, void *output_dev, int32_t batch, void *stream);
 
