@@ -102,51 +102,102 @@ __global__ __launch_bounds__(64) void global_avgpool_nhwc_i8_kernel(const void *
 // or would carry acc out of the binade (m + prefix >= 2^24, conservatively); that element takes the literal
 // step and the next round starts from the new acc (and binade).  Bit-identical to the literal loop --
 // tests/test_tail.py compares the two forms on adversarial rows.
+__device__ __forceinline__ double readlane_f64(double x, int l)  // (l wave-uniform)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+// Round 6: the same scheme in INTEGER arithmetic, four consecutive elements per lane and round (256 per round).  A round is one
+// wave's chain of dependent instructions, and in double precision (ldexp, floor, rint, compares: ~10 f64 instructions per element at
+// a quarter of the fp32 rate) it cost ~520 cycles -- 19 rounds = 9 850 of the kernel's 16 000 ticks for 1 000 classes
+// (tools/dev/r06_sm_trace.sh).  With x = RN_double(2^E + e):
+//   * x's exponent field is still E's  <=>  e did not carry the sum out of the binade ("big" above);
+//   * x's 52 mantissa bits ARE (x - 2^E) / 2^(E-52) = t' * 2^29: integer part = bits 29 .. 51, fraction = bits 0 .. 28 --
+//     rint(t') = integer part + (fraction > 2^28), a tie is fraction == 2^28 (it stops the round: the rounding of a tie is never used);
+//   * m is acc's own significand (float bits), and acc' = (m + prefix) * 2^(E-23) is assembled from bits as well.
+// One f64 addition per element is all the floating point left in a round.
+// (`e` is padded with 256 zeros behind its cnt elements: a zero adds nothing and never stops a round, so no lane tests validity.
+// A tie or an element that leaves the binade simply takes the increment 2^24, which trips the one stop criterion m + prefix >= 2^24
+// at exactly that element.  What a round costs is its INSTRUCTION COUNT -- one wave issues an instruction per ~5.8 cycles,
+// scalar or vector -- hence the shape of this loop.)
 __device__ __forceinline__ float running_sum_exact(const double *e, int cnt, int lane)
 {
     float acc = 0.f;  // wave-uniform
     int j = 0;
     while (j < cnt) {
-        if (!(acc >= 1.17549435e-38f)) {  // zero or subnormal: literal step
+        const uint32_t abits = __float_as_uint(acc);
+        const uint32_t aexp = abits >> 23;  // (sign included: a negative acc does not exist, NaN / inf take the literal path)
+        if (aexp == 0u || aexp >= 0xffu) {   // zero, subnormal (or not a positive finite number): literal step
             acc = (float)((double)acc + e[j]);
             ++j;
             continue;
         }
-        int ex;
-        (void)__builtin_frexpf(acc, &ex);  // acc = f * 2^ex, f in [0.5, 1)  ->  E = ex - 1
-        const int E = ex - 1;
-        const double base = __builtin_ldexp(1.0, E), inv_u = __builtin_ldexp(1.0, 23 - E);
-        const uint32_t m = (uint32_t)((double)acc * inv_u);  // exact
-        const int idx = j + lane;
-        const bool valid = idx < cnt;
-        const double ev = valid ? e[idx] : 0.0;
-        const double tp = ((base + ev) - base) * inv_u;  // t'
-        const bool big = !(tp < 8388608.0);              // >= 2^23: leaves the binade for sure
-        const double fl = __builtin_floor(tp);
-        const bool tie = (tp - fl) == 0.5;
-        uint32_t p = big ? 0x01000000u : (uint32_t)__builtin_rint(tp);  // this lane's increment
-        // inclusive prefix sum over the wave (increments <= 2^24 each: no overflow in 32 bits), on DPP:
+        const uint32_t m = (abits & 0x007fffffu) | 0x00800000u;  // acc = m * 2^(E-23), E = aexp - 127
+        const uint32_t base_hi = (aexp + (1023u - 127u)) << 20;  // the double 2^E (low word 0)
+        const double base = __hiloint2double((int)base_hi, 0);
+        const uint32_t limit = 0x01000000u - m;                  // the round stops at the first prefix >= limit
+        const double *ep = e + j + 4 * lane;
+        double ev[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ev[k] = ep[k];
+        uint32_t P[4];  // inclusive prefix of the increments inside the lane, saturated at 2^24 (every prefix in front of the
+                        // first stop is < 2^24 and exact)
+        uint32_t s4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double x = base + ev[k];
+            const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
+            const uint32_t frac = lo & 0x1fffffffu;
+            const uint32_t ip = ((hi << 3) | (lo >> 29)) & 0x007fffffu;
+            // exponent (or sign) field moved: >= 2^(E+1), inf or NaN; fraction exactly one half: a tie
+            const bool stop = ((hi ^ base_hi) > 0x000fffffu) || frac == 0x10000000u;
+            // (branch-free on purpose: hipcc otherwise wraps the three instructions of the regular case in an exec-mask branch)
+            const uint32_t inc = ip + (frac > 0x10000000u ? 1u : 0u) + (stop ? 0x01000000u : 0u);
+            s4 = min(s4 + inc, 0x01000000u);
+            P[k] = s4;
+        }
+        // inclusive prefix sum of the lanes' totals over the wave (<= 64 * 2^24: no overflow in 32 bits), on DPP:
         // row_shr 1, 2, 4, 8 scan the 16-lane rows, row_bcast15 / row_bcast31 carry the row totals
-        // (six VALU instructions instead of six LDS-crossbar shuffles)
+        uint32_t p = s4;
         p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x111, 0xf, 0xf, true);
         p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x112, 0xf, 0xf, true);
         p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x114, 0xf, 0xf, true);
         p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x118, 0xf, 0xf, true);
         p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x142, 0xa, 0xf, false);
         p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x143, 0xc, 0xf, false);
-        const bool stop = valid && (tie || big || m + p >= 0x01000000u);
-        const unsigned long long mask = __ballot(stop);
+        const uint32_t before = p - s4;                                   // the lanes in front of this one
+        const uint32_t room = limit > before ? limit - before : 0u;       // what this lane's prefixes may reach
+        // the lane's elements in front of its first stop (the prefixes are non-decreasing) and the prefix of the last of them
+        int fk = 0;
+        uint32_t last = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in_front = P[k] < room;
+            fk += in_front ? 1 : 0;
+            last = in_front ? P[k] : last;
+        }
+        const uint32_t reach = before + last;  // the sum's increment up to the lane's last element in front of its stop
+        const unsigned long long mask = __ballot(fk < 4);
         int nvalid = cnt - j;
-        nvalid = nvalid < 64 ? nvalid : 64;
-        int c = mask ? __builtin_ctzll(mask) : 64;
-        c = c < nvalid ? c : nvalid;
-        if (c > 0) {
-            const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)p, c - 1);  // c is wave-uniform
-            acc = (float)((double)(m + pc) * __builtin_ldexp(1.0, E - 23));  // exact: m + pc < 2^24
+        nvalid = nvalid < 256 ? nvalid : 256;
+        int c = 256;
+        uint32_t pc;
+        if (mask) {
+            const int L = __builtin_ctzll(mask);
+            c = 4 * L + __builtin_amdgcn_readlane(fk, L);
+            pc = (uint32_t)__builtin_amdgcn_readlane((int)reach, L);
+        } else {
+            pc = (uint32_t)__builtin_amdgcn_readlane((int)p, 63);  // (the zeros behind the row add nothing)
+        }
+        if (c > nvalid) c = nvalid;  // (a stop never sits on a zero behind the row: pc is the row's increment then as well)
+        if (c > 0) {  // elements j .. j + c - 1 advance acc inside its binade (c is wave-uniform)
+            acc = __uint_as_float((aexp << 23) | ((m + pc) & 0x007fffffu));  // (m + pc) * 2^(E-23), 2^23 <= m + pc < 2^24
             j += c;
         }
-        if (c < nvalid) {  // the stopping element: literal step (may change the binade)
-            acc = (float)((double)acc + e[j]);
+        if (c < nvalid) {  // the stopping element: literal step (may change the binade); its value sits in lane c / 4
+            const int ks = c & 3;
+            const double es = readlane_f64(ks == 0 ? ev[0] : ks == 1 ? ev[1] : ks == 2 ? ev[2] : ev[3], c >> 2);
+            acc = (float)((double)acc + es);
             ++j;
         }
     }
@@ -155,16 +206,29 @@ __device__ __forceinline__ float running_sum_exact(const double *e, int cnt, int
 
 constexpr int SOFTMAX_MAX_CNT = 8192;  // doubles parked in LDS: 64 KiB
 
+// -DSHL_SM_TRACE=1 (tools/dev): s_memtime of thread 0 of row 0 at the phase boundaries of softmax_kernel
+#ifndef SHL_SM_TRACE
+#define SHL_SM_TRACE 0
+#endif
+#if SHL_SM_TRACE
+static __device__ unsigned long long g_sm_trace[8];
+#define SM_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sm_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SM_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void softmax_kernel(const void *in, void *out, int dtype, int cnt,
                                                       int64_t inner, float si, float zi, float so, float zo, int seq_sum)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *e = reinterpret_cast<double *>(smem);          // [cnt]
-    float *red = reinterpret_cast<float *>(e + cnt);       // [256]
+    double *e = reinterpret_cast<double *>(smem);          // [cnt + 256]: 256 zeros behind the row (running_sum_exact)
+    float *red = reinterpret_cast<float *>(e + cnt + 256); // [256]
     const int64_t row = blockIdx.x;                         // outer * inner + k
     const int64_t o = row / inner, k = row - o * inner;
     const int64_t base = o * cnt * inner + k;
     const int tid = threadIdx.x;
+    e[cnt + tid] = 0.0;
+    SM_STAMP(0);
     // max (fmax over floats: exact whatever the order)
     float m = -3.402823466e+38f;
     for (int j = tid; j < cnt; j += 256) m = fmaxf(m, load_dequant(in, base + j * inner, dtype, si, zi));
@@ -183,9 +247,29 @@ __global__ __launch_bounds__(256) void softmax_kernel(const void *in, void *out,
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
-    for (int j = tid; j < cnt; j += 256)
-        e[j] = exp((double)__fsub_rn(load_dequant(in, base + j * inner, dtype, si, zi), m));
+    SM_STAMP(1);
+    // int8: the row holds at most 256 distinct values -- thread t evaluates the exponential (and, below, the quotient and its
+    // requantisation) of value t - 128 ONCE, the elements look theirs up (the same operations on the same operands as per
+    // element: bit-identical; one f64 exp and one f64 division per thread instead of cnt / 256 of each)
+    double *const lut_e = reinterpret_cast<double *>(red + 256);     // [256]
+    int8_t *const lut_q = reinterpret_cast<int8_t *>(lut_e + 256);   // [256]
+    uint8_t *const xb = reinterpret_cast<uint8_t *>(lut_q + 256);    // [cnt]: the row's bytes + 128 (the last pass reads them from LDS)
+    const bool lut = dtype == SHL_MI355X_I8;
+    if (lut) {
+        const float x = __fmul_rn(__fsub_rn((float)(tid - 128), zi), si);  // load_dequant of the byte value tid - 128
+        lut_e[tid] = exp((double)__fsub_rn(x, m));
+        __syncthreads();
+        for (int j = tid; j < cnt; j += 256) {
+            const int v = (int)static_cast<const int8_t *>(in)[base + j * inner] + 128;
+            xb[j] = (uint8_t)v;
+            e[j] = lut_e[v];
+        }
+    } else {
+        for (int j = tid; j < cnt; j += 256)
+            e[j] = exp((double)__fsub_rn(load_dequant(in, base + j * inner, dtype, si, zi), m));
+    }
     __syncthreads();
+    SM_STAMP(2);
     if (seq_sum) {
         if (tid == 0) {
             float acc = 0.f;  // `acc_exp += exp(...)`: double add, rounded to float every step
@@ -205,11 +289,27 @@ __global__ __launch_bounds__(256) void softmax_kernel(const void *in, void *out,
         if (tid == 0) red[0] = acc;
     }
     __syncthreads();
+    SM_STAMP(3);
     const double acc = (double)red[0];
-    for (int j = tid; j < cnt; j += 256) store_requant(out, base + j * inner, (float)(e[j] / acc), dtype, so, zo);
+    if (lut) {
+        lut_q[tid] = (int8_t)sat8_from_float(__fadd_rn(rintf(__fdiv_rn((float)(lut_e[tid] / acc), so)), zo));  // store_requant's int8 branch
+        __syncthreads();
+        for (int j = tid; j < cnt; j += 256)
+            static_cast<int8_t *>(out)[base + j * inner] = lut_q[xb[j]];
+    } else {
+        for (int j = tid; j < cnt; j += 256) store_requant(out, base + j * inner, (float)(e[j] / acc), dtype, so, zo);
+    }
+    SM_STAMP(4);
 }
 
 }  // namespace shl
+
+#if SHL_SM_TRACE
+extern "C" int shl_mi355x_debug_sm_trace(unsigned long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(shl::g_sm_trace), 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int shl_mi355x_global_avgpool2d(const void *input_dev, void *output_dev, int32_t dtype, int32_t layout,
                                            int32_t batch, int32_t channels, int32_t pixels, float in_scale,
@@ -256,7 +356,7 @@ extern "C" int shl_mi355x_softmax(const void *input_dev, void *output_dev, int32
         shl::set_error("softmax: too many rows");
         return SHL_MI355X_ENOTSUP;
     }
-    const size_t lds = (size_t)count * 8 + 256 * 4;
+    const size_t lds = ((size_t)count + 256) * 8 + 256 * 4 + 256 * 8 + 256 + (size_t)count;  // e[count + 256] | red[256] | lut_e[256] | lut_q[256] | xb[count]
     static shl::LdsOptIn opted_in;
     if (lds > 48 * 1024) shl::lds_opt_in(opted_in, reinterpret_cast<const void *>(shl::softmax_kernel), 96 * 1024);
     static const char *seq_env = getenv("SHL_MI355X_SOFTMAX_SEQ");  // "1": the literal one-lane running sum (A/B, tests)
