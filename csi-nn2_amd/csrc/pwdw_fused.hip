@@ -56,11 +56,19 @@ struct PwDwArgs {
     uint32_t spg_magic;        // j / spg == (j * spg_magic) >> 20 for j < 4096
     uint32_t tx_magic;         // same for tiles_x
     int32_t nrect;             // rectangles in all = tiles_x * tiles_y * N
+    // (round 6: what the kernel used to derive per wave -- a wave issues ONE instruction per ~5.8 cycles, scalar or vector, and at
+    // batch 1 a launch is one wave's chain: the prologue was 323 instructions in front of the MFMAs, integer divisions by ks and
+    // the 64-bit image offset among them; profiles/r06_notes.md)
+    int32_t ks_log2;           // log2(ks)
+    int32_t mwn;               // wave groups over the tiles = nwaves / ks
+    int64_t img_stride;        // bytes of an image of the pointwise input = H W C
 };
 
 // MTW: MFMA tiles per wave (upper bound), NSW: K sub-steps per wave (upper bound), MAXT: threads (the
-// 8-sub-step form needs more than the 256 registers a lane gets with two waves per SIMD)
-template <int MTW, int NSW, int MAXT>
+// 8-sub-step form needs more than the 256 registers a lane gets with two waves per SIMD).  EXACT: every wave has exactly NSW
+// sub-steps (K / 32 = ks NSW: every MobileNet pair but the first) -- no per-fragment guards, and the first MFMA of a tile takes
+// the constant 0 as its C operand instead of 16 zeroed registers per tile.
+template <int MTW, int NSW, int MAXT, bool EXACT>
 __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,16 +78,29 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar control around MFMA
     const int frow = lane & 31, fhalf = lane >> 5;
+    // every kernel argument the prologue needs, fetched in ONE batch in front of the first branch (an empty asm "uses" them here):
+    // the compiler otherwise fetches an argument inside the branch that first reads it -- four dependent s_load / s_waitcnt round
+    // trips of ~200 cycles in front of the first fragment load
+    asm volatile("" ::"s"(f.xg), "s"(f.xg_log2), "s"(f.spg), "s"(f.spg_magic), "s"(f.tx_magic), "s"(f.nrect), "s"(f.tiles_x), "s"(f.tiles_y));
+    asm volatile("" ::"s"(f.bh), "s"(f.bw), "s"(f.rw), "s"(f.npx), "s"(f.mt), "s"(f.ks), "s"(f.nsw), "s"(f.nsub), "s"(f.rw_magic),
+                 "s"(f.ks_log2), "s"(f.mwn), "s"(f.img_stride));
+    asm volatile("" ::"s"(q.in), "s"(q.w_frag), "s"(q.H), "s"(q.W), "s"(q.C), "s"(d.sh), "s"(d.sw), "s"(d.pt), "s"(d.pl), "s"(d.N));
     int slice = blockIdx.x, tx = blockIdx.y, ty = blockIdx.z, n = 0;
-    if (f.xg) {
+    {
+        // (computed whether or not the grid is XCD-mapped and then selected: inside `if (f.xg)` the fields below were fetched
+        // from the kernel arguments in two further dependent s_load / s_waitcnt round trips, ~200 cycles each)
         const int L = blockIdx.x;
         const int x = L & 7, j = L >> 3;                        // XCD, index among that XCD's workgroups
         const int b = (int)(((uint32_t)j * f.spg_magic) >> 20);
-        slice = (x & (f.xg - 1)) * f.spg + (j - b * f.spg);  // a group = spg ADJACENT slices
+        const int xslice = (x & (f.xg - 1)) * f.spg + (j - b * f.spg);  // a group = spg ADJACENT slices
         const int rect = b * (8 >> f.xg_log2) + (x >> f.xg_log2);
-        if (rect >= f.nrect) return;
-        ty = (int)(((uint32_t)rect * f.tx_magic) >> 20);
-        tx = rect - ty * f.tiles_x;
+        const int xty = (int)(((uint32_t)rect * f.tx_magic) >> 20);
+        const int xtx = rect - xty * f.tiles_x;
+        const bool mapped = f.xg != 0;
+        if (mapped && rect >= f.nrect) return;
+        slice = mapped ? xslice : slice;
+        ty = mapped ? xty : ty;
+        tx = mapped ? xtx : tx;
     }
     if (d.N > 1) {
         n = ty / f.tiles_y;
@@ -88,34 +109,26 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     const int oy0 = ty * f.bh, ox0 = tx * f.bw;
     const int ry0 = oy0 * d.sh - d.pt, rx0 = ox0 * d.sw - d.pl;  // patch origin in the image (may be -pad)
 
-    // ---- constants of the finishing roles, requested first (they arrive under the K loop)
-    // pointwise: wave w finishes channels 8 (w & 3) + 4 half .. +3 of the slice, for every tile (with 8
-    // waves: waves 0-3 the even tiles, waves 4-7 the odd ones)
     const int nwaves = f.nwaves;  // 4 or 8
     const int fgrp = wave & 3;
-    const int pc = slice * 32 + 8 * fgrp + 4 * fhalf;
-    const int4 p_ai = *reinterpret_cast<const int4 *>(q.acc_init + pc);
-    const float4 p_mu = *reinterpret_cast<const float4 *>(q.mult + pc);
-    const float4 p_bi = *reinterpret_cast<const float4 *>(q.bias + pc);
-
-    const DwThreadConsts dwk = dw_load_consts(d, slice * 32, tid);  // depthwise constants, requested early
 
     // ---- pointwise: this wave's (tile, K part) pairs
     const int ks = f.ks;
     const int kpart = wave & (ks - 1);
-    const int mw = ks == 8 ? 0 : (ks == 4 ? wave >> 2 : (ks == 2 ? wave >> 1 : wave));  // wave group over tiles
-    const int mwn = nwaves / ks;                                                        // number of wave groups
+    const int mw = wave >> f.ks_log2;  // wave group over tiles
+    const int mwn = f.mwn;             // number of wave groups = nwaves / ks
     const int sub0 = kpart * f.nsw;
-    int nsw = f.nsub - sub0;
-    nsw = nsw < f.nsw ? nsw : f.nsw;  // may be <= 0 for a ragged last part
+    int nsw = NSW;
+    if constexpr (!EXACT) {
+        nsw = f.nsub - sub0;
+        nsw = nsw < f.nsw ? nsw : f.nsw;  // may be <= 0 for a ragged last part
+    }
 
-    const char *img = static_cast<const char *>(q.in) + (int64_t)n * q.H * q.W * q.C;
-    // weights: from the plan's fragment-ordered copy when there is one (one coalesced 1 KiB load per
-    // fragment), else 16 bytes per lane out of the [Cout][K] rows
-    const bool frag = q.w_frag != nullptr;
-    const char *wp = frag ? static_cast<const char *>(q.w_frag) + ((int64_t)slice * f.nsub + sub0) * 1024 + lane * 16
-                          : static_cast<const char *>(q.w) + (int64_t)(slice * 32 + frow) * q.kstride + fhalf * 16 + sub0 * 32;
-    const int wstep = frag ? 1024 : 32;
+    const char *img = static_cast<const char *>(q.in) + (n ? (int64_t)n * f.img_stride : (int64_t)0);
+    // weights: the plan's fragment-ordered copy (one coalesced 1 KiB load per fragment; every pointwise plan the pair test
+    // admits has one: conv_plan.hip `frag_copy`)
+    const char *wp = static_cast<const char *>(q.w_frag) + ((int64_t)slice * f.nsub + sub0) * 1024 + lane * 16;
+    constexpr int wstep = 1024;
     v4i fa[NSW];
 #pragma unroll
     for (int s = 0; s < NSW; ++s)
@@ -130,25 +143,47 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
             const int r = (int)(((uint32_t)j * f.rw_magic) >> 20);
             const int c = j - r * f.rw;
             int y = ry0 + r, x = rx0 + c;  // pixels outside the image: any valid address (never used)
-            y = y < 0 ? 0 : (y >= q.H ? q.H - 1 : y);
-            x = x < 0 ? 0 : (x >= q.W ? q.W - 1 : x);
+            y = max(0, min(y, q.H - 1));
+            x = max(0, min(x, q.W - 1));
             const char *px = img + (y * q.W + x) * q.C + fhalf * 16 + sub0 * 32;
 #pragma unroll
             for (int s = 0; s < NSW; ++s)
                 if (s < nsw) fb[i][s] = *reinterpret_cast<const v4i *>(px + s * 32);
         }
     }
+    // ---- constants of the finishing roles, requested BEHIND the fragments (round 6; they were first: "they arrive under the K
+    // loop" -- but a wave issues an instruction per ~5.8 cycles, and the nine loads with their address arithmetic stood ~60
+    // instructions = 0.17 us in front of the loads the MFMAs wait for)
+    // pointwise: wave w finishes channels 8 (w & 3) + 4 half .. +3 of the slice, for every tile (with 8
+    // waves: waves 0-3 the even tiles, waves 4-7 the odd ones)
+    const int pc = slice * 32 + 8 * fgrp + 4 * fhalf;
+    const int4 p_ai = *reinterpret_cast<const int4 *>(q.acc_init + pc);
+    const float4 p_mu = *reinterpret_cast<const float4 *>(q.mult + pc);
+    const float4 p_bi = *reinterpret_cast<const float4 *>(q.bias + pc);
+
+    const DwThreadConsts dwk = dw_load_consts(d, slice * 32, tid);  // depthwise constants
+
     v16i acc[MTW];
+    if constexpr (EXACT) {
+        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0;
-#pragma unroll
-    for (int s = 0; s < NSW; ++s) {
-        if (s < nsw) {
+        for (int s = 0; s < NSW; ++s) {  // (sub-step outermost: consecutive MFMAs go to different accumulators)
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
-                if (mw + i * mwn < f.mt) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s], fb[i][s], acc[i], 0, 0, 0);
+                if (mw + i * mwn < f.mt) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s], fb[i][s], s == 0 ? zero16 : acc[i], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) {
+            if (s < nsw) {
+#pragma unroll
+                for (int i = 0; i < MTW; ++i)
+                    if (mw + i * mwn < f.mt) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s], fb[i][s], acc[i], 0, 0, 0);
+            }
         }
     }
 
@@ -221,7 +256,7 @@ static bool shapes_pair(const ConvArgs &q, const ConvArgs &d)
     if (d.Kh != 3 || d.Kw != 3 || d.dh != 1 || d.dw != 1 || d.C != d.Co || d.C != q.Co) return false;
     if (d.H != q.Ho || d.W != q.Wo || d.N != q.N) return false;
     if (d.sh < 1 || d.sh > 2 || d.sw < 1 || d.sw > 2 || d.pt > 2 || d.pl > 2 || d.pt < 0 || d.pl < 0) return false;
-    if (q.C > 1024) return false;  // 8 sub-steps per wave at most
+    if (q.C > 1024 || !q.w_frag) return false;  // 8 sub-steps per wave at most; the kernel reads the fragment-ordered weights
     if ((int64_t)q.H * q.W * q.C >= ((int64_t)1 << 31)) return false;  // 32-bit offsets inside an image
     return true;
 }
@@ -278,6 +313,9 @@ static bool choose_rect(const ConvArgs &q, const ConvArgs &d, PwDwArgs &f)
     f.ks = ks;
     f.nsw = nsw;
     f.nsub = nsub;
+    f.ks_log2 = ks == 8 ? 3 : (ks == 4 ? 2 : (ks == 2 ? 1 : 0));
+    f.mwn = nwaves / ks;
+    f.img_stride = (int64_t)q.H * q.W * q.C;
     f.rw_magic = ((1u << 20) + f.rw - 1) / f.rw;
     f.bw_magic = ((1u << 20) + f.bw - 1) / f.bw;
     // Which XCDs share what.  HBM-side bytes of the launch ~ xg x activations + (8 / xg) x weights (every slice group
@@ -353,11 +391,17 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         grid = dim3((unsigned)(8 * f.spg * ((f.nrect + rpg - 1) / rpg)), 1, 1);
     }
     const size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
-#define SHL_PWDW(NSWV, MAXT)                                                                                         \
+#define SHL_PWDW2(NSWV, MAXT, EX)                                                                                    \
     do {                                                                                                       \
         static LdsOptIn opted_in;                                                                              \
-        if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT>)); \
-        hipLaunchKernelGGL((pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT>), grid, dim3(64 * f.nwaves), lds, s, f);                   \
+        if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT, EX>)); \
+        hipLaunchKernelGGL((pwdw_fused_kernel<PWDW_MTW, NSWV, MAXT, EX>), grid, dim3(64 * f.nwaves), lds, s, f);               \
+    } while (0)
+    // every wave with exactly NSWV sub-steps: the guard-free instantiation
+#define SHL_PWDW(NSWV, MAXT)                                           \
+    do {                                                              \
+        if (f.nsw == NSWV && f.nsub == f.ks * NSWV) SHL_PWDW2(NSWV, MAXT, true); \
+        else SHL_PWDW2(NSWV, MAXT, false);                            \
     } while (0)
     if (f.nsw <= 2)
         SHL_PWDW(2, 512);
@@ -366,6 +410,7 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
     else
         SHL_PWDW(8, 256);
 #undef SHL_PWDW
+#undef SHL_PWDW2
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }
