@@ -68,9 +68,14 @@ struct PwDwArgs {
 // 8-sub-step form needs more than the 256 registers a lane gets with two waves per SIMD).  EXACT: every wave has exactly NSW
 // sub-steps (K / 32 = ks NSW: every MobileNet pair but the first) -- no per-fragment guards, and the first MFMA of a tile takes
 // the constant 0 as its C operand instead of 16 zeroed registers per tile.
-template <int MTW, int NSW, int MAXT, bool EXACT>
+// KSV, TPW (both or neither; four waves): the K split and the tiles per wave as compile-time values -- mt = TPW 4 / KSV tiles, every
+// wave exactly TPW of them: no tile guards around the loads, the MFMAs and the LDS writes (four scalar instructions per MFMA in the
+// generic form), the sums over the K parts unrolled.  0: run-time values (uneven tile counts, eight waves).
+template <int MTW, int NSW, int MAXT, bool EXACT, int KSV = 0, int TPW = 0>
 __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
 {
+    static_assert((KSV == 0) == (TPW == 0) && (TPW == 0 || (TPW == MTW && EXACT)), "pwdw_fused: KSV and TPW come together, with MTW = TPW");
+    constexpr bool FIXED = TPW != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvArgs &q = f.pw;
     const ConvArgs &d = f.dw;
@@ -109,14 +114,15 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     const int oy0 = ty * f.bh, ox0 = tx * f.bw;
     const int ry0 = oy0 * d.sh - d.pt, rx0 = ox0 * d.sw - d.pl;  // patch origin in the image (may be -pad)
 
-    const int nwaves = f.nwaves;  // 4 or 8
+    const int nwaves = FIXED ? 4 : f.nwaves;  // 4 or 8
     const int fgrp = wave & 3;
 
     // ---- pointwise: this wave's (tile, K part) pairs
-    const int ks = f.ks;
+    const int ks = FIXED ? KSV : f.ks;
     const int kpart = wave & (ks - 1);
-    const int mw = wave >> f.ks_log2;  // wave group over tiles
-    const int mwn = f.mwn;             // number of wave groups = nwaves / ks
+    const int mw = wave >> (FIXED ? (KSV == 4 ? 2 : (KSV == 2 ? 1 : 0)) : f.ks_log2);  // wave group over tiles
+    const int mwn = FIXED ? 4 / (KSV ? KSV : 1) : f.mwn;                                // number of wave groups = nwaves / ks
+    const int mt = FIXED ? TPW * (4 / (KSV ? KSV : 1)) : f.mt;                          // tiles of the patch
     const int sub0 = kpart * f.nsw;
     int nsw = NSW;
     if constexpr (!EXACT) {
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int tile = mw + i * mwn;
-        if (tile < f.mt) {
+        if (FIXED || tile < mt) {
             int j = tile * 32 + frow;
             j = j < f.npx ? j : f.npx - 1;
             const int r = (int)(((uint32_t)j * f.rw_magic) >> 20);
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
         for (int s = 0; s < NSW; ++s) {  // (sub-step outermost: consecutive MFMAs go to different accumulators)
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
-                if (mw + i * mwn < f.mt) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s], fb[i][s], s == 0 ? zero16 : acc[i], 0, 0, 0);
+                if (FIXED || mw + i * mwn < mt) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s], fb[i][s], s == 0 ? zero16 : acc[i], 0, 0, 0);
         }
     } else {
 #pragma unroll
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
             if (s < nsw) {
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
-                    if (mw + i * mwn < f.mt) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s], fb[i][s], acc[i], 0, 0, 0);
+                    if (mw + i * mwn < mt) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s], fb[i][s], acc[i], 0, 0, 0);
             }
         }
     }
@@ -190,11 +196,11 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     if (q.debug & 256) return;  // ablation (tools/pair_bench.py): stop after loads + MFMA
     // ---- partial sums -> LDS: part[((tile * ks + kpart) * 4 + group) * 64 + lane] = 4 channels
     v4i *part = reinterpret_cast<v4i *>(smem);
-    uint32_t *patch = reinterpret_cast<uint32_t *>(smem + (size_t)f.mt * ks * 4096);  // [pixel][8 dwords]
+    uint32_t *patch = reinterpret_cast<uint32_t *>(smem + (size_t)mt * ks * 4096);  // [pixel][8 dwords]
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int tile = mw + i * mwn;
-        if (tile < f.mt) {
+        if (FIXED || tile < mt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 v4i v;
@@ -213,12 +219,13 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     // per MobileNetV1 pass.  (Four tiles per round through small arrays: 74.7 us -- the code grew more than the chain shrank.)
     {
         const int tstep = nwaves >> 2;
-        for (int tile = wave >> 2; tile < f.mt; tile += 2 * tstep) {
+        for (int tile = wave >> 2; tile < mt; tile += 2 * tstep) {
             const int tile1 = tile + tstep;
-            const bool two = tile1 < f.mt;
+            const bool two = tile1 < mt;
             const int t1 = two ? tile1 : tile;
             v4i v0 = part[((tile * ks) * 4 + fgrp) * 64 + lane];
             v4i v1 = part[((t1 * ks) * 4 + fgrp) * 64 + lane];
+#pragma unroll
             for (int k = 1; k < ks; ++k) {
                 v0 += part[((tile * ks + k) * 4 + fgrp) * 64 + lane];
                 v1 += part[((t1 * ks + k) * 4 + fgrp) * 64 + lane];
@@ -391,6 +398,12 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         grid = dim3((unsigned)(8 * f.spg * ((f.nrect + rpg - 1) / rpg)), 1, 1);
     }
     const size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
+    {
+        static const char *pr = getenv("SHL_MI355X_PWDW_PRINT");  // "1": the geometry of every launch (tools/dev)
+        if (pr && pr[0] == '1')
+            fprintf(stderr, "pwdw_fused %d->%d @%dx%d s%d: rect %dx%d, npx %d, mt %d, ks %d, nsw %d, nsub %d, mwn %d, xg %d, grid %u\n", q.C, q.Co, d.H, d.W,
+                    d.sh, f.bh, f.bw, f.npx, f.mt, f.ks, f.nsw, f.nsub, f.mwn, f.xg, grid.x * grid.y * grid.z);
+    }
 #define SHL_PWDW2(NSWV, MAXT, EX)                                                                                    \
     do {                                                                                                       \
         static LdsOptIn opted_in;                                                                              \
@@ -403,6 +416,26 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         if (f.nsw == NSWV && f.nsub == f.ks * NSWV) SHL_PWDW2(NSWV, MAXT, true); \
         else SHL_PWDW2(NSWV, MAXT, false);                            \
     } while (0)
+    // the fully specialised forms: four waves, every wave exactly NSWV sub-steps and TPWV tiles, K split KSV (MobileNetV1 at batch
+    // 1: nine of its twelve pairs)
+#define SHL_PWDW_FIXED(NSWV, KSV, TPWV)                                                                                  \
+    if (f.nwaves == 4 && f.nsw == NSWV && f.nsub == KSV * NSWV && f.ks == KSV && f.mt == TPWV * (4 / KSV)) {            \
+        static LdsOptIn opted_in;                                                                                       \
+        if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(pwdw_fused_kernel<TPWV, NSWV, 512, true, KSV, TPWV>)); \
+        hipLaunchKernelGGL((pwdw_fused_kernel<TPWV, NSWV, 512, true, KSV, TPWV>), grid, dim3(256), lds, s, f);             \
+        SHL_HIP(hipGetLastError());                                                                                     \
+        return SHL_MI355X_OK;                                                                                           \
+    }
+    static const char *nofix = getenv("SHL_MI355X_PWDW_GENERIC");  // "1": the run-time form everywhere (A/B, tests)
+    if (!(nofix && nofix[0] == '1')) {
+        SHL_PWDW_FIXED(4, 4, 2)
+        SHL_PWDW_FIXED(4, 4, 1)
+        SHL_PWDW_FIXED(2, 4, 2)
+        SHL_PWDW_FIXED(2, 4, 1)
+        SHL_PWDW_FIXED(2, 2, 2)
+        SHL_PWDW_FIXED(2, 2, 1)
+    }
+#undef SHL_PWDW_FIXED
     if (f.nsw <= 2)
         SHL_PWDW(2, 512);
     else if (f.nsw <= 4)
