@@ -302,6 +302,15 @@ __device__ __forceinline__ uint32_t requant4_i8_rt(int s0, int s1, int s2, int s
     return a.div_exact ? requant4_i8_t<3>(s0, s1, s2, s3, m, b, a) : requant4_i8_t<0, kHwDiv>(s0, s1, s2, s3, m, b, a);
 }
 
+// EPI < 0: the wave-uniform run-time choice; else the one flavour (kernels whose latency is their instruction count and code size
+// instantiate the flavours they meet most: pwdw_fused.hip)
+template <int EPI>
+__device__ __forceinline__ uint32_t requant4_i8_sel(int s0, int s1, int s2, int s3, const float4 &m, const float4 &b, const ConvArgs &a)
+{
+    if constexpr (EPI < 0) return requant4_i8_rt(s0, s1, s2, s3, m, b, a);
+    else return requant4_i8_t<EPI>(s0, s1, s2, s3, m, b, a);
+}
+
 // run-time dispatch of the same code (kernels that are not specialised on EPI)
 template <bool kHwDiv = false>
 __device__ __forceinline__ int requant_i8_fast(int32_t S, float mult, float bias_f, const ConvArgs &a)

@@ -48,6 +48,7 @@ __device__ __forceinline__ DwThreadConsts dw_load_consts(const ConvArgs &d, int 
 // image), byte transposes + v_dot4_i32_i8 against the plan's dot4-packed weights, requantise, one dword
 // store.  `threads` = workgroup size (a multiple of 8).  Restates shl_ref_depthwise_conv2d_quant
 // (source/reference/convolution.c:416-460) + relu variants.
+template <int EPI = -1>  // the depthwise layer's epilogue flavour (common.h), -1: chosen at run time
 __device__ __forceinline__ void depthwise_from_patch(const ConvArgs &d, const uint32_t *patch, const DwPatchGeom &g,
                                                      const DwThreadConsts &k, int tid, int threads)
 {
@@ -88,7 +89,7 @@ __device__ __forceinline__ void depthwise_from_patch(const ConvArgs &d, const ui
             a4[ch] = __builtin_amdgcn_sdot4((int)t2, (int)wk[3 * ch + 2], a4[ch], false);
         }
         const int64_t o = (((int64_t)g.n * d.Ho + oy) * d.Wo + ox) * d.C + dc;
-        *reinterpret_cast<uint32_t *>(out + o) = requant4_i8_rt(a4[0], a4[1], a4[2], a4[3], d_mu, d_bi, d);
+        *reinterpret_cast<uint32_t *>(out + o) = requant4_i8_sel<EPI>(a4[0], a4[1], a4[2], a4[3], d_mu, d_bi, d);
     }
 }
 

@@ -68,10 +68,15 @@ struct PwDwArgs {
 // 8-sub-step form needs more than the 256 registers a lane gets with two waves per SIMD).  EXACT: every wave has exactly NSW
 // sub-steps (K / 32 = ks NSW: every MobileNet pair but the first) -- no per-fragment guards, and the first MFMA of a tile takes
 // the constant 0 as its C operand instead of 16 zeroed registers per tile.
-// KSV, TPW (both or neither; four waves): the K split and the tiles per wave as compile-time values -- mt = TPW 4 / KSV tiles, every
-// wave exactly TPW of them: no tile guards around the loads, the MFMAs and the LDS writes (four scalar instructions per MFMA in the
-// generic form), the sums over the K parts unrolled.  0: run-time values (uneven tile counts, eight waves).
-template <int MTW, int NSW, int MAXT, bool EXACT, int KSV = 0, int TPW = 0>
+// KSV, TPW (both or neither; four waves): the K split and the tiles per wave as compile-time values -- every wave runs exactly TPW
+// tiles, i.e. the patch is treated as TPW 4 / KSV tiles (tiles past the real mt read the patch's last pixel and park their sums
+// in LDS slots nothing reads: the host sizes the partial-sum area for the padded count): no tile guards around the loads, the
+// MFMAs and the LDS writes (four scalar instructions per MFMA in the generic form), the sums over the K parts unrolled.
+// 0: run-time values (eight waves, deeper patches).
+// EMT: the patch has exactly TPW 4 / KSV tiles (the finishing loop's trip count is a compile-time value as well: 0.1 us per launch).
+// EPQ / EPD: the two layers' epilogue flavours (common.h; -1: chosen at run time) -- with all four flavours of three requantisation
+// sites inline the kernel is 1 500 instructions, a third of which one launch runs, fetched cold by every workgroup.
+template <int MTW, int NSW, int MAXT, bool EXACT, int KSV = 0, int TPW = 0, bool EMT = false, int EPQ = -1, int EPD = -1>
 __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
 {
     static_assert((KSV == 0) == (TPW == 0) && (TPW == 0 || (TPW == MTW && EXACT)), "pwdw_fused: KSV and TPW come together, with MTW = TPW");
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     const int kpart = wave & (ks - 1);
     const int mw = wave >> (FIXED ? (KSV == 4 ? 2 : (KSV == 2 ? 1 : 0)) : f.ks_log2);  // wave group over tiles
     const int mwn = FIXED ? 4 / (KSV ? KSV : 1) : f.mwn;                                // number of wave groups = nwaves / ks
-    const int mt = FIXED ? TPW * (4 / (KSV ? KSV : 1)) : f.mt;                          // tiles of the patch
+    const int mtp = FIXED ? TPW * (4 / (KSV ? KSV : 1)) : f.mt;                         // tiles the waves run (padded)
+    const int mt = (FIXED && EMT) ? mtp : f.mt;                                         // tiles of the patch
     const int sub0 = kpart * f.nsw;
     int nsw = NSW;
     if constexpr (!EXACT) {
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     if (q.debug & 256) return;  // ablation (tools/pair_bench.py): stop after loads + MFMA
     // ---- partial sums -> LDS: part[((tile * ks + kpart) * 4 + group) * 64 + lane] = 4 channels
     v4i *part = reinterpret_cast<v4i *>(smem);
-    uint32_t *patch = reinterpret_cast<uint32_t *>(smem + (size_t)mt * ks * 4096);  // [pixel][8 dwords]
+    uint32_t *patch = reinterpret_cast<uint32_t *>(smem + (size_t)mtp * ks * 4096);  // [pixel][8 dwords]
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int tile = mw + i * mwn;
@@ -219,22 +225,28 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     // per MobileNetV1 pass.  (Four tiles per round through small arrays: 74.7 us -- the code grew more than the chain shrank.)
     {
         const int tstep = nwaves >> 2;
-        for (int tile = wave >> 2; tile < mt; tile += 2 * tstep) {
+        for (int tile = FIXED ? 0 : wave >> 2; tile < mt; tile += 2 * tstep) {  // (four waves: wave >> 2 = 0)
             const int tile1 = tile + tstep;
-            const bool two = tile1 < mt;
-            const int t1 = two ? tile1 : tile;
+            const int j0 = tile * 32 + frow;
             v4i v0 = part[((tile * ks) * 4 + fgrp) * 64 + lane];
-            v4i v1 = part[((t1 * ks) * 4 + fgrp) * 64 + lane];
+            if (tile1 < mt) {
+                v4i v1 = part[((tile1 * ks) * 4 + fgrp) * 64 + lane];
 #pragma unroll
-            for (int k = 1; k < ks; ++k) {
-                v0 += part[((tile * ks + k) * 4 + fgrp) * 64 + lane];
-                v1 += part[((t1 * ks + k) * 4 + fgrp) * 64 + lane];
+                for (int k = 1; k < ks; ++k) {
+                    v0 += part[((tile * ks + k) * 4 + fgrp) * 64 + lane];
+                    v1 += part[((tile1 * ks + k) * 4 + fgrp) * 64 + lane];
+                }
+                const uint32_t pk0 = requant4_i8_sel<EPQ>(v0[0] + p_ai.x, v0[1] + p_ai.y, v0[2] + p_ai.z, v0[3] + p_ai.w, p_mu, p_bi, q);
+                const uint32_t pk1 = requant4_i8_sel<EPQ>(v1[0] + p_ai.x, v1[1] + p_ai.y, v1[2] + p_ai.z, v1[3] + p_ai.w, p_mu, p_bi, q);
+                const int j1 = tile1 * 32 + frow;
+                if (j0 < f.npx) patch[dw_patch_slot(j0, 2 * fgrp + fhalf)] = pk0;
+                if (j1 < f.npx) patch[dw_patch_slot(j1, 2 * fgrp + fhalf)] = pk1;
+            } else {  // the odd last tile alone (it used to be computed twice: ~50 instructions of a wave that issues one per ~5.8 cycles)
+#pragma unroll
+                for (int k = 1; k < ks; ++k) v0 += part[((tile * ks + k) * 4 + fgrp) * 64 + lane];
+                const uint32_t pk0 = requant4_i8_sel<EPQ>(v0[0] + p_ai.x, v0[1] + p_ai.y, v0[2] + p_ai.z, v0[3] + p_ai.w, p_mu, p_bi, q);
+                if (j0 < f.npx) patch[dw_patch_slot(j0, 2 * fgrp + fhalf)] = pk0;
             }
-            const uint32_t pk0 = requant4_i8_rt(v0[0] + p_ai.x, v0[1] + p_ai.y, v0[2] + p_ai.z, v0[3] + p_ai.w, p_mu, p_bi, q);
-            const uint32_t pk1 = requant4_i8_rt(v1[0] + p_ai.x, v1[1] + p_ai.y, v1[2] + p_ai.z, v1[3] + p_ai.w, p_mu, p_bi, q);
-            const int j0 = tile * 32 + frow, j1 = t1 * 32 + frow;
-            if (j0 < f.npx) patch[dw_patch_slot(j0, 2 * fgrp + fhalf)] = pk0;
-            if (two && j1 < f.npx) patch[dw_patch_slot(j1, 2 * fgrp + fhalf)] = pk1;
         }
     }
     __syncthreads();
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     DwPatchGeom g;
     g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic;
     g.oy0 = oy0, g.ox0 = ox0, g.ry0 = ry0, g.rx0 = rx0, g.n = n, g.ch0 = slice * 32;
-    depthwise_from_patch(d, patch, g, dwk, tid, nwaves * 64);
+    depthwise_from_patch<EPD>(d, patch, g, dwk, tid, nwaves * 64);
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -397,7 +409,7 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         const int rpg = 8 / f.xg;
         grid = dim3((unsigned)(8 * f.spg * ((f.nrect + rpg - 1) / rpg)), 1, 1);
     }
-    const size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
+    size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
     {
         static const char *pr = getenv("SHL_MI355X_PWDW_PRINT");  // "1": the geometry of every launch (tools/dev)
         if (pr && pr[0] == '1')
@@ -418,11 +430,27 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
     } while (0)
     // the fully specialised forms: four waves, every wave exactly NSWV sub-steps and TPWV tiles, K split KSV (MobileNetV1 at batch
     // 1: nine of its twelve pairs)
+    // ... with both layers' epilogues compiled in for the two flavours whole models come in: clamp epilogues with power-of-two
+    // output scales (3) and with general scales (0)
+    const int epq = (q.act != SHL_MI355X_ACT_NONE && !q.act_clamp) ? -1 : (q.div_exact ? 3 : 0);
+    const int epd = (d.act != SHL_MI355X_ACT_NONE && !d.act_clamp) ? -1 : (d.div_exact ? 3 : 0);
+#define SHL_PWDW_EPI(TPWV, NSWV, KSV, EMTV)                                                                              \
+    do {                                                                                                                \
+        if (epq == 3 && epd == 3)                                                                                       \
+            hipLaunchKernelGGL((pwdw_fused_kernel<TPWV, NSWV, 512, true, KSV, TPWV, EMTV, 3, 3>), grid, dim3(256), lds, s, f); \
+        else if (epq == 0 && epd == 0)                                                                                  \
+            hipLaunchKernelGGL((pwdw_fused_kernel<TPWV, NSWV, 512, true, KSV, TPWV, EMTV, 0, 0>), grid, dim3(256), lds, s, f); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((pwdw_fused_kernel<TPWV, NSWV, 512, true, KSV, TPWV, EMTV>), grid, dim3(256), lds, s, f);    \
+    } while (0)
 #define SHL_PWDW_FIXED(NSWV, KSV, TPWV)                                                                                  \
-    if (f.nwaves == 4 && f.nsw == NSWV && f.nsub == KSV * NSWV && f.ks == KSV && f.mt == TPWV * (4 / KSV)) {            \
-        static LdsOptIn opted_in;                                                                                       \
-        if (lds > 64 * 1024) lds_opt_in(opted_in, reinterpret_cast<const void *>(pwdw_fused_kernel<TPWV, NSWV, 512, true, KSV, TPWV>)); \
-        hipLaunchKernelGGL((pwdw_fused_kernel<TPWV, NSWV, 512, true, KSV, TPWV>), grid, dim3(256), lds, s, f);             \
+    if (f.nwaves == 4 && f.nsw == NSWV && f.nsub == KSV * NSWV && f.ks == KSV && f.mt <= TPWV * (4 / KSV) &&            \
+        f.mt > (TPWV - 1) * (4 / KSV)) {                                                                                \
+        lds = (size_t)(TPWV * (4 / KSV)) * f.ks * 4096 + (size_t)f.mt * 32 * 32; /* partial sums of the padded tiles */  \
+        if (f.mt == TPWV * (4 / KSV))                                                                                   \
+            SHL_PWDW_EPI(TPWV, NSWV, KSV, true);                                                                        \
+        else                                                                                                            \
+            SHL_PWDW_EPI(TPWV, NSWV, KSV, false);                                                                       \
         SHL_HIP(hipGetLastError());                                                                                     \
         return SHL_MI355X_OK;                                                                                           \
     }
@@ -434,8 +462,13 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         SHL_PWDW_FIXED(2, 4, 1)
         SHL_PWDW_FIXED(2, 2, 2)
         SHL_PWDW_FIXED(2, 2, 1)
+        SHL_PWDW_FIXED(2, 1, 1)
+        SHL_PWDW_FIXED(2, 1, 2)
+        SHL_PWDW_FIXED(1, 1, 1)
+        SHL_PWDW_FIXED(1, 1, 2)
     }
 #undef SHL_PWDW_FIXED
+#undef SHL_PWDW_EPI
     if (f.nsw <= 2)
         SHL_PWDW(2, 512);
     else if (f.nsw <= 4)
