@@ -27,6 +27,10 @@ struct StemDwArgs {
     uint32_t rw_magic, bw_magic;  // j / rw == (j * rw_magic) >> 20, same for bw (j < 4096)
 };
 
+// EPQ / EPD: the two layers' epilogue flavours (common.h; -1: chosen at run time).  At batch 1 a launch is as long as one wave's
+// instruction stream -- fetched cold by every workgroup --, and four flavours inline at five requantisation sites are most of
+// the kernel's code (pwdw_fused.hip has the measurement).
+template <int EPQ, int EPD>
 __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
             const int4 ai = *reinterpret_cast<const int4 *>(t_tab + c);
             const float4 mu = *reinterpret_cast<const float4 *>(t_tab + 32 + c);
             const float4 bi = *reinterpret_cast<const float4 *>(t_tab + 64 + c);
-            const uint32_t pk = requant4_i8_rt(acc[4 * v] + ai.x, acc[4 * v + 1] + ai.y, acc[4 * v + 2] + ai.z,
+            const uint32_t pk = requant4_i8_sel<EPQ>(acc[4 * v] + ai.x, acc[4 * v + 1] + ai.y, acc[4 * v + 2] + ai.z,
                                                acc[4 * v + 3] + ai.w, mu, bi, q);
             if (valid) patch[dw_patch_slot(j, c >> 2)] = pk;
         }
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
     DwPatchGeom g;
     g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic;
     g.oy0 = oy0, g.ox0 = ox0, g.ry0 = ry0, g.rx0 = rx0, g.n = n, g.ch0 = 0;
-    depthwise_from_patch(d, patch, g, dwk, tid, 256);
+    depthwise_from_patch<EPD>(d, patch, g, dwk, tid, 256);
 }
 
 static bool stemdw_geometry(const ConvArgs &q, const ConvArgs &d, StemDwArgs &f)
@@ -155,7 +159,11 @@ int launch_stemdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
     }
     const dim3 grid((unsigned)f.tiles_x, (unsigned)(f.tiles_y * d.N));
     const size_t lds = (size_t)(7 * 32 + 96) * 4 + (size_t)f.npx * 32;
-    hipLaunchKernelGGL(stemdw_fused_kernel, grid, dim3(256), lds, s, f);
+    const int epq = (q.act != SHL_MI355X_ACT_NONE && !q.act_clamp) ? -1 : (q.div_exact ? 3 : 0);
+    const int epd = (d.act != SHL_MI355X_ACT_NONE && !d.act_clamp) ? -1 : (d.div_exact ? 3 : 0);
+    if (epq == 3 && epd == 3) hipLaunchKernelGGL((stemdw_fused_kernel<3, 3>), grid, dim3(256), lds, s, f);
+    else if (epq == 0 && epd == 0) hipLaunchKernelGGL((stemdw_fused_kernel<0, 0>), grid, dim3(256), lds, s, f);
+    else hipLaunchKernelGGL((stemdw_fused_kernel<-1, -1>), grid, dim3(256), lds, s, f);
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }
