@@ -564,6 +564,10 @@ int launch_dwconv_mfma(const ConvArgs &a, hipStream_t s);
 // pointwise int8 NHWC with the weight slice in registers, for bandwidth-bound sizes (conv1x1_stream.hip)
 bool conv1x1_resident_pick(const ConvArgs &a);   // conv1x1_resident.hip: deep-K pointwise, persistent workgroups, weights in registers
 int launch_conv1x1_resident(const ConvArgs &a, hipStream_t s);
+bool conv1x1_latency_pick(const ConvArgs &a);    // conv1x1_latency.hip: deep-K pointwise on maps of <= 64 pixels at small batches (one straight-line wave stream)
+int launch_conv1x1_latency(const ConvArgs &a, hipStream_t s);
+bool conv1x1_pool_fusable(const ConvArgs &a);    // ... with global_avgpool2d behind it in the same launch
+int launch_conv1x1_pool(const ConvArgs &a, void *pool_out, float si, float zi, float so, float zo, int store_map, hipStream_t s);
 bool conv1x1_stream_pick(const ConvArgs &a);
 int launch_conv1x1_stream(const ConvArgs &a, hipStream_t s);
 int launch_dwconv_channel(const ConvArgs &a, hipStream_t s);  // dwconv_channel.hip

@@ -1034,6 +1034,10 @@ int launch_conv_igemm(const ConvArgs &a, int dtype, int layout, hipStream_t s)
         igemm_note_family("resident1x1");
         return launch_conv1x1_resident(a, s);
     }
+    if (i8 && !variant_override()[0] && conv1x1_latency_pick(a)) {
+        igemm_note_family("latency1x1");
+        return launch_conv1x1_latency(a, s);
+    }
     if (i8 && !variant_override()[0] && conv1x1_stream_pick(a)) {
         igemm_note_family("stream1x1");
         return launch_conv1x1_stream(a, s);

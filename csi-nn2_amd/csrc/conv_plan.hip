@@ -514,6 +514,7 @@ static int plan_create_impl(const struct shl_mi355x_conv_desc *desc, const void 
             }
             if (conv1x1_stream_pick(probe)) p->kernel_name = "conv1x1_stream_i8_mfma32x32x32";
             if (conv1x1_resident_pick(probe)) p->kernel_name = "conv1x1_resident_i8_mfma32x32x32";
+            if (conv1x1_latency_pick(probe)) p->kernel_name = "conv1x1_latency_i8_mfma32x32x32";
         }
     } else if (algo == SHL_MI355X_ALGO_STEM) {
         w_bytes = stem_weight_bytes(d);
