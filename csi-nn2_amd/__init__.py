@@ -211,6 +211,8 @@ def load_hip():
         "shl_mi355x_pwdw_form": (C.c_int, [vp, vp, i32]),
         "shl_mi355x_pool_conv_fusable": (C.c_int, [vp, i32, i32]),
         "shl_mi355x_pool_conv_forward": (C.c_int, [vp, vp, vp, i32, i32, f32, i32, f32, i32, vp]),
+        "shl_mi355x_conv_pool_fusable": (C.c_int, [vp, i32]),
+        "shl_mi355x_conv_pool_forward": (C.c_int, [vp, vp, vp, vp, i32, f32, i32, f32, i32, vp]),
         "shl_mi355x_conv_plan_set_no_stream_consumer": (C.c_int, [vp, i32]),
         "shl_mi355x_pwdw_forward": (C.c_int, [vp, vp, vp, vp, i32, vp]),
         "shl_mi355x_relu_i8": (C.c_int, [vp, vp, sz, f32, i32, f32, i32, i32, vp]),

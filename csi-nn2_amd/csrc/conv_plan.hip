@@ -1069,6 +1069,41 @@ int shl_mi355x_pool_conv_forward(const shl_mi355x_conv_plan *plan, const void *i
     return launch_pool_gemv(a, pixels, in_scale, in_zp, mid_scale, mid_zp, (hipStream_t)stream);
 }
 
+/* pointwise 1x1 + the global_avgpool2d consuming it, fused into one launch (conv1x1_latency.hip) */
+int shl_mi355x_conv_pool_fusable(const shl_mi355x_conv_plan *plan, int32_t batch)
+{
+    using namespace shl;
+    if (!plan || batch <= 0) return 0;
+    const char *sel = getenv("SHL_MI355X_CONVPOOL");  // "0": keep the two launches (read per call: tests, A/B)
+    if (sel && sel[0] == '0') return 0;
+    if (plan->desc.dtype != SHL_MI355X_I8 || plan->desc.layout != SHL_MI355X_NHWC || plan->algo != SHL_MI355X_ALGO_IGEMM) return 0;
+    if (igemm_env_override()) return 0;
+    ConvArgs a;
+    static char dummy[16];
+    if (fill_args(plan, dummy, dummy, batch, a) != SHL_MI355X_OK) return 0;
+    return conv1x1_pool_fusable(a) ? 1 : 0;
+}
+
+int shl_mi355x_conv_pool_forward(const shl_mi355x_conv_plan *plan, const void *input_dev, void *map_dev, void *pool_dev, int32_t batch,
+                                 float mid_scale, int32_t mid_zp, float out_scale, int32_t out_zp, void *stream)
+{
+    using namespace shl;
+    if (!plan || !input_dev || !pool_dev) {
+        set_error("conv_pool_forward: NULL argument");
+        return SHL_MI355X_EINVAL;
+    }
+    if (!shl_mi355x_conv_pool_fusable(plan, batch)) {
+        set_error("conv_pool_forward: the pair does not qualify for the fused kernel");
+        return SHL_MI355X_ENOTSUP;
+    }
+    ConvArgs a;
+    static char dummy[16];
+    int rc = fill_args(plan, input_dev, map_dev ? map_dev : dummy, batch, a);
+    if (rc != SHL_MI355X_OK) return rc;
+    if (a.M == 0) return SHL_MI355X_OK;
+    return launch_conv1x1_pool(a, pool_dev, mid_scale, (float)mid_zp, out_scale, (float)out_zp, map_dev ? 1 : 0, (hipStream_t)stream);
+}
+
 /* pointwise 1x1 + the depthwise 3x3 consuming it, fused into one launch */
 int shl_mi355x_pwdw_form(const shl_mi355x_conv_plan *pw, const shl_mi355x_conv_plan *dw, int32_t batch)
 {

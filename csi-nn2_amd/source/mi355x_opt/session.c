@@ -245,6 +245,21 @@ static void plan_fusion(struct dev_session *ds, struct shl_ref_graph *g)
                 continue;
             }
         }
+        /* 1x1 convolution -> global_avgpool2d, the pooled tensor being all anything reads of it: one launch
+         * (csrc/conv1x1_latency.hip: the workgroup of a channel slice holds the whole map) */
+        if (is_conv_op(a->type) && b->type == CSINN_OP_GLOBAL_AVGPOOL2D && consumers_of(g, mid) == 1) {
+            struct csinn_tensor *cin = a->in[0]->data, *pmid = mid->data, *pout = b->out[0]->data;
+            struct csinn_pool_params *pp = b->data;
+            shl_mi355x_conv_plan *pa = shl_mi355x_registry_get(a->data);
+            if (pa && pp->base.layout == CSINN_LAYOUT_NHWC && pmid->dim_count == 4 && pmid->dtype == CSINN_DTYPE_INT8 && pmid->qinfo &&
+                pout->qinfo && pmid->quant_channel <= 1 && pout->quant_channel <= 1 &&
+                shl_mi355x_conv_pool_fusable(pa, cin->dim[0])) {
+                ds->fused[i] = 4;
+                ds->npool++;
+                i = j;
+                continue;
+            }
+        }
         /* pointwise -> depthwise (latency form, small batches) or depthwise -> pointwise (bandwidth form, large
          * batches: csrc/dwpw_stream.hip); shl_mi355x_pwdw_fusable tells the orders apart by the plans */
         const int pw_dw = (is_conv_op(a->type) && is_dw_op(b->type)) || (is_dw_op(a->type) && is_conv_op(b->type));
@@ -287,6 +302,16 @@ static int enqueue_layers(struct dev_session *ds, struct shl_ref_graph *g)
                                                   pmid->qinfo->scale, pmid->qinfo->zero_point, ds->stream);
             rc = st == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
             i = j + folded2;
+        } else if (ds->fused && ds->fused[i] == 4) { /* 1x1 convolution (+ folded activation) + global_avgpool2d */
+            const int j = i + 1 + folded;
+            struct shl_node *nx = g->layer[j];
+            struct dev_tensor *out2 = lookup(ds, nx->out[0]);
+            struct csinn_tensor *pmid = nx->in[0]->data, *pout = nx->out[0]->data;
+            int st = shl_mi355x_conv_pool_forward(shl_mi355x_registry_get(n->data), in->dev, NULL, out2->dev, in->shadow.dim[0],
+                                                  pmid->qinfo->scale, pmid->qinfo->zero_point, pout->qinfo->scale,
+                                                  pout->qinfo->zero_point, ds->stream);
+            rc = st == SHL_MI355X_OK ? CSINN_TRUE : CSINN_FALSE;
+            i = j;
         } else if (ds->fused && ds->fused[i]) {
             const int j = i + 1 + folded;
             struct shl_node *nx = g->layer[j];

@@ -276,6 +276,16 @@ int shl_mi355x_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_
 int shl_mi355x_pool_conv_fusable(const shl_mi355x_conv_plan *plan, int32_t batch, int32_t pixels);
 int shl_mi355x_pool_conv_forward(const shl_mi355x_conv_plan *plan, const void *input_dev, void *output_dev, int32_t batch,
                                  int32_t pixels, float in_scale, int32_t in_zp, float mid_scale, int32_t mid_zp, void *stream);
+/* The other order at the end of a classifier's body: a pointwise 1x1 convolution (int8 NHWC, a map of at most 64 pixels, 256 / 512 /
+ * 1024 input channels) + the global_avgpool2d that consumes it, as ONE launch (csrc/conv1x1_latency.hip: the workgroup that owns a
+ * 32-channel slice of an image holds all of its pixels, so it pools them right away).  `map_dev` receives the convolution's own
+ * output tensor and may be NULL when only the pooled tensor is read; (mid_scale, mid_zp) is the convolution's output record (= the
+ * pooling layer's input record), (out_scale, out_zp) the pooled tensor's.  Bit-identical to shl_mi355x_conv_forward followed by
+ * shl_mi355x_global_avgpool2d (source/reference/convolution.c:370-400, global_averagepool.c:46-50, averagepool.c:21-119).
+ * _fusable: 1 when the plan and the batch qualify (SHL_MI355X_CONVPOOL=0 turns it off). */
+int shl_mi355x_conv_pool_fusable(const shl_mi355x_conv_plan *plan, int32_t batch);
+int shl_mi355x_conv_pool_forward(const shl_mi355x_conv_plan *plan, const void *input_dev, void *map_dev, void *pool_dev, int32_t batch,
+                                 float mid_scale, int32_t mid_zp, float out_scale, int32_t out_zp, void *stream);
 /* A hint from the owner of the graph: this depthwise layer's output does NOT feed a pointwise layer the bandwidth form
  * (depthwise -> pointwise in one launch, large batches) takes -- the latency form (pointwise -> depthwise) then keeps the
  * layer instead of yielding it (shl_mi355x_pwdw_fusable asks plan pairs, it cannot see a layer's consumer). */

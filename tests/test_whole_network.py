@@ -247,6 +247,8 @@ def test_mobilenetv1_session_equals_the_oracle_model(gpu, dtype, layout):
     fe, hip, opt, dev = gpu
     ms = wl.ModelSession(fe, pkg.API_MI355X, dtype, layout)
     assert opt.shl_mi355x_session_is_device_resident(ms.sess) == 2
+    # int8 NHWC: the last pointwise layer runs the global_avgpool2d behind it in its own launch (csrc/conv1x1_latency.hip)
+    assert opt.shl_mi355x_session_fused_pools(ms.sess) == (1 if dtype == "int8" else 0)
     for k in range(2):
         x = ms.synthetic_input(k)
         got = ms.run(x).reshape(-1)
