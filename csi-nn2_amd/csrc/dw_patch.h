@@ -60,7 +60,7 @@ __device__ __forceinline__ void depthwise_from_patch(const ConvArgs &d, const ui
     const uint32_t zp4 = (uint32_t)(d.in_zp & 0xff) * 0x01010101u;
     const uint32_t wk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
     const int nout = g.bh * g.bw;
-    int8_t *out = static_cast<int8_t *>(d.out);
+    int8_t *const out_img = static_cast<int8_t *>(d.out) + (int64_t)g.n * d.Ho * d.Wo * d.C;
     for (int po = tid >> 3; po < nout; po += threads >> 3) {
         const int oyl = (int)(((uint32_t)po * g.bw_magic) >> 20);
         const int oxl = po - oyl * g.bw;
@@ -88,8 +88,10 @@ __device__ __forceinline__ void depthwise_from_patch(const ConvArgs &d, const ui
             a4[ch] = __builtin_amdgcn_sdot4((int)t1[ch], (int)wk[3 * ch + 1], a4[ch], false);
             a4[ch] = __builtin_amdgcn_sdot4((int)t2, (int)wk[3 * ch + 2], a4[ch], false);
         }
-        const int64_t o = (((int64_t)g.n * d.Ho + oy) * d.Wo + ox) * d.C + dc;
-        *reinterpret_cast<uint32_t *>(out + o) = requant4_i8_sel<EPI>(a4[0], a4[1], a4[2], a4[3], d_mu, d_bi, d);
+        // (the image's base is wave-uniform 64-bit arithmetic on the scalar unit; inside an image 32 bits address every byte:
+        // the callers admit images below 2 GiB)
+        const uint32_t o = (uint32_t)((oy * d.Wo + ox) * d.C + dc);
+        *reinterpret_cast<uint32_t *>(out_img + o) = requant4_i8_sel<EPI>(a4[0], a4[1], a4[2], a4[3], d_mu, d_bi, d);
     }
 }
 

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     asm volatile("" ::"s"(f.bh), "s"(f.bw), "s"(f.rw), "s"(f.npx), "s"(f.mt), "s"(f.ks), "s"(f.nsw), "s"(f.nsub), "s"(f.rw_magic),
                  "s"(f.ks_log2), "s"(f.mwn), "s"(f.img_stride));
     asm volatile("" ::"s"(q.in), "s"(q.w_frag), "s"(q.H), "s"(q.W), "s"(q.C), "s"(d.sh), "s"(d.sw), "s"(d.pt), "s"(d.pl), "s"(d.N));
+    // (only what stands in front of the fragment loads: with the epilogue's and the depthwise phase's arguments in the batch as well the
+    // pass got 0.5 us SLOWER -- those loads hide under the fragments' latency where the compiler puts them)
     int slice = blockIdx.x, tx = blockIdx.y, ty = blockIdx.z, n = 0;
     {
         // (computed whether or not the grid is XCD-mapped and then selected: inside `if (f.xg)` the fields below were fetched
@@ -277,6 +279,7 @@ static bool shapes_pair(const ConvArgs &q, const ConvArgs &d)
     if (d.sh < 1 || d.sh > 2 || d.sw < 1 || d.sw > 2 || d.pt > 2 || d.pl > 2 || d.pt < 0 || d.pl < 0) return false;
     if (q.C > 1024 || !q.w_frag) return false;  // 8 sub-steps per wave at most; the kernel reads the fragment-ordered weights
     if ((int64_t)q.H * q.W * q.C >= ((int64_t)1 << 31)) return false;  // 32-bit offsets inside an image
+    if ((int64_t)d.Ho * d.Wo * d.C >= ((int64_t)1 << 31)) return false;  // ... of the output as well (dw_patch.h)
     return true;
 }
 

@@ -36,6 +36,13 @@ __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvArgs &q = f.st;
     const ConvArgs &d = f.dw;
+    // the kernel arguments in one batch of scalar loads in front of the first branch (pwdw_fused.hip)
+    asm volatile("" ::"s"(q.in), "s"(q.w), "s"(q.acc_init), "s"(q.mult), "s"(q.bias), "s"(q.H), "s"(q.W), "s"(q.Ho), "s"(q.Wo), "s"(q.sh),
+                 "s"(q.sw), "s"(q.pt), "s"(q.pl), "s"(q.dh), "s"(q.dw), "s"(q.in_zp));
+    asm volatile("" ::"s"(f.bh), "s"(f.bw), "s"(f.tiles_y), "s"(f.rw), "s"(f.npx), "s"(f.rw_magic), "s"(f.bw_magic), "s"(d.N), "s"(d.sh),
+                 "s"(d.sw), "s"(d.pt), "s"(d.pl), "s"(d.w), "s"(d.acc_init), "s"(d.mult), "s"(d.bias), "s"(d.out));
+    asm volatile("" ::"s"(q.out_zp), "s"(q.out_zp_f), "s"(q.clamp_lo), "s"(q.clamp_hi), "s"(d.out_zp), "s"(d.out_zp_f), "s"(d.clamp_lo),
+                 "s"(d.clamp_hi), "s"(d.in_zp), "s"(d.Ho), "s"(d.Wo), "s"(d.H), "s"(d.W), "s"(d.C));
     const int tid = threadIdx.x;
     int32_t *w_lds = reinterpret_cast<int32_t *>(smem);               // [7][32] dwords of 4 consecutive k
     int32_t *t_tab = w_lds + 7 * 32;                                  // stem [acc_init | mult | bias][32]
@@ -125,6 +132,7 @@ static bool stemdw_geometry(const ConvArgs &q, const ConvArgs &d, StemDwArgs &f)
     if (d.Kh != 3 || d.Kw != 3 || d.dh != 1 || d.dw != 1 || d.C != 32 || d.Co != 32) return false;
     if (d.H != q.Ho || d.W != q.Wo || d.N != q.N || d.sh < 1 || d.sh > 2 || d.sw < 1 || d.sw > 2) return false;
     if (d.pt < 0 || d.pl < 0 || d.pt > 2 || d.pl > 2) return false;
+    if ((int64_t)d.Ho * d.Wo * d.C >= ((int64_t)1 << 31)) return false;  // 32-bit offsets inside an output image (dw_patch.h)
     f.bh = d.Ho < 2 ? d.Ho : 2;
     f.bw = d.Wo < 28 ? d.Wo : 28;
     if (const char *e = getenv("SHL_MI355X_STEMDW_TILE")) {  // "<bh>x<bw>": tuning override
