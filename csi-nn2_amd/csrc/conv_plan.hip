@@ -505,7 +505,7 @@ static int plan_create_impl(const struct shl_mi355x_conv_desc *desc, const void 
         }
         else
             p->kernel_name = i8 ? "conv_igemm_tile_i8_mfma32x32x32" : "conv_igemm_tile_f16_mfma32x32x16";
-        if (i8 && d.layout == SHL_MI355X_NHWC) {  // pointwise at bandwidth-bound sizes (conv1x1_stream.hip)
+        if (i8 && d.layout == SHL_MI355X_NHWC && !igemm_env_override()) {  // pointwise forms of their own (launch_conv_igemm asks them first unless a family is forced)
             probe.w_frag = &probe;  // the copy is made below for exactly these shapes
             probe.div_exact = i8_div_exact, probe.div_fma = i8_div_fma, probe.act = d.act;
             {

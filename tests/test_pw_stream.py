@@ -45,7 +45,8 @@ for i, kw in enumerate(SHAPES):
 
 
 def run(force):
-    env = dict(os.environ, SHL_MI355X_PWSTREAM=force, SHL_MI355X_TUNE="0")   # a kernel A/B: the selection is forced, not measured
+    # a kernel A/B: the selection is forced, not measured (and the latency form of small maps, conv1x1_latency.hip, stays out of it)
+    env = dict(os.environ, SHL_MI355X_PWSTREAM=force, SHL_MI355X_TUNE="0", SHL_MI355X_PWLAT="0")
     res = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
                          timeout=600, env=env)
     rows = [l.split() for l in res.stdout.splitlines() if l.startswith("CASE")]
