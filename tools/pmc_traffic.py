@@ -44,6 +44,8 @@ FOLD = [  # (substring of the demangled kernel function, dtype marker, plan kern
     ("dwpw_fused_kernel", "dwpw_fused_i8"),
     ("dwpw_stream_kernel", "dwpw_stream_i8"),
     ("conv1x1_resident_kernel", "conv1x1_resident_i8_mfma32x32x32"),
+    ("conv1x1_latency_kernel", "conv1x1_latency_i8_mfma32x32x32"),
+    ("dwpw_resident_kernel", "dwpw_resident_i8"),
     ("pwdw_f16_nchw_kernel", "pwdw_f16_nchw"),
     ("stemdw_f16_nchw_kernel", "stemdw_f16_nchw"),
     ("conv_group_direct_kernel", "conv_group_direct"),
