@@ -457,7 +457,7 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         SHL_HIP(hipGetLastError());                                                                                     \
         return SHL_MI355X_OK;                                                                                           \
     }
-    static const char *nofix = getenv("SHL_MI355X_PWDW_GENERIC");  // "1": the run-time form everywhere (A/B, tests)
+    const char *nofix = getenv("SHL_MI355X_PWDW_GENERIC");  // "1": the run-time form everywhere (A/B, tests; read per call)
     if (!(nofix && nofix[0] == '1')) {
         SHL_PWDW_FIXED(4, 4, 2)
         SHL_PWDW_FIXED(4, 4, 1)
