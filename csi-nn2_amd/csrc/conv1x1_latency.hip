@@ -121,7 +121,7 @@ static bool lat_shape(const ConvArgs &a)
 bool conv1x1_latency_pick(const ConvArgs &a)
 {
     if (!lat_shape(a)) return false;
-    static const char *env = getenv("SHL_MI355X_PWLAT");  // "0" never, "1" whenever the shape qualifies (A/B, tests)
+    const char *env = getenv("SHL_MI355X_PWLAT");  // "0" never, "1" whenever the shape qualifies (A/B, tests; read per call)
     if (env && env[0] == '0') return false;
     if (env && env[0] == '1') return true;
     return (int64_t)(a.Co >> 5) * a.N <= 256;  // one round of workgroups (the tuner measures it against the other families)
