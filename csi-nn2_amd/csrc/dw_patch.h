@@ -1,9 +1,13 @@
 // dw_patch.h -- depthwise 3x3 (int8, 32 channels) from an int8 patch [pixel][32 B] in LDS: the second
 // phase of the latency-form fused kernels (pwdw_fused.hip, stemdw_fused.hip).
 //
-// Patch layout: pixel j = r * rw + c of the rectangle's input patch, 8 dwords (4 channels each); the dword
-// of channel group g sits at index g ^ ((j >> 2) & 7) so that both the producer's stores (32 pixels
-// x one group) and the reads below (8 groups x 4 pixels per 32 lanes) are bank-conflict free.
+// Patch layout (round 6): eight PLANES of dwords, plane g = channels 4 g .. 4 g + 3 of every patch pixel j = r * rw + c, `pitch`
+// dwords apart (a multiple of 32, + 8).  The producer's stores (32 consecutive pixels of one group) are consecutive dwords; a
+// reader's nine taps are three row bases + the immediate offsets 0 / 4 / 8 bytes (x sw).  It replaced [pixel][8 dwords] with the
+// dword index XOR-swizzled by the pixel: conflict-free both ways, but six address instructions per tap -- 54 of the depthwise
+// phase's ~95 instructions per thread, in kernels whose duration is one wave's instruction count (profiles/r06_notes.md); the
+// two-way bank conflicts of this layout cost a few cycles on nine reads.  Patch pixels OUTSIDE the image hold the depthwise
+// layer's input zero point (the producer writes it): the reader tests nothing.
 #pragma once
 
 #include "common.h"
@@ -11,11 +15,17 @@
 namespace shl {
 
 // where the producer phase must put channel group `group` (0..7) of patch pixel j
-__device__ __forceinline__ int dw_patch_slot(int j, int group) { return j * 8 + (group ^ ((j >> 2) & 7)); }
+__device__ __forceinline__ int dw_patch_slot(int j, int group, int pitch) { return group * pitch + j; }
+// plane pitch in dwords for a patch of npx pixels, and the bytes of the whole patch
+__host__ __device__ __forceinline__ int dw_patch_pitch(int npx) { return ((npx + 31) & ~31) + 8; }
+__host__ __device__ __forceinline__ size_t dw_patch_bytes(int npx) { return (size_t)dw_patch_pitch(npx) * 32; }
+// what the producer stores for a patch pixel outside the image
+__device__ __forceinline__ uint32_t dw_patch_pad(const ConvArgs &d) { return (uint32_t)(d.in_zp & 0xff) * 0x01010101u; }
 
 struct DwPatchGeom {
     int bh, bw;         // output rectangle of the workgroup
     int rw;             // patch width in pixels
+    int pitch;          // plane pitch in dwords (dw_patch_pitch)
     uint32_t bw_magic;  // po / bw == (po * bw_magic) >> 20 for po < 4096
     int oy0, ox0;       // first output pixel of the rectangle
     int ry0, rx0;       // patch origin in the depthwise layer's input image (may be negative: padding)
@@ -57,7 +67,6 @@ __device__ __forceinline__ void depthwise_from_patch(const ConvArgs &d, const ui
     const uint4 w0 = k.w0, w1 = k.w1, w2 = k.w2;
     const int4 d_ai = k.ai;
     const float4 d_mu = k.mu, d_bi = k.bi;
-    const uint32_t zp4 = (uint32_t)(d.in_zp & 0xff) * 0x01010101u;
     const uint32_t wk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
     const int nout = g.bh * g.bw;
     int8_t *const out_img = static_cast<int8_t *>(d.out) + (int64_t)g.n * d.Ho * d.Wo * d.C;
@@ -67,15 +76,11 @@ __device__ __forceinline__ void depthwise_from_patch(const ConvArgs &d, const ui
         const int oy = g.oy0 + oyl, ox = g.ox0 + oxl;
         if (oy >= d.Ho || ox >= d.Wo) continue;
         uint32_t iv[9];
+        const uint32_t *p00 = patch + cg * g.pitch + (oyl * d.sh) * g.rw + oxl * d.sw;  // tap (0, 0)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int r = oyl * d.sh + ky, c = oxl * d.sw + kx;
-                const bool ok = (unsigned)(g.ry0 + r) < (unsigned)d.H && (unsigned)(g.rx0 + c) < (unsigned)d.W;
-                const uint32_t v = patch[dw_patch_slot(r * g.rw + c, cg)];
-                iv[ky * 3 + kx] = ok ? v : zp4;
-            }
+            for (int kx = 0; kx < 3; ++kx) iv[ky * 3 + kx] = p00[ky * g.rw + kx];
         const uint32_t r0[4] = {iv[0], iv[1], iv[2], iv[3]}, r1[4] = {iv[4], iv[5], iv[6], iv[7]};
         uint32_t t0[4], t1[4];
         transpose4x4_bytes(r0, t0);  // t0[ch] = taps 0..3 of channel ch

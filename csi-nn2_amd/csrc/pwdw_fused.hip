@@ -226,6 +226,14 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     // overlaps (the patch writes also keep the compiler from moving the next tile's reads up): 71.0 - 71.2 -> 70.5 - 70.9 us
     // per MobileNetV1 pass.  (Four tiles per round through small arrays: 74.7 us -- the code grew more than the chain shrank.)
     {
+        // patch pixels outside the image take the depthwise layer's input zero point (dw_patch.h: the reader tests nothing)
+        const int ppitch = dw_patch_pitch(f.npx);
+        const uint32_t zpad = dw_patch_pad(d);
+        auto in_image = [&](int j) {
+            const int r = (int)(((uint32_t)j * f.rw_magic) >> 20);
+            const int c = j - r * f.rw;
+            return (unsigned)(ry0 + r) < (unsigned)q.H && (unsigned)(rx0 + c) < (unsigned)q.W;
+        };
         const int tstep = nwaves >> 2;
         for (int tile = FIXED ? 0 : wave >> 2; tile < mt; tile += 2 * tstep) {  // (four waves: wave >> 2 = 0)
             const int tile1 = tile + tstep;
@@ -241,13 +249,13 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
                 const uint32_t pk0 = requant4_i8_sel<EPQ>(v0[0] + p_ai.x, v0[1] + p_ai.y, v0[2] + p_ai.z, v0[3] + p_ai.w, p_mu, p_bi, q);
                 const uint32_t pk1 = requant4_i8_sel<EPQ>(v1[0] + p_ai.x, v1[1] + p_ai.y, v1[2] + p_ai.z, v1[3] + p_ai.w, p_mu, p_bi, q);
                 const int j1 = tile1 * 32 + frow;
-                if (j0 < f.npx) patch[dw_patch_slot(j0, 2 * fgrp + fhalf)] = pk0;
-                if (j1 < f.npx) patch[dw_patch_slot(j1, 2 * fgrp + fhalf)] = pk1;
+                if (j0 < f.npx) patch[dw_patch_slot(j0, 2 * fgrp + fhalf, ppitch)] = in_image(j0) ? pk0 : zpad;
+                if (j1 < f.npx) patch[dw_patch_slot(j1, 2 * fgrp + fhalf, ppitch)] = in_image(j1) ? pk1 : zpad;
             } else {  // the odd last tile alone (it used to be computed twice: ~50 instructions of a wave that issues one per ~5.8 cycles)
 #pragma unroll
                 for (int k = 1; k < ks; ++k) v0 += part[((tile * ks + k) * 4 + fgrp) * 64 + lane];
                 const uint32_t pk0 = requant4_i8_sel<EPQ>(v0[0] + p_ai.x, v0[1] + p_ai.y, v0[2] + p_ai.z, v0[3] + p_ai.w, p_mu, p_bi, q);
-                if (j0 < f.npx) patch[dw_patch_slot(j0, 2 * fgrp + fhalf)] = pk0;
+                if (j0 < f.npx) patch[dw_patch_slot(j0, 2 * fgrp + fhalf, ppitch)] = in_image(j0) ? pk0 : zpad;
             }
         }
     }
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     if (q.debug & 1024) return;  // ablation: stop after the pointwise epilogue
     // ---- depthwise 3x3 on the slice's 32 channels, from the LDS patch (dw_patch.h)
     DwPatchGeom g;
-    g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic;
+    g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic, g.pitch = dw_patch_pitch(f.npx);
     g.oy0 = oy0, g.ox0 = ox0, g.ry0 = ry0, g.rx0 = rx0, g.n = n, g.ch0 = slice * 32;
     depthwise_from_patch<EPD>(d, patch, g, dwk, tid, nwaves * 64);
 }
@@ -307,7 +315,7 @@ static bool choose_rect(const ConvArgs &q, const ConvArgs &d, PwDwArgs &f)
             const int npx = rh * rw;
             const int mt = (npx + 31) / 32;
             if (mt > mt_max || rw > 256 || bw > 256 || npx >= 4096 || bh * bw >= 4096) continue;
-            if ((size_t)mt * ks * 4096 + (size_t)mt * 1024 > 96 * 1024) continue;  // partial sums + patch in LDS
+            if ((size_t)mt * ks * 4096 + dw_patch_bytes(npx) > 96 * 1024) continue;  // partial sums + patch in LDS
             const int64_t blocks = slices * ((d.Ho + bh - 1) / bh) * ((d.Wo + bw - 1) / bw) * d.N;
             // Measured on MobileNetV1 at batch 1 (tools/pair_bench.py --sweep, profiles/r01_notes.md): what
             // a rectangle costs is the bytes its CU has to pull through its L1 -- (mt pixel tiles + 1
@@ -412,7 +420,7 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         const int rpg = 8 / f.xg;
         grid = dim3((unsigned)(8 * f.spg * ((f.nrect + rpg - 1) / rpg)), 1, 1);
     }
-    size_t lds = (size_t)f.mt * f.ks * 4096 + (size_t)f.mt * 32 * 32;
+    size_t lds = (size_t)f.mt * f.ks * 4096 + dw_patch_bytes(f.npx);
     {
         static const char *pr = getenv("SHL_MI355X_PWDW_PRINT");  // "1": the geometry of every launch (tools/dev)
         if (pr && pr[0] == '1')
@@ -449,7 +457,7 @@ int launch_pwdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
 #define SHL_PWDW_FIXED(NSWV, KSV, TPWV)                                                                                  \
     if (f.nwaves == 4 && f.nsw == NSWV && f.nsub == KSV * NSWV && f.ks == KSV && f.mt <= TPWV * (4 / KSV) &&            \
         f.mt > (TPWV - 1) * (4 / KSV)) {                                                                                \
-        lds = (size_t)(TPWV * (4 / KSV)) * f.ks * 4096 + (size_t)f.mt * 32 * 32; /* partial sums of the padded tiles */  \
+        lds = (size_t)(TPWV * (4 / KSV)) * f.ks * 4096 + dw_patch_bytes(f.npx); /* partial sums of the padded tiles */    \
         if (f.mt == TPWV * (4 / KSV))                                                                                   \
             SHL_PWDW_EPI(TPWV, NSWV, KSV, true);                                                                        \
         else                                                                                                            \

@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
     const int8_t *img = static_cast<const int8_t *>(q.in) + (int64_t)n * q.H * q.W * 3;
     // input bytes first (global latency), then the barrier that publishes weights and tables
     const int ntasks = 2 * f.npx;
+    const int ppitch = dw_patch_pitch(f.npx);
+    const uint32_t zpad = dw_patch_pad(d);
     for (int base = 0; base < ntasks; base += 256) {  // uniform trip count: the barrier below is safe
         const bool valid = base + tid < ntasks;
         const int task = valid ? base + tid : ntasks - 1;
@@ -114,14 +116,14 @@ __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
             const float4 bi = *reinterpret_cast<const float4 *>(t_tab + 64 + c);
             const uint32_t pk = requant4_i8_sel<EPQ>(acc[4 * v] + ai.x, acc[4 * v + 1] + ai.y, acc[4 * v + 2] + ai.z,
                                                acc[4 * v + 3] + ai.w, mu, bi, q);
-            if (valid) patch[dw_patch_slot(j, c >> 2)] = pk;
+            if (valid) patch[dw_patch_slot(j, c >> 2, ppitch)] = inside ? pk : zpad;  // (outside the image: the depthwise layer's padding value)
         }
     }
     __syncthreads();
 
     // ---- phase 2: depthwise 3x3 from the patch (dw_patch.h)
     DwPatchGeom g;
-    g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic;
+    g.bh = f.bh, g.bw = f.bw, g.rw = f.rw, g.bw_magic = f.bw_magic, g.pitch = ppitch;
     g.oy0 = oy0, g.ox0 = ox0, g.ry0 = ry0, g.rx0 = rx0, g.n = n, g.ch0 = 0;
     depthwise_from_patch<EPD>(d, patch, g, dwk, tid, 256);
 }
@@ -166,7 +168,7 @@ int launch_stemdw_fused(const ConvArgs &q, const ConvArgs &d, hipStream_t s)
         return SHL_MI355X_ENOTSUP;
     }
     const dim3 grid((unsigned)f.tiles_x, (unsigned)(f.tiles_y * d.N));
-    const size_t lds = (size_t)(7 * 32 + 96) * 4 + (size_t)f.npx * 32;
+    const size_t lds = (size_t)(7 * 32 + 96) * 4 + dw_patch_bytes(f.npx);
     const int epq = (q.act != SHL_MI355X_ACT_NONE && !q.act_clamp) ? -1 : (q.div_exact ? 3 : 0);
     const int epd = (d.act != SHL_MI355X_ACT_NONE && !d.act_clamp) ? -1 : (d.div_exact ? 3 : 0);
     if (epq == 3 && epd == 3) hipLaunchKernelGGL((stemdw_fused_kernel<3, 3>), grid, dim3(256), lds, s, f);
