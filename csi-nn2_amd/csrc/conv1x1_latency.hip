@@ -38,6 +38,7 @@ __global__ __launch_bounds__(512) void conv1x1_latency_kernel(ConvArgs a, LatPoo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fhalf = lane >> 5;
     const int slice = blockIdx.x, n = blockIdx.y;
+    const int t0 = blockIdx.z;  // first pixel tile of this workgroup (the tiles of an image may be dealt to two workgroups)
     const int HW = a.Ho * a.Wo;
     constexpr int NSUB = 8 * NSW;  // K sub-steps in all = C / 32
     const int sub0 = wave * NSW;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(512) void conv1x1_latency_kernel(ConvArgs a, LatPoo
     v4i fb[MT][NSW];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        const int p = min(t * 32 + frow, HW - 1);
+        const int p = min((t0 + t) * 32 + frow, HW - 1);
         const char *px = img + p * a.C;
 #pragma unroll
         for (int s = 0; s < NSW; ++s) fb[t][s] = *reinterpret_cast<const v4i *>(px + s * 32);
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(512) void conv1x1_latency_kernel(ConvArgs a, LatPoo
 #pragma unroll
         for (int k = 1; k < 8; ++k) v += part[((ftile * 8 + k) * 4 + fgrp) * 64 + lane];
         const uint32_t pk = requant4_i8_sel<EPI>(v[0] + p_ai.x, v[1] + p_ai.y, v[2] + p_ai.z, v[3] + p_ai.w, p_mu, p_bi, a);
-        const int p = ftile * 32 + frow;
+        const int p = (t0 + ftile) * 32 + frow;
         if (p < HW) {
             if (!POOL || pl.store_map) *reinterpret_cast<uint32_t *>(static_cast<char *>(a.out) + ((int64_t)n * HW + p) * a.Co + pc) = pk;
             if constexpr (POOL) pmap[p * 8 + 2 * fgrp + fhalf] = pk;
@@ -131,9 +132,14 @@ bool conv1x1_pool_fusable(const ConvArgs &a) { return lat_shape(a) && (int64_t)(
 
 static int launch_lat(const ConvArgs &a, const LatPoolArgs &pl, hipStream_t s)
 {
-    const int HW = a.Ho * a.Wo, mt = HW > 32 ? 2 : 1, nsw = a.C / 256, epi = lat_epi(a);
+    const int HW = a.Ho * a.Wo, nsw = a.C / 256, epi = lat_epi(a);
     const bool pool = pl.out != nullptr;
-    const dim3 grid((unsigned)(a.Co >> 5), (unsigned)a.N);
+    int mt = HW > 32 ? 2 : 1, zsplit = 1;
+    // two pixel tiles and few workgroups: one tile per workgroup (twice the workgroups fetch the weights, each wave runs half the
+    // loads, MFMAs and LDS writes; the pooling form needs the whole map in one workgroup)
+    const char *sp = getenv("SHL_MI355X_PWLAT_SPLIT");  // "0": never (A/B)
+    if (!pool && mt == 2 && (int64_t)(a.Co >> 5) * a.N * 2 <= 256 && !(sp && sp[0] == '0')) mt = 1, zsplit = 2;
+    const dim3 grid((unsigned)(a.Co >> 5), (unsigned)a.N, (unsigned)zsplit);
     const size_t lds = (size_t)mt * 8 * 4096 + (pool ? (size_t)HW * 32 : 0);
 #define SHL_LAT4(NSWV, MTV, EPIV, POOLV)                                                                      \
     do {                                                                                                      \
