@@ -12,36 +12,42 @@
 //
 // Replaces shl_ref_fullyconnected_f32 (source/reference/fullyconnected.c:21-52) and the 1x1 case of
 // shl_ref_conv2d_nhwc_f32 (convolution.c:28-89) inside their *_quant wrappers.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace shl {
 
 constexpr int GEMV_OPW = 4;  // output channels per wave
 
-template <bool kI8>
+// OPW: output channels per wave -- 4, or 2 where that still is one round of workgroups (round 6: twice the waves stream the
+// weights, each with half the loads and half the butterflies in its instruction stream: MobileNetV1's classifier at batch 1)
+template <bool kI8, int OPW>
 __global__ __launch_bounds__(256) void conv_gemv_kernel(ConvArgs a)
 {
     constexpr int ESIZE = kI8 ? 1 : 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = blockIdx.y;
-    const int oc0 = (blockIdx.x * 4 + wave) * GEMV_OPW;
+    const int oc0 = (blockIdx.x * 4 + wave) * OPW;
     if (oc0 >= a.Co) return;  // wave-uniform
     const int kb = a.C * ESIZE;
     const char *in = static_cast<const char *>(a.in) + (int64_t)p * kb;
     const char *w = static_cast<const char *>(a.w);
-    int32_t acc_i[GEMV_OPW] = {0, 0, 0, 0};
-    float acc_f[GEMV_OPW] = {0.f, 0.f, 0.f, 0.f};
+    int32_t acc_i[OPW];
+    float acc_f[OPW];
+#pragma unroll
+    for (int o = 0; o < OPW; ++o) acc_i[o] = 0, acc_f[o] = 0.f;
     for (int off = lane * 16; off < kb; off += 1024) {
         const v4i x = *reinterpret_cast<const v4i *>(in + off);
-        v4i wv[GEMV_OPW];
+        v4i wv[OPW];
 #pragma unroll
-        for (int o = 0; o < GEMV_OPW; ++o) {
+        for (int o = 0; o < OPW; ++o) {
             const int oc = oc0 + o < a.Co ? oc0 + o : a.Co - 1;
             wv[o] = *reinterpret_cast<const v4i *>(w + (int64_t)oc * a.kstride + off);
         }
 #pragma unroll
-        for (int o = 0; o < GEMV_OPW; ++o)
+        for (int o = 0; o < OPW; ++o)
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 if constexpr (kI8) {
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_gemv_kernel(ConvArgs a)
             }
     }
 #pragma unroll
-    for (int o = 0; o < GEMV_OPW; ++o)
+    for (int o = 0; o < OPW; ++o)
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) {
             if constexpr (kI8)
@@ -65,10 +71,12 @@ __global__ __launch_bounds__(256) void conv_gemv_kernel(ConvArgs a)
             else
                 acc_f[o] += __shfl_xor(acc_f[o], s, 64);
         }
-    if (lane < GEMV_OPW && oc0 + lane < a.Co) {
+    if (lane < OPW && oc0 + lane < a.Co) {
         const int oc = oc0 + lane;
-        const int32_t S = lane == 0 ? acc_i[0] : lane == 1 ? acc_i[1] : lane == 2 ? acc_i[2] : acc_i[3];
-        const float F = lane == 0 ? acc_f[0] : lane == 1 ? acc_f[1] : lane == 2 ? acc_f[2] : acc_f[3];
+        int32_t S = acc_i[0];
+        float F = acc_f[0];
+#pragma unroll
+        for (int o = 1; o < OPW; ++o) S = lane == o ? acc_i[o] : S, F = lane == o ? acc_f[o] : F;
         if constexpr (kI8) {
             static_cast<int8_t *>(a.out)[(int64_t)p * a.Co + oc] =
                 (int8_t)requant_i8_fast(S + a.acc_init[oc], a.mult[oc], a.bias[oc], a);
@@ -196,11 +204,17 @@ bool conv_gemv_pick(const ConvArgs &a, int esize)
 
 int launch_conv_gemv(const ConvArgs &a, int dtype, hipStream_t s)
 {
-    const dim3 grid((unsigned)((a.Co + 4 * GEMV_OPW - 1) / (4 * GEMV_OPW)), (unsigned)a.M);
-    if (dtype == SHL_MI355X_I8)
-        hipLaunchKernelGGL(conv_gemv_kernel<true>, grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(conv_gemv_kernel<false>, grid, dim3(256), 0, s, a);
+    const char *env = getenv("SHL_MI355X_GEMV_OPW");  // "4": the four-channel form always (A/B)
+    const bool two = (int64_t)((a.Co + 7) / 8) * a.M <= 256 && !(env && env[0] == '4');
+    const int opw = two ? 2 : GEMV_OPW;
+    const dim3 grid((unsigned)((a.Co + 4 * opw - 1) / (4 * opw)), (unsigned)a.M);
+    if (dtype == SHL_MI355X_I8) {
+        if (two) hipLaunchKernelGGL((conv_gemv_kernel<true, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemv_kernel<true, GEMV_OPW>), grid, dim3(256), 0, s, a);
+    } else {
+        if (two) hipLaunchKernelGGL((conv_gemv_kernel<false, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemv_kernel<false, GEMV_OPW>), grid, dim3(256), 0, s, a);
+    }
     SHL_HIP(hipGetLastError());
     return SHL_MI355X_OK;
 }
