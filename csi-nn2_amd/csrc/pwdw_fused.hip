@@ -18,7 +18,7 @@
 //      both contiguous 16-byte pieces per lane -- then v_mfma_i32_32x32x32_i8.
 //   2. partial sums meet in LDS; wave w finishes register group w (channels 8w + 4 half .. +3) of
 //      every tile: + acc_init, pointwise requantisation (+ relu), one dword into the LDS patch
-//      [pixel][32 B] (dword index XOR-swizzled with the pixel so stores and loads are conflict-free).
+//      as eight dword planes [channel quad][pixel] (dw_patch.h; pixels outside the image get the depthwise layer's padding value).
 //   3. depthwise: thread = (output pixel, 4 channels): nine dwords from the LDS patch (the padding
 //      value for taps outside the image), byte transposes + v_dot4_i32_i8 against the depthwise
 //      plan's packed weights, depthwise requantisation (+ relu), one dword to HBM.
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(MAXT) void pwdw_fused_kernel(PwDwArgs f)
     if (q.debug & 256) return;  // ablation (tools/pair_bench.py): stop after loads + MFMA
     // ---- partial sums -> LDS: part[((tile * ks + kpart) * 4 + group) * 64 + lane] = 4 channels
     v4i *part = reinterpret_cast<v4i *>(smem);
-    uint32_t *patch = reinterpret_cast<uint32_t *>(smem + (size_t)mtp * ks * 4096);  // [pixel][8 dwords]
+    uint32_t *patch = reinterpret_cast<uint32_t *>(smem + (size_t)mtp * ks * 4096);  // eight dword planes (dw_patch.h)
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int tile = mw + i * mwn;

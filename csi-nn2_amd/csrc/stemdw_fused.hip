@@ -6,7 +6,7 @@
 //   phase 1    the stem layer on the rectangle's input patch (+ one-pixel halo): a thread owns one patch
 //              pixel x 16 channels, exactly as conv_stem.hip does (27 input bytes packed into 7 dwords,
 //              weights [k/4][32] in LDS, v_dot4_i32_i8, the stem's requantisation) and leaves the int8
-//              result in an LDS patch [pixel][32 B]; patch pixels outside the image are never read
+//              result in an LDS patch of eight dword planes (dw_patch.h); patch pixels outside the image get the padding value
 //   phase 2    the depthwise layer from the patch: dw_patch.h, shared with pwdw_fused.hip (thread = output
 //              pixel x 4 channels, byte transposes + v_dot4_i32_i8 against the dot4-packed weights)
 // Bit-identical to the two stand-alone launches.  Restates shl_ref_conv2d_quant followed by
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void stemdw_fused_kernel(StemDwArgs f)
     const int tid = threadIdx.x;
     int32_t *w_lds = reinterpret_cast<int32_t *>(smem);               // [7][32] dwords of 4 consecutive k
     int32_t *t_tab = w_lds + 7 * 32;                                  // stem [acc_init | mult | bias][32]
-    uint32_t *patch = reinterpret_cast<uint32_t *>(t_tab + 96);       // [pixel][8 dwords], swizzled
+    uint32_t *patch = reinterpret_cast<uint32_t *>(t_tab + 96);       // eight dword planes (dw_patch.h)
     if (tid < 224) w_lds[tid] = static_cast<const int32_t *>(q.w)[tid];
     if (tid < 96) {
         const int which = tid >> 5, i = tid & 31;
